@@ -1,0 +1,309 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by IMPORTING the reference (build container only).
+
+    python oracle/gen_golden.py            # writes tests/golden/*.npz
+
+The reference (/root/reference, read-only) is a Python package; it is imported here, driven
+exactly as its own entry point drives it, and only DATA (inputs / expected outputs / checksums)
+is written to tests/golden/.  No reference source travels.  /root/reference does not exist on the
+GPU box; nothing under tests/ -m gpu, smoke() or bench.py runs this script.
+
+What is restated from the reference's driver (it cannot be imported: it needs torchvision,
+pytorchcv and CUDA at import / model build time, /root/reference/fix_train.py:22,38,269):
+  * flag broadcast onto the QAT modules        fix_train.py:270-295
+  * int_op_only conversion                      fix_train.py:930-934
+  * input quantisation                          fix_train.py:683-692
+One shim: torch>=2 refuses `param.data = int_tensor` on a grad-requiring Parameter
+(fix_quant_ops.py:705-706 worked on the pinned torch 1.11), so new Conv2d/Linear parameters are
+created with requires_grad=False while `int_model()` runs.  No reference file is modified.
+
+One yml per process (the reference's FLAGS is an import-time singleton, myutils/config.py:152-178),
+so this script re-executes itself per model with `--child`.
+"""
+import argparse
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+GOLD = os.path.join(REPO, 'tests', 'golden')
+
+YMLS = {
+    'resnet18': 'apps/imagenet/resnet18/conventional/res18_fix_quant_test_int_op_only.yml',
+    'resnet50': 'apps/imagenet/resnet50/tiny_finetuning/res50_fix_quant_nvidia_pretrained_test_int_op_only_on_cpu.yml',
+    'mobilenet_v1': 'apps/imagenet/mobilenetv1/conventional/mbv1_fix_quant_test_int_op_only_on_cpu.yml',
+    'mobilenet_v2': 'apps/imagenet/mobilenetv2/conventional/mbv2_fix_quant_test_int_op_only_on_cpu.yml',
+}
+
+
+def checksum(a: np.ndarray):
+    """(plain sum, position-weighted sum) in wrapping int64 — order- and value-sensitive."""
+    v = np.ascontiguousarray(a).reshape(-1).astype(np.int64)
+    with np.errstate(over='ignore'):
+        wgt = (np.arange(v.size, dtype=np.int64) % 65521) + 1
+        return np.array([v.sum(), (v * wgt).sum()], dtype=np.int64)
+
+
+# --------------------------------------------------------------------------- child: one model
+
+def build_reference_int_model(arch):
+    import torch
+    import torch.nn as nn
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    sys.argv = ['gen_golden', f'app:{os.path.join(REF, YMLS[arch])}', 'bs:1']
+    from myutils.config import FLAGS
+    model_lib = importlib.import_module(FLAGS.model)
+    from models.fix_quant_ops import ReLUClipFXQConvBN, ReLUClipFXQLinear
+    torch.manual_seed(0)
+    model = model_lib.Model(FLAGS.num_classes)
+    # -- fix_train.py:270-295
+    for m in model.modules():
+        if isinstance(m, (ReLUClipFXQConvBN, ReLUClipFXQLinear)):
+            m.set_weight_format(FLAGS.weight_format)
+            m.set_input_format(FLAGS.input_format)
+            m.rescale_type = getattr(FLAGS, 'rescale_type', 'constant')
+            m.set_alpha()
+            m.floating = getattr(FLAGS, 'floating_model', False)
+            m.floating_wo_clip = getattr(FLAGS, 'floating_wo_clip', False)
+            m.format_type = getattr(FLAGS, 'format_type', None)
+            m.format_from_metric = getattr(FLAGS, 'format_from_metric', False)
+            m.metric = getattr(FLAGS, 'metric', None)
+            m.format_grid_search = getattr(FLAGS, 'format_grid_search', False)
+            m.set_metric_func()
+            m.register_input_format(FLAGS.input_format,
+                                    momentum=getattr(FLAGS, 'momentum_for_metric', 0.1))
+            m.no_clipping = getattr(FLAGS, 'no_clipping', False)
+            m.input_fraclen_sharing = getattr(FLAGS, 'input_fraclen_sharing', False)
+            m.quant_bias = getattr(FLAGS, 'quant_bias', False)
+            m.int_infer = getattr(FLAGS, 'int_infer', False)
+        if isinstance(m, ReLUClipFXQConvBN):
+            m.rescale_forward = getattr(FLAGS, 'rescale_forward_conv', False)
+        if isinstance(m, ReLUClipFXQLinear):
+            m.rescale_forward = getattr(FLAGS, 'rescale_forward', True)
+    model.eval()
+    # -- fix_train.py:930-934 with the requires_grad shim
+    orig_conv, orig_lin = nn.Conv2d.__init__, nn.Linear.__init__
+
+    def conv_init(self, *a, **k):
+        orig_conv(self, *a, **k)
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    def lin_init(self, *a, **k):
+        orig_lin(self, *a, **k)
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    model.apply(lambda m: setattr(m, 'int_op_only', True))
+    nn.Conv2d.__init__, nn.Linear.__init__ = conv_init, lin_init
+    try:
+        with torch.no_grad():
+            int_model = model.int_model().cpu()
+    finally:
+        nn.Conv2d.__init__, nn.Linear.__init__ = orig_conv, orig_lin
+    int_model.apply(lambda m: setattr(m, 'int_op_only', True))
+    return int_model, FLAGS
+
+
+def child_model(arch):
+    import torch
+    import torch.nn as nn
+    sys.path.insert(0, REPO)
+    from f8net_amd import synth, topology
+    int_model, FLAGS = build_reference_int_model(arch)
+    normalize = bool(getattr(FLAGS, 'normalize', False))
+    spec = topology.get(arch, normalize=normalize)
+
+    # structural check: our topology table == the reference export
+    sd = int_model.state_dict()
+    ref_keys = sorted({k.rsplit('.', 1)[0] for k in sd})
+    assert ref_keys == sorted(spec.layer_keys()), (ref_keys, spec.layer_keys())
+    mods = dict(int_model.named_modules())
+    for c in spec.convs():
+        m = mods[c.key]
+        assert isinstance(m, nn.Conv2d)
+        assert (m.in_channels, m.out_channels, m.kernel_size[0], m.stride[0], m.padding[0], m.groups) == \
+            (c.cin, c.cout, c.k, c.stride, c.pad, c.groups), c.key
+        assert bool(m.input_symmetric) == c.signed_in, (c.key, m.input_symmetric)
+    assert bool(mods[spec.fc_key].input_symmetric) == spec.fc_signed_in
+
+    out = {}
+    fr = topology.R50_NVIDIA_FRACLENS if arch == 'resnet50' else None
+    for seed in (1234,):
+        params = synth.make_params(spec, seed=seed, fraclens=fr)
+        # overwrite the exported layers in place with our integers
+        with torch.no_grad():
+            for key in spec.layer_keys():
+                m = mods[key]
+                m.weight.data = torch.from_numpy(params[key + '.weight']).clone()
+                m.bias.data = torch.from_numpy(params[key + '.bias']).clone()
+                m.weight_fraclen.copy_(torch.from_numpy(params[key + '.weight_fraclen']))
+                m.input_fraclen.copy_(torch.from_numpy(params[key + '.input_fraclen']))
+        for hw, n in ((64, 2), (224, 1)):
+            x_np, x_fl = synth.make_input(spec, params, n, hw, seed=7)
+            caps = {}
+
+            def mk(name):
+                def hook(mod, inp, outp):
+                    caps[name] = checksum(outp.detach().numpy())
+                return hook
+            handles = []
+            for key in spec.layer_keys():
+                handles.append(mods[key].register_forward_hook(mk(key)))
+            for b in spec.blocks:
+                handles.append(mods[b.name].register_forward_hook(mk(b.name)))
+            x = torch.from_numpy(x_np)
+            setattr(x, 'output_fraclen', x_fl)
+            with torch.no_grad():
+                logits = int_model(x)
+            for h in handles:
+                h.remove()
+            tag = f's{seed}_hw{hw}_n{n}'
+            out[f'{tag}/logits'] = logits.numpy().astype(np.float32)
+            assert np.count_nonzero(out[f'{tag}/logits']) > 0.9 * logits.numel(), 'degenerate logits'
+            names = sorted(caps)
+            out[f'{tag}/cap_names'] = np.array(names)
+            out[f'{tag}/cap_sums'] = np.stack([caps[k] for k in names])
+    out['normalize'] = np.array(normalize)
+    np.savez_compressed(os.path.join(GOLD, f'net_{arch}.npz'), **out)
+    print(f'[gen_golden] {arch}: wrote net_{arch}.npz ({len(out)} arrays)')
+
+
+def child_ops():
+    """Op-level known answers from the reference's own functions / the torch ops it calls."""
+    import torch
+    import torch.nn as nn
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    sys.path.insert(0, REPO)
+    sys.argv = ['gen_golden', f'app:{os.path.join(REF, YMLS["resnet18"])}', 'bs:1']
+    from models.fix_quant_ops import int_op_only_fix_quant, FXQAvgPool2d, FXQMaxPool2d
+    from f8net_amd import synth
+    out = {}
+    # --- requant KATs (SURVEY.md App. B input vector + edge values + random)
+    kat_in = np.array([-13, -12, -11, -10, -9, -8, -7, -6, -5, -4, -3, -2, -1, 0, 1, 2, 3, 4, 5, 6, 7, 8,
+                       9, 10, 11, 12, 13, 2000, -2000, 1020, 1022, 1018], dtype=np.int32)
+    edge = np.array([2**31 - 1, -2**31, -2**31 + 1, 2**31 - 2, 2**30, -2**30, 2**30 - 1, 255, 256, 254,
+                     127, 128, -127, -128, 65535, -65536, 1 << 23, -(1 << 23)], dtype=np.int32)
+    rnd = synth.rand_normal_int(3, 'requant', (4096,), 30000.0).astype(np.int32)
+    rnd2 = synth.rand_uniform_int(4, 'requant2', (2048,), -2**31, 2**31 - 1).astype(np.int32)
+    vec = np.concatenate([kat_in, edge, rnd, rnd2])
+    out['requant/in'] = vec
+    cases = []
+    for signed in (True, False):
+        for dst_fl in range(0, 8 if signed else 9):
+            for src_fl in (0, 3, 5, 6, 8, 9, 11, 14, 19, 22):
+                if src_fl - dst_fl > 20 or src_fl - dst_fl < -6:
+                    continue
+                r = int_op_only_fix_quant(torch.from_numpy(vec.copy()), 8, dst_fl, src_fl, signed)
+                assert r.dtype == torch.int32 and r.output_fraclen == dst_fl
+                cases.append((dst_fl, src_fl, int(signed)))
+                out[f'requant/out_{dst_fl}_{src_fl}_{int(signed)}'] = r.numpy()
+    out['requant/cases'] = np.array(cases, dtype=np.int32)
+    # --- integer conv / linear exactly as the reference executes them: nn.Conv2d with int32 params
+    geoms = [  # (N, C, H, W, K, k, stride, pad, groups)
+        (2, 3, 17, 19, 8, 7, 2, 3, 1), (2, 16, 9, 9, 24, 3, 1, 1, 1), (1, 16, 10, 10, 8, 3, 2, 1, 1),
+        (2, 32, 7, 7, 16, 1, 1, 0, 1), (2, 32, 8, 8, 16, 1, 2, 0, 1), (2, 24, 9, 11, 24, 3, 1, 1, 24),
+        (1, 24, 10, 8, 24, 3, 2, 1, 24), (1, 3, 12, 12, 8, 3, 2, 1, 1),
+    ]
+    for gi, (N, C, H, W, K, k, s, p, g) in enumerate(geoms):
+        x = synth.rand_uniform_int(11, f'cx{gi}', (N, C, H, W), -127, 255).astype(np.int32)
+        w = synth.rand_uniform_int(12, f'cw{gi}', (K, C // g, k, k), -127, 127).astype(np.int32)
+        b = synth.rand_normal_int(13, f'cb{gi}', (K,), 5e4).astype(np.int32)
+        conv = nn.Conv2d(C, K, k, stride=s, padding=p, groups=g, bias=True)
+        conv.weight.requires_grad_(False)
+        conv.bias.requires_grad_(False)
+        conv.weight.data = torch.from_numpy(w)
+        conv.bias.data = torch.from_numpy(b)
+        with torch.no_grad():
+            y = conv(torch.from_numpy(x))
+        assert y.dtype == torch.int32
+        out[f'conv/{gi}/geom'] = np.array([N, C, H, W, K, k, s, p, g], dtype=np.int32)
+        out[f'conv/{gi}/x'], out[f'conv/{gi}/w'], out[f'conv/{gi}/b'] = x, w, b
+        out[f'conv/{gi}/y'] = y.numpy()
+    # wrap-around (conv(65536*65536) == 0)
+    conv = nn.Conv2d(1, 1, 1, bias=True)
+    for prm in conv.parameters():
+        prm.requires_grad_(False)
+    conv.weight.data = torch.full((1, 1, 1, 1), 65536, dtype=torch.int32)
+    conv.bias.data = torch.tensor([7], dtype=torch.int32)
+    with torch.no_grad():
+        out['conv/wrap_y'] = conv(torch.full((1, 1, 2, 2), 65537, dtype=torch.int32)).numpy()
+    x = synth.rand_uniform_int(21, 'lx', (3, 40), -127, 255).astype(np.int32)
+    w = synth.rand_uniform_int(22, 'lw', (10, 40), -127, 127).astype(np.int32)
+    b = synth.rand_normal_int(23, 'lb', (10,), 1e5).astype(np.int32)
+    fc = nn.Linear(40, 10)
+    for prm in fc.parameters():
+        prm.requires_grad_(False)
+    fc.weight.data, fc.bias.data = torch.from_numpy(w), torch.from_numpy(b)
+    with torch.no_grad():
+        y = fc(torch.from_numpy(x))
+    out['linear/x'], out['linear/w'], out['linear/b'], out['linear/y'] = x, w, b, y.numpy()
+    out['linear/y_float'] = y.float().numpy()
+    # --- pools
+    ap = FXQAvgPool2d(7)
+    ap.int_op_only = True
+    x = synth.rand_normal_int(31, 'ap', (2, 5, 7, 7), 3e5).astype(np.int32)
+    t = torch.from_numpy(x)
+    setattr(t, 'output_fraclen', 13)
+    r = ap(t)
+    out['avgpool/x'], out['avgpool/y'] = x, r.numpy()
+    out['avgpool/fl'] = np.array([13, r.output_fraclen], dtype=np.int32)
+    x = np.maximum(synth.rand_normal_int(32, 'mp', (2, 4, 11, 12), 2e5), 0).astype(np.int32)
+    mp = nn.MaxPool2d(3, 2, 1)
+    out['maxpool/x'] = x
+    out['maxpool/y'] = mp(torch.from_numpy(x).float()).int().numpy()          # fix_resnet.py:359
+    out['maxpool/y_fxq'] = FXQMaxPool2d(3, 2, 1)(torch.from_numpy(x)).numpy()  # quant_maxpool: True
+    # --- residual align-add (fix_resnet.py:40-54), run through torch ops as the reference does
+    a = synth.rand_normal_int(41, 'ra', (2, 6, 5, 5), 4e5).astype(np.int32)
+    bb = synth.rand_normal_int(42, 'rb', (2, 6, 5, 5), 4e5).astype(np.int32)
+    a.reshape(-1)[:4] = [2**31 - 1, -2**31, 2**30, -2**30]
+    bb.reshape(-1)[:4] = [1, -1, 2**30, -2**30]
+    out['add/res'], out['add/x'] = a, bb
+    for res_fl, x_fl in ((11, 9), (9, 12), (10, 10)):
+        res, x = torch.from_numpy(a.copy()), torch.from_numpy(bb.copy())
+        if res_fl > x_fl:
+            x = x << (res_fl - x_fl)
+            res += x
+        else:
+            res = res << (x_fl - res_fl)
+            res += x
+        res.clamp_(max=(1 << 31) - 1, min=-(1 << 31) + 1)
+        out[f'add/out_{res_fl}_{x_fl}'] = res.numpy()
+    # --- input quantisation (fix_train.py:683-692)
+    from models.fix_quant_ops import fix_quant
+    img = (synth.rand_uniform_int(51, 'img', (1, 3, 8, 8), 0, 1000).astype(np.float32) / 1000.0)
+    out['inq/img'] = img
+    out['inq/u8'] = (255 * torch.from_numpy(img.copy())).round_().int().numpy()
+    mean = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(1, 3, 1, 1)
+    std = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(1, 3, 1, 1)
+    xn = ((img - mean) / std).astype(np.float32)
+    fl = torch.tensor([5], dtype=torch.int32)
+    q = (fix_quant(torch.from_numpy(xn.copy()), 8, fl * 1.0, 1, True)[0] * (2 ** fl)).int()
+    out['inq/xn'], out['inq/s8_fl5'] = xn, q.numpy()
+    np.savez_compressed(os.path.join(GOLD, 'ops.npz'), **out)
+    print(f'[gen_golden] ops: wrote ops.npz ({len(out)} arrays)')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--child', default=None)
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    if args.child == 'ops':
+        child_ops()
+    elif args.child:
+        child_model(args.child)
+    else:
+        env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+        for c in ['ops'] + list(YMLS):
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), '--child', c], env=env)
+
+
+if __name__ == '__main__':
+    main()
