@@ -1,0 +1,13 @@
+#!/bin/bash
+# Builds libf8net.so (gfx950 only) in-tree: f8net_amd/libf8net.so
+set -e
+cd "$(dirname "$0")"
+OUT=../libf8net.so
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+mkdir -p ../../build
+$HIPCC $FLAGS -c f8_kernels.hip -o ../../build/f8_kernels.o &
+$HIPCC $FLAGS -x hip -c f8_net.cpp -o ../../build/f8_net.o &
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC ../../build/f8_kernels.o ../../build/f8_net.o -o $OUT
+echo "built $(readlink -f $OUT)"

@@ -1,0 +1,105 @@
+// f8_internal.h — kernel argument blocks and launchers shared by f8_kernels.hip and f8_net.cpp.
+// Not part of the ABI (include/f8net.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace f8 {
+
+// One requantised int8 output of an epilogue: int_op_only_fix_quant with n = src_fl - dst_fl.
+struct QuantOut {
+    int8_t* ptr;      // NHWC int8, row stride ld (bytes); nullptr = absent
+    int32_t n;        // shift (> 0 right with round-half-even, <= 0 left)
+    int32_t lo, hi;   // clamp bounds: [-127,127] or [0,255]
+};
+
+// Implicit-GEMM int8 convolution / linear on v_mfma_i32_32x32x32_i8.
+//   D[cout][pixel] = sum_k W[cout][k] * (X[pixel][k] ^ xor_mask)   (+ offset-corrected bias)
+// X rows are gathered from an NHWC int8 tensor: K runs over taps (r,s) then CK bytes per tap.
+struct ConvArgs {
+    const int8_t* x;  uint32_t x_bytes;
+    const int8_t* w;  uint32_t w_bytes;    // packed [coutP][ktot], K-contiguous
+    const int32_t* bias;                   // [coutP], offset-corrected (see pack_conv_weights)
+    int32_t M;                             // N*P*Q output pixels
+    int32_t PQ, Q;
+    int32_t sN, sP, sQ;                    // input byte strides: per image, per output row, per output col
+    int32_t origin;                        // byte offset of tap (0,0) at p=q=0 (negative with padding)
+    int32_t H, W, stride, pad, kh, kw;
+    int32_t CK;                            // bytes per tap (multiple of BK)
+    int32_t tapH, tapW;                    // byte offset per tap row / col
+    int32_t ktot;                          // kh*kw*CK
+    uint32_t xor_mask;                     // 0x80808080 for unsigned inputs, 0 for signed
+    int32_t coutP;                         // padded cout = row stride of NHWC outputs (elements)
+    // epilogue
+    int32_t relu0;                         // ReLU directly after the conv
+    const int32_t* res;                    // int32 NHWC residual operand or nullptr
+    int32_t acc_shl, res_shl;              // alignment shifts (one of them is 0)
+    int32_t relu1;                         // ReLU after the residual add
+    int32_t* out32;                        // NHWC int32 (stride coutP) or nullptr
+    QuantOut q[2];
+    // dense [M][ldo] float32 / int32 output with a real-cout guard (linear logits), or nullptr
+    void* outd; int32_t ldo, cout_real, outd_float;
+};
+
+// Depthwise 3x3 (groups == C), NHWC int8 in, VALU.
+struct DwArgs {
+    const int8_t* x; const int8_t* w;      // w: [9][Cs] tap-major
+    const int32_t* bias;                   // [Cs]
+    int32_t N, H, W, P, Q, Cs, stride, pad;
+    int32_t in_signed;
+    int32_t relu0;
+    int32_t* out32;
+    QuantOut q[2];
+};
+
+struct PoolArgs {                          // max-pool, NHWC
+    const void* x; int32_t in_is_i8, in_signed;
+    int32_t N, H, W, P, Q, Cs, k, stride, pad;
+    int32_t* out32;
+    QuantOut q[2];                         // when in_is_i8: q[0].ptr is the int8 output, no requant
+};
+
+struct AvgArgs {                           // FXQAvgPool2d sum over H*W, NHWC int32 in
+    const int32_t* x; int32_t N, HW, Cs;
+    int32_t* out32;                        // [N][Cs] or nullptr
+    QuantOut q[2];
+};
+
+struct AddArgs {                           // standalone align-add (when it cannot be fused)
+    const int32_t* a; const int32_t* b; size_t n;
+    int32_t a_shl, b_shl, relu;
+    int32_t* out32;
+    QuantOut q[2];
+};
+
+struct InArgs {                            // network input: int32 NCHW -> NHWC forms
+    const int32_t* x; int32_t N, C, H, W;
+    int8_t* out8;  int32_t Cs8;            // NHWC int8 (Cs8-channel rows), or
+    int8_t* stem;  int32_t Hp, Wp, pad;    // zero-haloed NHWC4 for the stem conv
+    int32_t* out32; int32_t Cs32;
+};
+
+struct OutArgs {                           // NHWC int32 -> NCHW int32 / float32
+    const int32_t* x; int32_t N, C, HW, Cs;
+    void* out; int32_t as_float;
+};
+
+struct ConvTile { int bm, bn, bk; };
+
+// Tile choice for a conv; returns false if no kernel instance fits (ck % bk).
+bool pick_conv_tile(int M, int coutP, int ck, bool has_pad, ConvTile* t);
+int  conv_grid(const ConvTile& t, int M, int coutP);
+
+hipError_t launch_conv(const ConvArgs& a, const ConvTile& t, hipStream_t s);
+hipError_t launch_dwconv(const DwArgs& a, hipStream_t s);
+hipError_t launch_maxpool(const PoolArgs& a, hipStream_t s);
+hipError_t launch_avgpool(const AvgArgs& a, hipStream_t s);
+hipError_t launch_add(const AddArgs& a, hipStream_t s);
+hipError_t launch_input(const InArgs& a, hipStream_t s);
+hipError_t launch_output(const OutArgs& a, hipStream_t s);
+hipError_t launch_requant_i32(const int32_t* src, int32_t* dst, size_t n, int sh, int lo, int hi, hipStream_t s);
+hipError_t launch_relu_i32(int32_t* x, size_t n, hipStream_t s);
+hipError_t launch_add_align_i32(int32_t* res, const int32_t* x, size_t n, int res_shl, int x_shl, hipStream_t s);
+
+}  // namespace f8

@@ -1,0 +1,908 @@
+// f8_net.cpp — graph builder, planner and executor behind include/f8net.h.
+//
+// The builder records the reference-level integer graph (IntModel.forward,
+// /root/reference/models/fix_resnet.py:352-383 and siblings).  f8_net_finalize turns it into a list
+// of kernel launches:
+//   * every conv's input requantisation (int_op_only_fix_quant, fix_quant_ops.py:90-114) moves into
+//     the epilogue of the tensor's PRODUCER, which then emits int8 NHWC in the consumer's format
+//     (up to two formats per producer; further ones fall back to a stand-alone requant launch);
+//   * ReLU and the residual align-add-clamp (fix_resnet.py:40-54,77) ride in the conv epilogue;
+//   * tensors keep an int32 NHWC form only where the reference semantics need 32 bits
+//     (residual operands, pooling inputs, network outputs);
+//   * a max-pool whose result is only consumed in one int8 format runs on int8 (requant is monotone,
+//     so it commutes with max exactly).
+// Planning touches no device, so it runs (and is tested) without a GPU.
+#include "../../include/f8net.h"
+#include "f8_internal.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace f8;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+    return fail(F8_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline size_t round_up_z(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+enum FormKind { FORM_I32 = 0, FORM_I8 = 1, FORM_STEM = 2 };
+struct Form {
+    int kind; int n; int sgn;          // I8: requant shift + signedness of the consumer format
+    size_t bytes_per_img = 0;
+    size_t off = 0;                    // arena offset (max_batch sized)
+    int first = -1, last = -1;         // step lifetime
+    int Hp = 0, Wp = 0, pad = 0;       // STEM
+};
+struct Tensor {
+    int C = 0, H = 0, W = 0, Cs = 0, fl = 0;
+    int prod = -1;
+    std::vector<int> consumers;        // node ids
+    std::vector<Form> forms;
+    std::string label;
+    bool dense_out = false;            // written straight to the caller's output buffer
+};
+enum NodeKind { N_INPUT, N_CONV, N_ADD, N_MAXPOOL, N_AVGPOOL, N_LINEAR };
+struct Node {
+    int kind; int a = -1, b = -1; int out = -1;
+    f8_conv_desc cd{};                 // conv / linear (as 1x1 conv)
+    std::vector<int8_t> w; std::vector<int32_t> bias;   // raw OIHW int8 + bias
+    int relu = 0;                      // add
+    int pk = 0, pstride = 0, ppad = 0; // maxpool
+    int shift = 0;                     // avgpool
+    // planning
+    int fused_into = -1;               // add: conv node that carries it
+    int fused_add = -1;                // conv: add node carried
+    bool stem = false, depthwise = false;
+    size_t w_off = 0, b_off = 0; int coutP = 0, ck = 0, ktot = 0;
+    ConvTile tile{};
+};
+enum StepKind { S_INPUT, S_CONV, S_DW, S_ADD, S_MAXPOOL, S_AVGPOOL, S_REQUANT, S_OUTPUT };
+struct OutSel { int t = -1; int f32 = -1; int f8[2] = {-1, -1}; };
+struct Step {
+    int kind; int node;
+    int src_t = -1, src_f = -1;        // main input tensor / form
+    int res_t = -1, res_f = -1;        // residual (conv) or second operand (add)
+    OutSel out;
+    int acc_shl = 0, res_shl = 0, relu0 = 0, relu1 = 0;
+    bool dense = false;
+    std::string name;
+    double bytes_per_img = 0, bytes_const = 0, ops_per_img = 0;
+};
+
+}  // namespace
+
+struct f8_net {
+    std::vector<Tensor> tensors;
+    std::vector<Node> nodes;
+    int out_t = -1, out_float = 0;
+    bool finalized = false;
+    int max_batch = 0;
+    std::vector<Step> steps;
+    std::vector<uint8_t> wblob;
+    size_t arena_bytes = 0;
+    size_t stem_zero_off = 0, stem_zero_bytes = 0;
+    // device
+    char* d_arena = nullptr; char* d_w = nullptr; bool uploaded = false;
+    hipEvent_t* events = nullptr; int n_events = 0;
+};
+
+namespace {
+
+int add_form(Tensor& t, int kind, int n, int sgn) {
+    for (size_t i = 0; i < t.forms.size(); ++i)
+        if (t.forms[i].kind == kind && (kind != FORM_I8 || (t.forms[i].n == n && t.forms[i].sgn == sgn))) return (int)i;
+    Form f; f.kind = kind; f.n = n; f.sgn = sgn;
+    t.forms.push_back(f);
+    return (int)t.forms.size() - 1;
+}
+int find_form(const Tensor& t, int kind, int n, int sgn) {
+    for (size_t i = 0; i < t.forms.size(); ++i)
+        if (t.forms[i].kind == kind && (kind != FORM_I8 || (t.forms[i].n == n && t.forms[i].sgn == sgn))) return (int)i;
+    return -1;
+}
+
+int check_t(const f8_net* net, int t, const char* who) {
+    if (!net) return fail(F8_ERR_INVALID, "%s: null net", who);
+    if (net->finalized) return fail(F8_ERR_STATE, "%s: net already finalized", who);
+    if (t < 0 || t >= (int)net->tensors.size()) return fail(F8_ERR_INVALID, "%s: bad tensor id %d", who, t);
+    return 0;
+}
+
+int new_tensor(f8_net* net, int C, int H, int W, int fl, int prod) {
+    Tensor t; t.C = C; t.H = H; t.W = W; t.Cs = round_up(C, 32); t.fl = fl; t.prod = prod;
+    net->tensors.push_back(t);
+    return (int)net->tensors.size() - 1;
+}
+
+// shift / clamp of a consumer's int_op_only_fix_quant; validates what the reference asserts
+int consumer_format(const Tensor& src, const f8_conv_desc& d, int* n, const char* who) {
+    const int maxfl = d.input_signed ? 7 : 8;
+    if (d.input_fl < 0 || d.input_fl > maxfl)
+        return fail(F8_ERR_INVALID, "%s: input_fl %d outside [0,%d] (fix_quant_ops.py:91-96)", who, d.input_fl, maxfl);
+    *n = d.quant_input ? src.fl - d.input_fl : 0;
+    if (*n > 30 || *n < -31) return fail(F8_ERR_INVALID, "%s: requant shift %d out of range", who, *n);
+    return 0;
+}
+
+void set_q(QuantOut& q, char* base, const Form& f) {
+    q.ptr = (int8_t*)(base + f.off); q.n = f.n;
+    q.lo = f.sgn ? -127 : 0; q.hi = f.sgn ? 127 : 255;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* f8_status_string(int s) {
+    switch (s) {
+        case F8_OK: return "ok";
+        case F8_ERR_INVALID: return "invalid argument";
+        case F8_ERR_UNSUPPORTED: return "unsupported";
+        case F8_ERR_HIP: return "HIP error";
+        case F8_ERR_NOMEM: return "out of memory";
+        case F8_ERR_STATE: return "bad state";
+        default: return "unknown";
+    }
+}
+const char* f8_last_error(void) { return g_err.c_str(); }
+int f8_version(void) { return F8NET_VERSION; }
+int f8_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+// ------------------------------------------------------------------------------ op level
+int f8_requant_i32(const int32_t* src, int32_t* dst, size_t n, int src_fl, int dst_fl, int is_signed, void* stream) {
+    if (dst_fl < 0 || dst_fl > (is_signed ? 7 : 8))
+        return fail(F8_ERR_INVALID, "f8_requant_i32: fl %d outside [0,%d]", dst_fl, is_signed ? 7 : 8);
+    const int sh = src_fl - dst_fl;
+    if (sh > 30 || sh < -31) return fail(F8_ERR_INVALID, "f8_requant_i32: shift %d out of range", sh);
+    if (n == 0) return F8_OK;
+    if (!src || !dst) return fail(F8_ERR_INVALID, "f8_requant_i32: null pointer");
+    hipError_t e = launch_requant_i32(src, dst, n, sh, is_signed ? -127 : 0, is_signed ? 127 : 255, (hipStream_t)stream);
+    return e == hipSuccess ? F8_OK : hip_fail(e, "f8_requant_i32");
+}
+int f8_relu_i32(int32_t* x, size_t n, void* stream) {
+    if (n == 0) return F8_OK;
+    if (!x) return fail(F8_ERR_INVALID, "f8_relu_i32: null pointer");
+    hipError_t e = launch_relu_i32(x, n, (hipStream_t)stream);
+    return e == hipSuccess ? F8_OK : hip_fail(e, "f8_relu_i32");
+}
+int f8_add_align_i32(int32_t* res, const int32_t* x, size_t n, int res_fl, int x_fl, int* out_fl, void* stream) {
+    const int d = res_fl - x_fl;
+    if (d > 31 || d < -31) return fail(F8_ERR_INVALID, "f8_add_align_i32: fraclen gap %d too large", d);
+    if (out_fl) *out_fl = std::max(res_fl, x_fl);
+    if (n == 0) return F8_OK;
+    if (!res || !x) return fail(F8_ERR_INVALID, "f8_add_align_i32: null pointer");
+    hipError_t e = launch_add_align_i32(res, x, n, d < 0 ? -d : 0, d > 0 ? d : 0, (hipStream_t)stream);
+    return e == hipSuccess ? F8_OK : hip_fail(e, "f8_add_align_i32");
+}
+
+// ------------------------------------------------------------------------------ builder
+f8_net* f8_net_create(void) { return new (std::nothrow) f8_net(); }
+
+void f8_net_destroy(f8_net* net) {
+    if (!net) return;
+    if (net->d_arena) (void)hipFree(net->d_arena);
+    if (net->d_w) (void)hipFree(net->d_w);
+    if (net->events) {
+        for (int i = 0; i < net->n_events; ++i) (void)hipEventDestroy(net->events[i]);
+        delete[] net->events;
+    }
+    delete net;
+}
+
+int f8_net_input(f8_net* net, int C, int H, int W, int fraclen) {
+    if (!net) return fail(F8_ERR_INVALID, "f8_net_input: null net");
+    if (net->finalized) return fail(F8_ERR_STATE, "f8_net_input: finalized");
+    if (C <= 0 || H <= 0 || W <= 0) return fail(F8_ERR_INVALID, "f8_net_input: bad shape");
+    for (auto& n : net->nodes) if (n.kind == N_INPUT) return fail(F8_ERR_UNSUPPORTED, "f8_net_input: one input per net");
+    Node nd; nd.kind = N_INPUT;
+    net->nodes.push_back(nd);
+    const int t = new_tensor(net, C, H, W, fraclen, (int)net->nodes.size() - 1);
+    net->nodes.back().out = t;
+    return t;
+}
+
+static int add_conv_node(f8_net* net, int src, const f8_conv_desc& d, const int32_t* w, const int32_t* b,
+                         int kind, const char* who) {
+    int rc = check_t(net, src, who);
+    if (rc) return rc;
+    const Tensor& s = net->tensors[src];
+    if (d.cin != s.C) return fail(F8_ERR_INVALID, "%s: cin %d != source channels %d", who, d.cin, s.C);
+    if (d.kernel < 1 || d.stride < 1 || d.pad < 0 || d.cout < 1) return fail(F8_ERR_INVALID, "%s: bad geometry", who);
+    if (!(d.groups == 1 || (d.groups == d.cin && d.cout == d.cin)))
+        return fail(F8_ERR_UNSUPPORTED, "%s: groups must be 1 or cin (depthwise)", who);
+    if (d.groups != 1 && !(d.kernel == 3 && d.pad == 1))
+        return fail(F8_ERR_UNSUPPORTED, "%s: depthwise is built for 3x3 pad 1", who);
+    if (d.weight_fl < 0 || d.weight_fl > 31) return fail(F8_ERR_INVALID, "%s: bad weight_fl", who);
+    int n;
+    rc = consumer_format(s, d, &n, who);
+    if (rc) return rc;
+    const int P = (s.H + 2 * d.pad - d.kernel) / d.stride + 1, Q = (s.W + 2 * d.pad - d.kernel) / d.stride + 1;
+    if (P < 1 || Q < 1) return fail(F8_ERR_INVALID, "%s: kernel larger than padded input", who);
+    if (!w) return fail(F8_ERR_INVALID, "%s: null weight", who);
+    Node nd; nd.kind = kind; nd.a = src; nd.cd = d;
+    const size_t wn = (size_t)d.cout * (d.cin / d.groups) * d.kernel * d.kernel;
+    nd.w.resize(wn);
+    for (size_t i = 0; i < wn; ++i) {
+        if (w[i] < -128 || w[i] > 127) return fail(F8_ERR_INVALID, "%s: weight %d does not fit int8", who, w[i]);
+        nd.w[i] = (int8_t)w[i];
+    }
+    nd.bias.assign(d.cout, 0);
+    if (b) for (int i = 0; i < d.cout; ++i) nd.bias[i] = b[i];
+    net->nodes.push_back(std::move(nd));
+    const int id = (int)net->nodes.size() - 1;
+    const int t = new_tensor(net, d.cout, P, Q, d.weight_fl + d.input_fl, id);
+    net->nodes[id].out = t;
+    net->tensors[src].consumers.push_back(id);
+    return t;
+}
+
+int f8_net_conv(f8_net* net, int src, const f8_conv_desc* desc, const int32_t* w, const int32_t* b) {
+    if (!desc) return fail(F8_ERR_INVALID, "f8_net_conv: null desc");
+    return add_conv_node(net, src, *desc, w, b, N_CONV, "f8_net_conv");
+}
+
+int f8_net_linear(f8_net* net, int src, const f8_linear_desc* d, const int32_t* w, const int32_t* b) {
+    if (!d) return fail(F8_ERR_INVALID, "f8_net_linear: null desc");
+    int rc = check_t(net, src, "f8_net_linear");
+    if (rc) return rc;
+    const Tensor& s = net->tensors[src];
+    if (s.H != 1 || s.W != 1) return fail(F8_ERR_INVALID, "f8_net_linear: source must be [C,1,1]");
+    f8_conv_desc c{};
+    c.cin = d->in_features; c.cout = d->out_features; c.kernel = 1; c.stride = 1; c.pad = 0; c.groups = 1;
+    c.weight_fl = d->weight_fl; c.input_fl = d->input_fl; c.input_signed = d->input_signed;
+    c.quant_input = d->quant_input; c.relu = 0;
+    return add_conv_node(net, src, c, w, b, N_LINEAR, "f8_net_linear");
+}
+
+int f8_net_add(f8_net* net, int a, int b, int relu) {
+    int rc = check_t(net, a, "f8_net_add");
+    if (rc) return rc;
+    rc = check_t(net, b, "f8_net_add");
+    if (rc) return rc;
+    const Tensor &ta = net->tensors[a], &tb = net->tensors[b];
+    if (ta.C != tb.C || ta.H != tb.H || ta.W != tb.W) return fail(F8_ERR_INVALID, "f8_net_add: shape mismatch");
+    if (a == b) return fail(F8_ERR_UNSUPPORTED, "f8_net_add: operands must differ");
+    if (std::abs(ta.fl - tb.fl) > 31) return fail(F8_ERR_INVALID, "f8_net_add: fraclen gap too large");
+    Node nd; nd.kind = N_ADD; nd.a = a; nd.b = b; nd.relu = relu;
+    net->nodes.push_back(nd);
+    const int id = (int)net->nodes.size() - 1;
+    const int t = new_tensor(net, ta.C, ta.H, ta.W, std::max(ta.fl, tb.fl), id);
+    net->nodes[id].out = t;
+    net->tensors[a].consumers.push_back(id);
+    net->tensors[b].consumers.push_back(id);
+    return t;
+}
+
+int f8_net_maxpool(f8_net* net, int src, int k, int stride, int pad) {
+    int rc = check_t(net, src, "f8_net_maxpool");
+    if (rc) return rc;
+    const Tensor& s = net->tensors[src];
+    if (k < 1 || stride < 1 || pad < 0 || pad * 2 > k) return fail(F8_ERR_INVALID, "f8_net_maxpool: bad geometry");
+    const int P = (s.H + 2 * pad - k) / stride + 1, Q = (s.W + 2 * pad - k) / stride + 1;
+    if (P < 1 || Q < 1) return fail(F8_ERR_INVALID, "f8_net_maxpool: window larger than input");
+    Node nd; nd.kind = N_MAXPOOL; nd.a = src; nd.pk = k; nd.pstride = stride; nd.ppad = pad;
+    net->nodes.push_back(nd);
+    const int id = (int)net->nodes.size() - 1;
+    const int t = new_tensor(net, s.C, P, Q, s.fl, id);
+    net->nodes[id].out = t;
+    net->tensors[src].consumers.push_back(id);
+    return t;
+}
+
+int f8_net_avgpool_sum(f8_net* net, int src, int shift) {
+    int rc = check_t(net, src, "f8_net_avgpool_sum");
+    if (rc) return rc;
+    const Tensor& s = net->tensors[src];
+    if (shift < 0 || s.fl + shift > 32)   // fix_quant_ops.py:129 `assert output_fraclen <= 32`
+        return fail(F8_ERR_INVALID, "f8_net_avgpool_sum: output fraclen %d > 32", s.fl + shift);
+    Node nd; nd.kind = N_AVGPOOL; nd.a = src; nd.shift = shift;
+    net->nodes.push_back(nd);
+    const int id = (int)net->nodes.size() - 1;
+    const int t = new_tensor(net, s.C, 1, 1, s.fl + shift, id);
+    net->nodes[id].out = t;
+    net->tensors[src].consumers.push_back(id);
+    return t;
+}
+
+int f8_net_output(f8_net* net, int src, int as_float) {
+    int rc = check_t(net, src, "f8_net_output");
+    if (rc) return rc;
+    if (net->out_t >= 0) return fail(F8_ERR_UNSUPPORTED, "f8_net_output: one output per net");
+    net->out_t = src; net->out_float = as_float ? 1 : 0;
+    return F8_OK;
+}
+
+int f8_net_set_label(f8_net* net, int t, const char* label) {
+    if (!net || t < 0 || t >= (int)net->tensors.size()) return fail(F8_ERR_INVALID, "f8_net_set_label: bad tensor");
+    net->tensors[t].label = label ? label : "";
+    return F8_OK;
+}
+
+// ------------------------------------------------------------------------------ planner
+static void pack_conv_weights(f8_net* net, Node& nd, const Tensor& src) {
+    // Packed layout: [coutP][taps][CK] int8, K-contiguous per output channel, zero padded.
+    // Generic: tap = (r,s), CK = Cs(src) channels.  Stem (cin <= 4, source = network input held as
+    // zero-haloed NHWC4): one "tap" per kernel ROW, CK = 32 bytes = 8 pixels x 4 channels of which
+    // the first kw pixels / cin channels carry weights.
+    // Bias is offset-corrected for unsigned inputs: b' = b + 128 * sum_k w  (kernel header).
+    const f8_conv_desc& d = nd.cd;
+    const int k = d.kernel;
+    nd.coutP = round_up(d.cout, 32);
+    if (nd.stem) { nd.ck = 32; nd.ktot = k * 32; }
+    else { nd.ck = src.Cs; nd.ktot = k * k * src.Cs; }
+    nd.w_off = round_up_z(net->wblob.size(), 256);
+    const size_t wbytes = (size_t)nd.coutP * nd.ktot;
+    nd.b_off = round_up_z(nd.w_off + wbytes, 256);
+    net->wblob.resize(nd.b_off + (size_t)nd.coutP * 4, 0);
+    int8_t* wp = (int8_t*)net->wblob.data() + nd.w_off;
+    int32_t* bp = (int32_t*)(net->wblob.data() + nd.b_off);
+    for (int o = 0; o < d.cout; ++o) {
+        long long sum = 0;
+        for (int c = 0; c < d.cin; ++c)
+            for (int r = 0; r < k; ++r)
+                for (int s = 0; s < k; ++s) {
+                    const int8_t v = nd.w[(((size_t)o * d.cin + c) * k + r) * k + s];
+                    sum += v;
+                    size_t idx;
+                    if (nd.stem) idx = (size_t)o * nd.ktot + (size_t)r * 32 + (size_t)s * 4 + c;
+                    else idx = (size_t)o * nd.ktot + ((size_t)(r * k + s)) * src.Cs + c;
+                    wp[idx] = v;
+                }
+        uint32_t b = (uint32_t)nd.bias[o];
+        if (!d.input_signed) b += (uint32_t)(128ll * sum);
+        bp[o] = (int32_t)b;
+    }
+}
+
+static void pack_dw_weights(f8_net* net, Node& nd, const Tensor& src) {
+    const f8_conv_desc& d = nd.cd;
+    nd.coutP = src.Cs; nd.ck = 0; nd.ktot = 0;
+    nd.w_off = round_up_z(net->wblob.size(), 256);
+    nd.b_off = round_up_z(nd.w_off + (size_t)9 * src.Cs, 256);
+    net->wblob.resize(nd.b_off + (size_t)src.Cs * 4, 0);
+    int8_t* wp = (int8_t*)net->wblob.data() + nd.w_off;
+    int32_t* bp = (int32_t*)(net->wblob.data() + nd.b_off);
+    for (int c = 0; c < d.cout; ++c) {
+        for (int t = 0; t < 9; ++t) wp[(size_t)t * src.Cs + c] = nd.w[(size_t)c * 9 + t];
+        bp[c] = nd.bias[c];
+    }
+}
+
+static std::string tname(const f8_net* net, int t) {
+    const Tensor& T = net->tensors[t];
+    if (!T.label.empty()) return T.label;
+    char b[32]; snprintf(b, sizeof b, "t%d", t);
+    return b;
+}
+
+// choose the forms a producer writes; extra int8 formats beyond two need the int32 form
+static void select_outputs(f8_net* net, int t, OutSel* o, std::vector<int>* extra) {
+    Tensor& T = net->tensors[t];
+    o->t = t;
+    int n8 = 0;
+    for (size_t i = 0; i < T.forms.size(); ++i) if (T.forms[i].kind == FORM_I8) ++n8;
+    if (n8 > 2) add_form(T, FORM_I32, 0, 0);
+    o->f32 = find_form(T, FORM_I32, 0, 0);
+    int k = 0;
+    for (size_t i = 0; i < T.forms.size(); ++i)
+        if (T.forms[i].kind == FORM_I8) {
+            if (k < 2) o->f8[k++] = (int)i;
+            else if (extra) extra->push_back((int)i);
+        }
+}
+
+int f8_net_finalize(f8_net* net, int max_batch) {
+    if (!net) return fail(F8_ERR_INVALID, "f8_net_finalize: null net");
+    if (net->finalized) return fail(F8_ERR_STATE, "f8_net_finalize: already finalized");
+    if (max_batch < 1) return fail(F8_ERR_INVALID, "f8_net_finalize: max_batch < 1");
+    if (net->out_t < 0) return fail(F8_ERR_STATE, "f8_net_finalize: no output marked");
+    if (net->nodes.empty() || net->nodes[0].kind != N_INPUT) return fail(F8_ERR_STATE, "f8_net_finalize: first node must be the input");
+    auto& T = net->tensors;
+    auto& ND = net->nodes;
+    const int nn = (int)ND.size();
+
+    // ---- 1. residual fusion: an add rides in the epilogue of the LATER of its two producers when
+    //         that producer is an MFMA conv nobody else reads and the other operand is already there.
+    for (int i = 0; i < nn; ++i) {
+        Node& ad = ND[i];
+        if (ad.kind != N_ADD) continue;
+        for (int pass = 0; pass < 2 && ad.fused_into < 0; ++pass) {
+            const int x = pass == 0 ? ad.a : ad.b, y = pass == 0 ? ad.b : ad.a;
+            const int px = T[x].prod, py = T[y].prod;
+            Node& cx = ND[px];
+            if (cx.kind != N_CONV || cx.cd.groups != 1 || cx.fused_add >= 0) continue;
+            if (T[x].consumers.size() != 1 || x == net->out_t) continue;
+            if (py > px) continue;     // other operand must exist before the conv runs
+            ad.fused_into = px; cx.fused_add = i;
+        }
+    }
+
+    // ---- 2. which forms does each tensor need?  (reverse order: consumers before producers)
+    {
+        Tensor& O = T[net->out_t];
+        const Node& p = ND[O.prod];
+        if (p.kind == N_LINEAR && O.consumers.empty()) O.dense_out = true;
+        else add_form(O, FORM_I32, 0, 0);
+    }
+    for (int i = nn - 1; i >= 0; --i) {
+        Node& nd = ND[i];
+        switch (nd.kind) {
+            case N_CONV: case N_LINEAR: {
+                Tensor& s = T[nd.a];
+                int n = 0;
+                consumer_format(s, nd.cd, &n, "finalize");
+                nd.depthwise = nd.cd.groups != 1;
+                nd.stem = !nd.depthwise && nd.cd.cin <= 4 && ND[s.prod].kind == N_INPUT && nd.cd.kernel <= 8 &&
+                          s.consumers.size() == 1 && nd.a != net->out_t;
+                if (nd.stem) {
+                    const int P = T[nd.out].H, Q = T[nd.out].W;
+                    (void)P;
+                    const int f = add_form(s, FORM_STEM, 0, 0);
+                    Form& F = s.forms[f];
+                    F.pad = nd.cd.pad;
+                    F.Hp = s.H + 2 * nd.cd.pad;
+                    F.Wp = round_up(std::max(s.W + 2 * nd.cd.pad, nd.cd.stride * (Q - 1) + 8), 2);
+                } else {
+                    add_form(s, FORM_I8, n, nd.cd.input_signed ? 1 : 0);
+                }
+                if (nd.fused_add >= 0) {
+                    const Node& ad = ND[nd.fused_add];
+                    const int other = (ad.a == nd.out) ? ad.b : ad.a;
+                    add_form(T[other], FORM_I32, 0, 0);
+                }
+                break;
+            }
+            case N_ADD:
+                if (nd.fused_into < 0) { add_form(T[nd.a], FORM_I32, 0, 0); add_form(T[nd.b], FORM_I32, 0, 0); }
+                break;
+            case N_MAXPOOL: {
+                Tensor& o = T[nd.out];
+                if (o.forms.size() == 1 && o.forms[0].kind == FORM_I8)
+                    add_form(T[nd.a], FORM_I8, o.forms[0].n, o.forms[0].sgn);
+                else
+                    add_form(T[nd.a], FORM_I32, 0, 0);
+                break;
+            }
+            case N_AVGPOOL:
+                add_form(T[nd.a], FORM_I32, 0, 0);
+                break;
+            default: break;
+        }
+    }
+
+    // ---- 3. emit steps in node order
+    net->steps.clear();
+    auto touch = [&](int t, int f, int step) {
+        if (t < 0 || f < 0) return;
+        Form& F = T[t].forms[f];
+        if (F.first < 0) F.first = step;
+        F.last = std::max(F.last, step);
+    };
+    auto emit_requants = [&](int t, const std::vector<int>& extra) {
+        for (int f : extra) {
+            Step st; st.kind = S_REQUANT; st.node = T[t].prod;
+            st.src_t = t; st.src_f = find_form(T[t], FORM_I32, 0, 0);
+            st.out.t = t; st.out.f8[0] = f;
+            st.name = "requant:" + tname(net, t);
+            const double e = (double)T[t].H * T[t].W * T[t].Cs;
+            st.bytes_per_img = e * 5;
+            net->steps.push_back(st);
+        }
+    };
+    for (int i = 0; i < nn; ++i) {
+        Node& nd = ND[i];
+        if (nd.kind == N_ADD && nd.fused_into >= 0) continue;
+        Step st; st.node = i;
+        std::vector<int> extra;
+        int out_t = nd.out;
+        switch (nd.kind) {
+            case N_INPUT: {
+                st.kind = S_INPUT;
+                Tensor& o = T[nd.out];
+                if (o.forms.empty()) add_form(o, FORM_I32, 0, 0);
+                for (auto& F : o.forms)
+                    if (F.kind == FORM_I8 && F.n != 0)
+                        return fail(F8_ERR_UNSUPPORTED, "finalize: a conv with quant_input=1 directly on the network input "
+                                    "(the reference feeds head-format integers, fix_train.py:683-692)");
+                st.out.t = nd.out;
+                st.name = "input";
+                double b = (double)o.C * o.H * o.W * 4;
+                for (auto& F : o.forms) b += (double)o.H * o.W * (F.kind == FORM_I32 ? o.Cs * 4 : (F.kind == FORM_STEM ? 4 : o.Cs));
+                st.bytes_per_img = b;
+                break;
+            }
+            case N_CONV: case N_LINEAR: {
+                Tensor& s = T[nd.a];
+                st.kind = nd.depthwise ? S_DW : S_CONV;
+                st.src_t = nd.a;
+                int n = 0; consumer_format(s, nd.cd, &n, "finalize");
+                st.src_f = nd.stem ? find_form(s, FORM_STEM, 0, 0) : find_form(s, FORM_I8, n, nd.cd.input_signed ? 1 : 0);
+                st.relu0 = nd.cd.relu;
+                if (nd.depthwise) pack_dw_weights(net, nd, s);
+                else {
+                    pack_conv_weights(net, nd, s);
+                    const int M1 = T[nd.out].H * T[nd.out].W;
+                    if (!pick_conv_tile(M1 * max_batch, nd.coutP, nd.ck, nd.cd.pad > 0 && !nd.stem, &nd.tile))
+                        return fail(F8_ERR_UNSUPPORTED, "finalize: no conv kernel instance for ck=%d coutP=%d", nd.ck, nd.coutP);
+                }
+                if (nd.fused_add >= 0) {
+                    const Node& ad = ND[nd.fused_add];
+                    const int other = (ad.a == nd.out) ? ad.b : ad.a;
+                    st.res_t = other; st.res_f = find_form(T[other], FORM_I32, 0, 0);
+                    const int dfl = T[nd.out].fl - T[other].fl;     // >0: residual shifts left
+                    st.acc_shl = dfl < 0 ? -dfl : 0; st.res_shl = dfl > 0 ? dfl : 0;
+                    st.relu1 = ad.relu;
+                    out_t = ad.out;
+                }
+                Tensor& o = T[out_t];
+                if (o.dense_out) { st.dense = true; st.out.t = out_t; }
+                else select_outputs(net, out_t, &st.out, &extra);
+                const f8_conv_desc& d = nd.cd;
+                const double opix = (double)T[nd.out].H * T[nd.out].W;
+                st.ops_per_img = 2.0 * opix * d.cout * (d.cin / d.groups) * d.kernel * d.kernel;
+                double b = (double)s.H * s.W * (nd.stem ? 4 : s.Cs);            // input once
+                if (st.res_t >= 0) b += opix * o.Cs * 4;
+                if (st.dense) b += (double)d.cout * 4;
+                if (st.out.f32 >= 0) b += opix * o.Cs * 4;
+                for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += opix * o.Cs;
+                st.bytes_per_img = b;
+                st.bytes_const = nd.depthwise ? (double)s.Cs * 13 : (double)nd.coutP * (nd.ktot + 4);
+                char buf[160];
+                if (nd.depthwise) snprintf(buf, sizeof buf, "dwconv3x3s%d:%s", d.stride, tname(net, nd.out).c_str());
+                else snprintf(buf, sizeof buf, "conv%dx%ds%d_t%dx%dx%d%s%s:%s", d.kernel, d.kernel, d.stride, nd.tile.bm, nd.tile.bn,
+                              nd.tile.bk, nd.stem ? "_stem" : "", st.res_t >= 0 ? "_res" : "", tname(net, nd.out).c_str());
+                st.name = buf;
+                break;
+            }
+            case N_ADD: {
+                st.kind = S_ADD;
+                st.src_t = nd.a; st.src_f = find_form(T[nd.a], FORM_I32, 0, 0);
+                st.res_t = nd.b; st.res_f = find_form(T[nd.b], FORM_I32, 0, 0);
+                const int dfl = T[nd.a].fl - T[nd.b].fl;
+                st.acc_shl = dfl < 0 ? -dfl : 0; st.res_shl = dfl > 0 ? dfl : 0;
+                st.relu1 = nd.relu;
+                select_outputs(net, nd.out, &st.out, &extra);
+                st.name = "add:" + tname(net, nd.out);
+                const double e = (double)T[nd.out].H * T[nd.out].W * T[nd.out].Cs;
+                st.bytes_per_img = e * 8 + (st.out.f32 >= 0 ? e * 4 : 0) + (st.out.f8[0] >= 0 ? e : 0) + (st.out.f8[1] >= 0 ? e : 0);
+                break;
+            }
+            case N_MAXPOOL: {
+                st.kind = S_MAXPOOL;
+                Tensor& s = T[nd.a]; Tensor& o = T[nd.out];
+                st.src_t = nd.a;
+                const bool i8 = (o.forms.size() == 1 && o.forms[0].kind == FORM_I8);
+                st.src_f = i8 ? find_form(s, FORM_I8, o.forms[0].n, o.forms[0].sgn) : find_form(s, FORM_I32, 0, 0);
+                if (o.forms.empty()) add_form(o, FORM_I32, 0, 0);
+                select_outputs(net, nd.out, &st.out, &extra);
+                st.name = std::string(i8 ? "maxpool_i8:" : "maxpool_i32:") + tname(net, nd.out);
+                const double ei = (double)s.H * s.W * s.Cs, eo = (double)o.H * o.W * o.Cs;
+                st.bytes_per_img = ei * (i8 ? 1 : 4) + (st.out.f32 >= 0 ? eo * 4 : 0) + (st.out.f8[0] >= 0 ? eo : 0) + (st.out.f8[1] >= 0 ? eo : 0);
+                break;
+            }
+            case N_AVGPOOL: {
+                st.kind = S_AVGPOOL;
+                Tensor& s = T[nd.a]; Tensor& o = T[nd.out];
+                st.src_t = nd.a; st.src_f = find_form(s, FORM_I32, 0, 0);
+                if (o.forms.empty()) add_form(o, FORM_I32, 0, 0);
+                select_outputs(net, nd.out, &st.out, &extra);
+                st.name = "avgpool_sum:" + tname(net, nd.out);
+                st.bytes_per_img = (double)s.H * s.W * s.Cs * 4 + (double)o.Cs * 5;
+                break;
+            }
+        }
+        net->steps.push_back(st);
+        emit_requants(st.out.t, extra);
+    }
+    if (!T[net->out_t].dense_out) {
+        Step st; st.kind = S_OUTPUT; st.node = T[net->out_t].prod;
+        st.src_t = net->out_t; st.src_f = find_form(T[net->out_t], FORM_I32, 0, 0);
+        st.name = "output:" + tname(net, net->out_t);
+        st.bytes_per_img = (double)T[net->out_t].H * T[net->out_t].W * (T[net->out_t].Cs + T[net->out_t].C) * 4;
+        net->steps.push_back(st);
+    }
+
+    // ---- 4. lifetimes and arena layout (first-fit over a free list; in-place residual update)
+    for (size_t si = 0; si < net->steps.size(); ++si) {
+        Step& st = net->steps[si];
+        touch(st.src_t, st.src_f, (int)si);
+        touch(st.res_t, st.res_f, (int)si);
+        if (st.out.t >= 0 && !st.dense) {
+            touch(st.out.t, st.out.f32, (int)si);
+            touch(st.out.t, st.out.f8[0], (int)si);
+            touch(st.out.t, st.out.f8[1], (int)si);
+            if (st.kind == S_INPUT)
+                for (size_t f = 0; f < T[st.out.t].forms.size(); ++f) touch(st.out.t, (int)f, (int)si);
+        }
+    }
+    struct Blk { size_t off, size; };
+    std::vector<Blk> freel;
+    size_t top = 0;
+    auto alloc = [&](size_t sz) -> size_t {
+        sz = round_up_z(sz, 256);
+        size_t best = (size_t)-1; int bi = -1;
+        for (size_t i = 0; i < freel.size(); ++i)
+            if (freel[i].size >= sz && freel[i].size < best) { best = freel[i].size; bi = (int)i; }
+        if (bi >= 0) {
+            size_t off = freel[bi].off;
+            if (freel[bi].size == sz) freel.erase(freel.begin() + bi);
+            else { freel[bi].off += sz; freel[bi].size -= sz; }
+            return off;
+        }
+        size_t off = top; top += sz; return off;
+    };
+    auto release = [&](size_t off, size_t sz) {
+        sz = round_up_z(sz, 256);
+        freel.push_back({off, sz});
+        std::sort(freel.begin(), freel.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
+        for (size_t i = 0; i + 1 < freel.size();)
+            if (freel[i].off + freel[i].size == freel[i + 1].off) { freel[i].size += freel[i + 1].size; freel.erase(freel.begin() + i + 1); }
+            else ++i;
+    };
+    for (auto& t : T)
+        for (auto& F : t.forms) {
+            if (F.kind == FORM_I32) F.bytes_per_img = (size_t)t.H * t.W * t.Cs * 4;
+            else if (F.kind == FORM_I8) F.bytes_per_img = (size_t)t.H * t.W * t.Cs;
+            else F.bytes_per_img = (size_t)F.Hp * F.Wp * 4;
+        }
+    // the stem image keeps a zero halo that is written once at upload: give it a private region
+    for (auto& t : T)
+        for (auto& F : t.forms)
+            if (F.kind == FORM_STEM) {
+                F.off = alloc(F.bytes_per_img * max_batch);
+                net->stem_zero_off = F.off; net->stem_zero_bytes = F.bytes_per_img * max_batch;
+            }
+    for (size_t si = 0; si < net->steps.size(); ++si) {
+        Step& st = net->steps[si];
+        // forms born at this step
+        for (size_t ti = 0; ti < T.size(); ++ti)
+            for (size_t f = 0; f < T[ti].forms.size(); ++f) {
+                Form& F = T[ti].forms[f];
+                if (F.kind == FORM_STEM || F.first != (int)si) continue;
+                // in-place residual: out32 of a conv/add step may overwrite a residual operand that dies here
+                // (each thread reads its element before writing it; same NHWC geometry)
+                if (F.kind == FORM_I32 && (int)ti == st.out.t && (int)f == st.out.f32 && st.res_t >= 0 &&
+                    (st.kind == S_CONV || st.kind == S_ADD)) {
+                    Form& R = T[st.res_t].forms[st.res_f];
+                    if (R.last == (int)si && R.bytes_per_img == F.bytes_per_img && R.kind == FORM_I32) {
+                        F.off = R.off; R.last = -2;   // ownership moves to F
+                        continue;
+                    }
+                }
+                F.off = alloc(F.bytes_per_img * max_batch);
+            }
+        // forms dying at this step
+        for (size_t ti = 0; ti < T.size(); ++ti)
+            for (auto& F : T[ti].forms)
+                if (F.kind != FORM_STEM && F.last == (int)si && F.first >= 0) release(F.off, F.bytes_per_img * max_batch);
+    }
+    net->arena_bytes = top;
+    for (auto& t : T)
+        for (auto& F : t.forms)
+            if (F.bytes_per_img * (size_t)max_batch >= (1ull << 31))
+                return fail(F8_ERR_UNSUPPORTED, "finalize: a tensor exceeds 2 GiB at max_batch %d (buffer addressing)", max_batch);
+    net->max_batch = max_batch;
+    net->finalized = true;
+    return F8_OK;
+}
+
+size_t f8_net_describe(const f8_net* net, char* buf, size_t cap) {
+    std::string s;
+    if (net && net->finalized) {
+        char line[512];
+        for (size_t i = 0; i < net->steps.size(); ++i) {
+            const Step& st = net->steps[i];
+            int n8 = (st.out.f8[0] >= 0) + (st.out.f8[1] >= 0);
+            snprintf(line, sizeof line, "%3zu %-58s out[i32=%d i8=%d dense=%d] res=%d relu=%d/%d shl=%d/%d\n", i, st.name.c_str(),
+                     st.out.f32 >= 0, n8, (int)st.dense, st.res_t >= 0, st.relu0, st.relu1, st.acc_shl, st.res_shl);
+            s += line;
+        }
+        snprintf(line, sizeof line, "arena=%zu B (max_batch %d) weights=%zu B launches=%zu\n", net->arena_bytes, net->max_batch,
+                 net->wblob.size(), net->steps.size());
+        s += line;
+    }
+    if (buf && cap) { size_t n = std::min(cap - 1, s.size()); memcpy(buf, s.data(), n); buf[n] = 0; }
+    return s.size() + 1;
+}
+int f8_net_num_launches(const f8_net* net) { return (net && net->finalized) ? (int)net->steps.size() : F8_ERR_STATE; }
+size_t f8_net_arena_bytes(const f8_net* net) { return net ? net->arena_bytes : 0; }
+size_t f8_net_weight_bytes(const f8_net* net) { return net ? net->wblob.size() : 0; }
+int f8_net_output_fraclen(const f8_net* net) { return (net && net->out_t >= 0) ? net->tensors[net->out_t].fl : F8_ERR_STATE; }
+size_t f8_net_output_elems(const f8_net* net) {
+    if (!net || net->out_t < 0) return 0;
+    const Tensor& t = net->tensors[net->out_t];
+    return (size_t)t.C * t.H * t.W;
+}
+
+int f8_net_launch_info(const f8_net* net, int i, int N, char* name, size_t name_cap, double* alg_bytes, double* alg_ops) {
+    if (!net || !net->finalized) return fail(F8_ERR_STATE, "f8_net_launch_info: not finalized");
+    if (i < 0 || i >= (int)net->steps.size()) return fail(F8_ERR_INVALID, "f8_net_launch_info: index");
+    const Step& st = net->steps[i];
+    if (name && name_cap) { snprintf(name, name_cap, "%s", st.name.c_str()); }
+    if (alg_bytes) *alg_bytes = st.bytes_per_img * N + st.bytes_const;
+    if (alg_ops) *alg_ops = st.ops_per_img * N;
+    return F8_OK;
+}
+
+// ------------------------------------------------------------------------------ executor
+int f8_net_upload(f8_net* net) {
+    if (!net || !net->finalized) return fail(F8_ERR_STATE, "f8_net_upload: not finalized");
+    if (net->uploaded) return F8_OK;
+    hipError_t e;
+    if ((e = hipMalloc((void**)&net->d_arena, std::max<size_t>(net->arena_bytes, 256))) != hipSuccess) return hip_fail(e, "hipMalloc(arena)");
+    if ((e = hipMalloc((void**)&net->d_w, std::max<size_t>(net->wblob.size(), 256))) != hipSuccess) return hip_fail(e, "hipMalloc(weights)");
+    if (!net->wblob.empty() && (e = hipMemcpy(net->d_w, net->wblob.data(), net->wblob.size(), hipMemcpyHostToDevice)) != hipSuccess)
+        return hip_fail(e, "hipMemcpy(weights)");
+    if (net->stem_zero_bytes && (e = hipMemset(net->d_arena + net->stem_zero_off, 0, net->stem_zero_bytes)) != hipSuccess)
+        return hip_fail(e, "hipMemset(stem halo)");
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return hip_fail(e, "upload sync");
+    net->uploaded = true;
+    return F8_OK;
+}
+
+static int run_step(f8_net* net, const Step& st, const int32_t* input, void* output, int N, hipStream_t s) {
+    auto& T = net->tensors;
+    char* A = net->d_arena;
+    const Node& nd = net->nodes[st.node];
+    auto fill_out = [&](int32_t** out32, QuantOut q[2]) {
+        *out32 = nullptr; q[0].ptr = q[1].ptr = nullptr; q[0].n = q[1].n = 0; q[0].lo = q[1].lo = 0; q[0].hi = q[1].hi = 0;
+        if (st.out.t < 0 || st.dense) return;
+        const Tensor& o = T[st.out.t];
+        if (st.out.f32 >= 0) *out32 = (int32_t*)(A + o.forms[st.out.f32].off);
+        for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) set_q(q[k], A, o.forms[st.out.f8[k]]);
+    };
+    hipError_t e = hipSuccess;
+    switch (st.kind) {
+        case S_INPUT: {
+            const Tensor& o = T[st.out.t];
+            InArgs a{}; a.x = input; a.N = N; a.C = o.C; a.H = o.H; a.W = o.W;
+            for (auto& F : o.forms) {
+                if (F.kind == FORM_I8) { a.out8 = (int8_t*)(A + F.off); a.Cs8 = o.Cs; }
+                else if (F.kind == FORM_I32) { a.out32 = (int32_t*)(A + F.off); a.Cs32 = o.Cs; }
+                else { a.stem = (int8_t*)(A + F.off); a.Hp = F.Hp; a.Wp = F.Wp; a.pad = F.pad; }
+            }
+            e = launch_input(a, s);
+            break;
+        }
+        case S_CONV: {
+            const Tensor& sT = T[st.src_t]; const Form& sF = sT.forms[st.src_f];
+            const Tensor& oT = T[nd.out];
+            const f8_conv_desc& d = nd.cd;
+            ConvArgs a{};
+            a.x = (const int8_t*)(A + sF.off); a.x_bytes = (uint32_t)(sF.bytes_per_img * N);
+            a.w = (const int8_t*)(net->d_w + nd.w_off); a.w_bytes = (uint32_t)((size_t)nd.coutP * nd.ktot);
+            a.bias = (const int32_t*)(net->d_w + nd.b_off);
+            a.PQ = oT.H * oT.W; a.Q = oT.W; a.M = N * a.PQ;
+            a.stride = d.stride; a.kh = d.kernel; a.CK = nd.ck; a.ktot = nd.ktot; a.coutP = nd.coutP;
+            a.xor_mask = d.input_signed ? 0u : 0x80808080u;
+            if (nd.stem) {
+                a.sN = (int)sF.bytes_per_img; a.sP = d.stride * sF.Wp * 4; a.sQ = d.stride * 4;
+                a.origin = 0; a.H = sF.Hp; a.W = sF.Wp; a.pad = 0; a.kw = 1;
+                a.tapH = sF.Wp * 4; a.tapW = 0;
+            } else {
+                a.sN = sT.H * sT.W * sT.Cs; a.sP = d.stride * sT.W * sT.Cs; a.sQ = d.stride * sT.Cs;
+                a.origin = -(d.pad * sT.W + d.pad) * sT.Cs; a.H = sT.H; a.W = sT.W; a.pad = d.pad; a.kw = d.kernel;
+                a.tapH = sT.W * sT.Cs; a.tapW = sT.Cs;
+            }
+            a.relu0 = st.relu0;
+            if (st.res_t >= 0) { a.res = (const int32_t*)(A + T[st.res_t].forms[st.res_f].off); a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1; }
+            fill_out(&a.out32, a.q);
+            if (st.dense) { a.outd = output; a.ldo = d.cout; a.cout_real = d.cout; a.outd_float = net->out_float; }
+            e = launch_conv(a, nd.tile, s);
+            break;
+        }
+        case S_DW: {
+            const Tensor& sT = T[st.src_t]; const Form& sF = sT.forms[st.src_f];
+            const Tensor& oT = T[nd.out];
+            DwArgs a{};
+            a.x = (const int8_t*)(A + sF.off); a.w = (const int8_t*)(net->d_w + nd.w_off); a.bias = (const int32_t*)(net->d_w + nd.b_off);
+            a.N = N; a.H = sT.H; a.W = sT.W; a.P = oT.H; a.Q = oT.W; a.Cs = sT.Cs; a.stride = nd.cd.stride; a.pad = nd.cd.pad;
+            a.in_signed = nd.cd.input_signed; a.relu0 = st.relu0;
+            fill_out(&a.out32, a.q);
+            e = launch_dwconv(a, s);
+            break;
+        }
+        case S_ADD: case S_REQUANT: {
+            const Tensor& sT = T[st.src_t];
+            AddArgs a{};
+            a.a = (const int32_t*)(A + sT.forms[st.src_f].off);
+            a.b = st.kind == S_ADD ? (const int32_t*)(A + T[st.res_t].forms[st.res_f].off) : nullptr;
+            a.n = (size_t)N * sT.H * sT.W * sT.Cs; a.a_shl = st.acc_shl; a.b_shl = st.res_shl; a.relu = st.relu1;
+            fill_out(&a.out32, a.q);
+            e = launch_add(a, s);
+            break;
+        }
+        case S_MAXPOOL: {
+            const Tensor& sT = T[st.src_t]; const Form& sF = sT.forms[st.src_f];
+            const Tensor& oT = T[nd.out];
+            PoolArgs a{};
+            a.x = A + sF.off; a.in_is_i8 = sF.kind == FORM_I8; a.in_signed = sF.sgn;
+            a.N = N; a.H = sT.H; a.W = sT.W; a.P = oT.H; a.Q = oT.W; a.Cs = sT.Cs; a.k = nd.pk; a.stride = nd.pstride; a.pad = nd.ppad;
+            fill_out(&a.out32, a.q);
+            e = launch_maxpool(a, s);
+            break;
+        }
+        case S_AVGPOOL: {
+            const Tensor& sT = T[st.src_t];
+            AvgArgs a{};
+            a.x = (const int32_t*)(A + sT.forms[st.src_f].off); a.N = N; a.HW = sT.H * sT.W; a.Cs = sT.Cs;
+            fill_out(&a.out32, a.q);
+            e = launch_avgpool(a, s);
+            break;
+        }
+        case S_OUTPUT: {
+            const Tensor& sT = T[st.src_t];
+            OutArgs a{};
+            a.x = (const int32_t*)(A + sT.forms[st.src_f].off); a.N = N; a.C = sT.C; a.HW = sT.H * sT.W; a.Cs = sT.Cs;
+            a.out = output; a.as_float = net->out_float;
+            e = launch_output(a, s);
+            break;
+        }
+    }
+    if (e != hipSuccess) return hip_fail(e, st.name.c_str());
+    return F8_OK;
+}
+
+static int run_common(f8_net* net, const int32_t* input, void* output, int N, void* stream, float* ms, int cap) {
+    if (!net || !net->finalized) return fail(F8_ERR_STATE, "f8_net_run: not finalized");
+    if (N < 1 || N > net->max_batch) return fail(F8_ERR_INVALID, "f8_net_run: N=%d outside [1,%d]", N, net->max_batch);
+    if (!input || !output) return fail(F8_ERR_INVALID, "f8_net_run: null pointer");
+    int rc = f8_net_upload(net);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int ns = (int)net->steps.size();
+    if (ms) {
+        if (cap < ns) return fail(F8_ERR_INVALID, "f8_net_run_profiled: ms capacity %d < %d launches", cap, ns);
+        if (net->n_events < ns + 1) {
+            if (net->events) { for (int i = 0; i < net->n_events; ++i) (void)hipEventDestroy(net->events[i]); delete[] net->events; }
+            net->events = new hipEvent_t[ns + 1]; net->n_events = ns + 1;
+            for (int i = 0; i <= ns; ++i) { hipError_t e = hipEventCreate(&net->events[i]); if (e != hipSuccess) return hip_fail(e, "hipEventCreate"); }
+        }
+        (void)hipEventRecord(net->events[0], s);
+    }
+    for (int i = 0; i < ns; ++i) {
+        rc = run_step(net, net->steps[i], input, output, N, s);
+        if (rc) return rc;
+        if (ms) (void)hipEventRecord(net->events[i + 1], s);
+    }
+    if (ms) {
+        hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return hip_fail(e, "f8_net_run_profiled: sync");
+        for (int i = 0; i < ns; ++i) (void)hipEventElapsedTime(&ms[i], net->events[i], net->events[i + 1]);
+    }
+    return F8_OK;
+}
+
+int f8_net_run(f8_net* net, const int32_t* input, void* output, int N, void* stream) {
+    return run_common(net, input, output, N, stream, nullptr, 0);
+}
+int f8_net_run_profiled(f8_net* net, const int32_t* input, void* output, int N, void* stream, float* ms, int cap) {
+    if (!ms) return fail(F8_ERR_INVALID, "f8_net_run_profiled: null ms");
+    return run_common(net, input, output, N, stream, ms, cap);
+}
+
+}  // extern "C"

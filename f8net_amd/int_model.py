@@ -1,0 +1,153 @@
+"""IntModel / IntBlock-shaped module tree with the reference's state_dict keys.
+
+Mirrors the exported integer models of the reference (`Model.int_model()`,
+/root/reference/models/fix_resnet.py:526-544, fix_mobilenet_v2.py:405-423,
+fix_mobilenet_v1.py:258-281): `head.0`, `stage_{i}_layer_{j}.body.{0,2,4}`,
+`stage_{i}_layer_{j}.shortcut.0`, `tail.0`, `classifier.0`, each with `weight`, `bias` (int32),
+`weight_fraclen`, `input_fraclen`.  `load_state_dict` therefore accepts the reference export's
+state_dict unchanged.
+
+Two forwards over the same parameters:
+  * `forward(x)`            — whole network as ONE planned chain of fused HIP launches (the
+                              performance path; plan cached per input size / batch capacity);
+  * `forward_op_level(x)`   — the reference's own control flow (IntBlock.forward,
+                              fix_resnet.py:26-77) calling our op-level kernels one by one, NCHW
+                              int32 at every seam (the parity granularity).
+Both take what `forward_loss` (fix_train.py:683-692) hands the reference: an int32 NCHW tensor
+carrying the attribute `output_fraclen`, here resident in HBM, and return float32 logits.
+"""
+import torch
+import torch.nn as nn
+
+from . import topology
+from .net import build_net
+from .ops import (F8Conv2d, F8Linear, F8MaxPool2d, FXQAvgPool2d, IntReLU, add_align_,
+                  int_op_only_fix_quant)
+
+
+def _conv_module(c: topology.ConvSpec) -> F8Conv2d:
+    return F8Conv2d(c.cin, c.cout, c.k, stride=c.stride, padding=c.pad, groups=c.groups,
+                    input_symmetric=c.signed_in)
+
+
+class IntBlock(nn.Module):
+    """fix_resnet.py:12-77 / fix_mobilenet_v2.py:11-48 / fix_mobilenet_v1.py:18-38."""
+
+    def __init__(self, bspec: topology.BlockSpec):
+        super().__init__()
+        layers = []
+        for c in bspec.body:
+            # ReLUs occupy the odd indices, so conv keys are body.0/.2/.4 as in the export
+            layers.append(_conv_module(c))
+            layers.append(IntReLU() if c.relu else None)
+        while layers and layers[-1] is None:
+            layers.pop()
+        self.body = nn.Sequential(*[l if l is not None else nn.Identity() for l in layers])
+        self.has_shortcut = bspec.shortcut is not None
+        if self.has_shortcut:
+            self.shortcut = nn.Sequential(_conv_module(bspec.shortcut))
+        self.residual = bspec.residual
+        self.post_relu = IntReLU() if bspec.post_relu else None
+        self.int_op_only = True
+
+    def forward(self, x):
+        res = x
+        for layer_ in self.body:
+            if isinstance(layer_, nn.Conv2d):
+                res = int_op_only_fix_quant(res, 8, layer_.input_fraclen.item(), res.output_fraclen,
+                                            layer_.input_symmetric)
+                res = layer_(res)
+                setattr(res, 'output_fraclen', (layer_.weight_fraclen + layer_.input_fraclen).item())
+            elif not isinstance(layer_, nn.Identity):
+                fl = res.output_fraclen
+                res = layer_(res)
+                setattr(res, 'output_fraclen', fl)
+        if self.has_shortcut:
+            sc = self.shortcut[0]
+            sx = int_op_only_fix_quant(x, 8, sc.input_fraclen.item(), x.output_fraclen, sc.input_symmetric)
+            sx = sc(sx)
+            res, _ = add_align_(res, sx, res.output_fraclen, (sc.weight_fraclen + sc.input_fraclen).item())
+        elif self.residual:
+            res, _ = add_align_(res, x, res.output_fraclen, x.output_fraclen)
+        if self.post_relu is not None:
+            fl = res.output_fraclen
+            res = self.post_relu(res)
+            setattr(res, 'output_fraclen', fl)
+        return res
+
+
+class IntModel(nn.Module):
+    """fix_resnet.py:322-383 / fix_mobilenet_v2.py:179-241 / fix_mobilenet_v1.py:95-147."""
+
+    def __init__(self, spec: topology.NetSpec):
+        super().__init__()
+        self.spec = spec
+        head = [_conv_module(spec.head), IntReLU()]
+        if spec.head_maxpool:
+            head.append(F8MaxPool2d(3, 2, 1))
+        self.head = nn.Sequential(*head)
+        for b in spec.blocks:
+            setattr(self, b.name, IntBlock(b))
+        if spec.tail is not None:
+            self.tail = nn.Sequential(_conv_module(spec.tail), IntReLU())
+        self.avgpool = FXQAvgPool2d(7)
+        self.classifier = nn.Sequential(F8Linear(spec.fc_in, spec.num_classes, input_symmetric=spec.fc_signed_in))
+        self.int_op_only = True
+        self._plans = {}
+
+    # -- performance path ------------------------------------------------------------------
+    def plan(self, hw: int, max_batch: int):
+        key = hw
+        net = self._plans.get(key)
+        if net is None or net.max_batch < max_batch:
+            net = build_net(self.spec, self.state_dict(), max_batch, hw)
+            self._plans[key] = net
+        return net
+
+    def forward(self, x):
+        if not hasattr(x, 'output_fraclen'):
+            raise ValueError('IntModel.forward: input must carry `output_fraclen` (fix_train.py:687,692)')
+        head_fl = int(self.head[0].input_fraclen.item())
+        if x.output_fraclen != head_fl:
+            raise ValueError(f'input output_fraclen {x.output_fraclen} != head.input_fraclen {head_fl}')
+        assert x.shape[2] == x.shape[3], 'square inputs'
+        return self.plan(int(x.shape[2]), int(x.shape[0])).run(x.contiguous())
+
+    def _load_from_state_dict(self, *a, **k):
+        super()._load_from_state_dict(*a, **k)
+        self._plans = {}
+
+    # -- parity path: the reference's control flow over op-level kernels ----------------------
+    def forward_op_level(self, x):
+        fl_in = x.output_fraclen
+        h = self.head[0](x.contiguous())
+        h = self.head[1](h)
+        if self.spec.head_maxpool:
+            h = self.head[2](h)
+        setattr(h, 'output_fraclen', (self.head[0].weight_fraclen + self.head[0].input_fraclen).item())
+        assert fl_in == self.head[0].input_fraclen.item()
+        x = h
+        for b in self.spec.blocks:
+            x = getattr(self, b.name)(x)
+        if self.spec.tail is not None:
+            t0 = self.tail[0]
+            x = int_op_only_fix_quant(x, 8, t0.input_fraclen.item(), x.output_fraclen, t0.input_symmetric)
+            x = self.tail[1](t0(x))
+            setattr(x, 'output_fraclen', (t0.weight_fraclen + t0.input_fraclen).item())
+        x = self.avgpool(x)
+        fl = x.output_fraclen
+        x = x.view(x.size(0), -1)
+        fc = self.classifier[0]
+        x = int_op_only_fix_quant(x, 8, fc.input_fraclen.item(), fl, fc.input_symmetric)
+        return fc(x).float()
+
+
+def from_params(spec: topology.NetSpec, params: dict) -> IntModel:
+    """Build an IntModel and load an exported-IntModel parameter dict (numpy or torch)."""
+    m = IntModel(spec)
+    sd = {}
+    for k, v in params.items():
+        t = v if isinstance(v, torch.Tensor) else torch.from_numpy(__import__('numpy').ascontiguousarray(v))
+        sd[k] = t.to(torch.int32)
+    m.load_state_dict(sd, strict=True)
+    return m

