@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ResNet-50 fixed-point-8 integer forward, bs = 128 images per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the whole hot path over one synthetic batch already resident in HBM:
+int32 NCHW images (the reference's input format, fix_train.py:683-692) -> 57 fused HIP launches
+(libf8net.so) -> fp32 logits; with N > 1 every rank runs its own 128 images (weak scaling) and the
+logits are all-gathered over RCCL (the path's one exchange step).  Rank 0 prints ONE JSON line.
+
+Parameters: the reference's real learned fraction lengths for the NVIDIA-pretrained ResNet-50
+(fraclen_visual/res50_fix_quant_nvidia_pretrained.out:492-1138; `normalize: True`, signed head
+input) with seeded synthetic int8 weights — Model-Zoo checkpoints are unreachable (no network).
+
+roofline  : dominant kernel symbol by time; achieved = sum(algorithmic bytes of its launches) /
+            sum(their durations), durations from HIP events on the launch stream (f8_net_run_profiled).
+cpu_baseline: the CPU oracle (oracle/, a port of the reference's int32 CPU forward) timed on the host
+            cores for a bounded sample of the same workload, rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BS = 128
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+MFMA_I8_PEAK_TOPS = 5033.0     # 256 CU x 4 SIMD x 2048 op/clk x 2.4 GHz
+R50_OPS_PER_IMG = 8.178368512e9        # 2 * 4 089 184 256 MACs
+R50_STRUCT_BYTES_PER_IMG = 93444000.0  # structural byte model of SURVEY.md §8d
+
+
+def cpu_baseline(spec, params, x_np, x_fl, ref_logits):
+    """Time the oracle on a bounded sample (~10-30 s of CPU work) and check it against the GPU."""
+    import numpy as np
+    from oracle import oracle
+    oracle.build()
+    t0 = time.time()
+    y1 = oracle.net_forward(spec, params, x_np[:1], x_fl)
+    t1 = time.time() - t0
+    n = int(max(1, min(16, 15.0 / max(t1, 1e-3))))
+    t0 = time.time()
+    y = oracle.net_forward(spec, params, x_np[:n], x_fl)
+    dt = time.time() - t0
+    ok = bool(np.array_equal(y, ref_logits[:n]) and np.array_equal(y1, ref_logits[:1]))
+    return {'value': round(n / dt, 3), 'unit': 'img/s', 'cores': oracle.num_threads(), 'kind': 'port',
+            'sample': f'{n} images of the same batch (ResNet-50, 224x224), one forward, {dt:.1f} s; '
+                      f'host has {os.cpu_count()} logical cpus',
+            'matches_gpu_bit_exact': ok}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--arch', default='resnet50', help='other nets are parity-test cases, not bench lines')
+    ap.add_argument('--bs', type=int, default=BS, help='images per GPU (the headline metric is quoted at 128)')
+    ap.add_argument('--per-layer', action='store_true', help='also print the per-launch table to stderr')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from f8net_amd import dist as f8dist
+    from f8net_amd import synth, topology
+    from f8net_amd.net import build_net
+
+    global BS
+    BS = args.bs
+    rank, world, local_rank = f8dist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (there is no CPU product path)'
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    normalize = args.arch == 'resnet50'
+    spec = topology.get(args.arch, normalize=normalize)
+    fr = topology.R50_NVIDIA_FRACLENS if args.arch == 'resnet50' else None
+    params = synth.make_params(spec, seed=1234, fraclens=fr)
+    x_np, x_fl = synth.make_input(spec, params, BS, 224, seed=1 + rank)
+    net = build_net(spec, params, max_batch=BS, hw=224)
+    net.upload()
+    x = torch.from_numpy(x_np).to(dev)
+    logits = torch.empty((BS, spec.num_classes), dtype=torch.float32, device=dev)
+    sharded = f8dist.ShardedForward(lambda t: net.run(t, out=logits), spec.num_classes)
+
+    def step():
+        return sharded(x)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert out.shape == (BS * world, spec.num_classes)
+
+    result = None
+    if rank == 0:
+        imgs = BS * world * args.steps
+        value = imgs / dt
+        # ---- roofline of the dominant kernel, measured live (HIP events on the launch stream)
+        n_l = net.num_launches
+        acc = [0.0] * n_l
+        reps = 5
+        for _ in range(reps):
+            _, ms = net.run_profiled(x, out=logits)
+            acc = [a + m for a, m in zip(acc, ms)]
+        ms = [a / reps for a in acc]
+        by_kernel = {}
+        rows = []
+        for i in range(n_l):
+            name, nbytes, nops = net.launch_info(i, BS)
+            k = net.launch_kernel(i)
+            e = by_kernel.setdefault(k, {'ms': 0.0, 'bytes': 0.0, 'ops': 0.0, 'launches': 0})
+            e['ms'] += ms[i]; e['bytes'] += nbytes; e['ops'] += nops; e['launches'] += 1
+            rows.append((i, name, ms[i], nbytes, nops))
+        dom = max(by_kernel, key=lambda k: by_kernel[k]['ms'])
+        d = by_kernel[dom]
+        achieved = d['bytes'] / (d['ms'] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(tpath):     # HBM bytes per launch from separate rocprofv3 --pmc passes
+            try:
+                traffic = json.load(open(tpath)).get(dom, {}).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        total_ms = sum(ms)
+        if args.per_layer:
+            for i, name, m, b, o in rows:
+                print(f'{i:3d} {name:58s} {m*1e3:8.1f} us {b/1e6:8.1f} MB {b/m/1e6 if m else 0:7.0f} GB/s '
+                      f'{o/m/1e9 if m else 0:7.0f} TOP/s', file=sys.stderr)
+            for k, e in sorted(by_kernel.items(), key=lambda kv: -kv[1]['ms']):
+                print(f'  {e["ms"]*1e3:8.1f} us {100*e["ms"]/total_ms:5.1f}% x{e["launches"]:2d}  '
+                      f'{e["bytes"]/e["ms"]/1e6:7.0f} GB/s  {k}', file=sys.stderr)
+        result = {
+            'metric': 'images/sec at bs=128 (ResNet-50 INT8)', 'value': round(value, 1), 'unit': 'img/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * dt / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'int8 x int8 -> int32 (exact integer)', 'data': 'synthetic',
+            'config': {'workload': f'{spec.arch} fix_quant INT8 int_op_only forward, bs={BS} per GPU, 224x224, '
+                                   f'NVIDIA-pretrained fraclens (normalize: True), int32 NCHW input resident in HBM',
+                       'global_batch': BS * world, 'parallelism': f'dp{world} (batch shards + RCCL all-gather of logits)',
+                       'launches_per_step': n_l},
+            'roofline': {'bound': 'hbm', 'kernel': dom, 'launches_per_step': d['launches'],
+                         'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                         'avg_launch_us': round(1e3 * d['ms'] / d['launches'], 2),
+                         'alg_bytes_per_launch': round(d['bytes'] / d['launches'], 0),
+                         'kernel_share_of_step': round(d['ms'] / total_ms, 3)},
+            'whole_net': {'sum_kernel_ms': round(total_ms, 4),
+                          'mfma_int8_frac_of_peak': round(value / world * R50_OPS_PER_IMG / 1e12 / MFMA_I8_PEAK_TOPS, 4),
+                          'hbm_frac_structural_bytes': round(value / world * R50_STRUCT_BYTES_PER_IMG / 1e9 / HBM_PEAK_GBS, 4),
+                          'alg_bytes_per_img': round(sum(r[3] for r in rows) / BS, 0)},
+        }
+        if world == 1 and not args.no_cpu_baseline and args.arch == 'resnet50':
+            result['cpu_baseline'] = cpu_baseline(spec, params, x_np, x_fl, logits[:BS].cpu().numpy())
+        elif world == 1:
+            result['cpu_baseline'] = None
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == '__main__':
+    main()

@@ -62,6 +62,7 @@ SYMBOLS = [
     ('f8_net_run_profiled', _i, [_vp, _vp, _vp, _i, _vp, ctypes.POINTER(ctypes.c_float), _i]),
     ('f8_net_launch_info', _i, [_vp, _i, _i, ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_double),
                                 ctypes.POINTER(ctypes.c_double)]),
+    ('f8_net_launch_kernel', _i, [_vp, _i, ctypes.c_char_p, _sz]),
     ('f8_net_set_label', _i, [_vp, _i, ctypes.c_char_p]),
 ]
 

@@ -85,7 +85,7 @@ struct Step {
     OutSel out;
     int acc_shl = 0, res_shl = 0, relu0 = 0, relu1 = 0;
     bool dense = false;
-    std::string name;
+    std::string name, kernel;          // kernel = device symbol as rocprofv3 prints it
     double bytes_per_img = 0, bytes_const = 0, ops_per_img = 0;
 };
 
@@ -507,7 +507,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
             Step st; st.kind = S_REQUANT; st.node = T[t].prod;
             st.src_t = t; st.src_f = find_form(T[t], FORM_I32, 0, 0);
             st.out.t = t; st.out.f8[0] = f;
-            st.name = "requant:" + tname(net, t);
+            st.name = "requant:" + tname(net, t); st.kernel = "f8::add_kernel";
             const double e = (double)T[t].H * T[t].W * T[t].Cs;
             st.bytes_per_img = e * 5;
             net->steps.push_back(st);
@@ -529,7 +529,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                         return fail(F8_ERR_UNSUPPORTED, "finalize: a conv with quant_input=1 directly on the network input "
                                     "(the reference feeds head-format integers, fix_train.py:683-692)");
                 st.out.t = nd.out;
-                st.name = "input";
+                st.name = "input"; st.kernel = "f8::input_kernel";
                 double b = (double)o.C * o.H * o.W * 4;
                 for (auto& F : o.forms) b += (double)o.H * o.W * (F.kind == FORM_I32 ? o.Cs * 4 : (F.kind == FORM_STEM ? 4 : o.Cs));
                 st.bytes_per_img = b;
@@ -576,6 +576,13 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 else snprintf(buf, sizeof buf, "conv%dx%ds%d_t%dx%dx%d%s%s:%s", d.kernel, d.kernel, d.stride, nd.tile.bm, nd.tile.bn,
                               nd.tile.bk, nd.stem ? "_stem" : "", st.res_t >= 0 ? "_res" : "", tname(net, nd.out).c_str());
                 st.name = buf;
+                if (nd.depthwise) snprintf(buf, sizeof buf, "f8::dwconv3x3_kernel<%s>", d.input_signed ? "true" : "false");
+                else {
+                    const int wpx = (nd.tile.bm == 128 && nd.tile.bn <= 64) ? 4 : 2, wco = 4 / wpx;
+                    snprintf(buf, sizeof buf, "f8::conv_igemm_kernel<%d, %d, %d, %d, %d, %s>", nd.tile.bm, nd.tile.bn, nd.tile.bk, wpx, wco,
+                             (d.pad > 0 && !nd.stem) ? "true" : "false");
+                }
+                st.kernel = buf;
                 break;
             }
             case N_ADD: {
@@ -586,7 +593,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 st.acc_shl = dfl < 0 ? -dfl : 0; st.res_shl = dfl > 0 ? dfl : 0;
                 st.relu1 = nd.relu;
                 select_outputs(net, nd.out, &st.out, &extra);
-                st.name = "add:" + tname(net, nd.out);
+                st.name = "add:" + tname(net, nd.out); st.kernel = "f8::add_kernel";
                 const double e = (double)T[nd.out].H * T[nd.out].W * T[nd.out].Cs;
                 st.bytes_per_img = e * 8 + (st.out.f32 >= 0 ? e * 4 : 0) + (st.out.f8[0] >= 0 ? e : 0) + (st.out.f8[1] >= 0 ? e : 0);
                 break;
@@ -599,7 +606,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 st.src_f = i8 ? find_form(s, FORM_I8, o.forms[0].n, o.forms[0].sgn) : find_form(s, FORM_I32, 0, 0);
                 if (o.forms.empty()) add_form(o, FORM_I32, 0, 0);
                 select_outputs(net, nd.out, &st.out, &extra);
-                st.name = std::string(i8 ? "maxpool_i8:" : "maxpool_i32:") + tname(net, nd.out);
+                st.name = std::string(i8 ? "maxpool_i8:" : "maxpool_i32:") + tname(net, nd.out); st.kernel = "f8::maxpool_kernel";
                 const double ei = (double)s.H * s.W * s.Cs, eo = (double)o.H * o.W * o.Cs;
                 st.bytes_per_img = ei * (i8 ? 1 : 4) + (st.out.f32 >= 0 ? eo * 4 : 0) + (st.out.f8[0] >= 0 ? eo : 0) + (st.out.f8[1] >= 0 ? eo : 0);
                 break;
@@ -610,7 +617,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 st.src_t = nd.a; st.src_f = find_form(s, FORM_I32, 0, 0);
                 if (o.forms.empty()) add_form(o, FORM_I32, 0, 0);
                 select_outputs(net, nd.out, &st.out, &extra);
-                st.name = "avgpool_sum:" + tname(net, nd.out);
+                st.name = "avgpool_sum:" + tname(net, nd.out); st.kernel = "f8::avgpool_kernel";
                 st.bytes_per_img = (double)s.H * s.W * s.Cs * 4 + (double)o.Cs * 5;
                 break;
             }
@@ -621,7 +628,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
     if (!T[net->out_t].dense_out) {
         Step st; st.kind = S_OUTPUT; st.node = T[net->out_t].prod;
         st.src_t = net->out_t; st.src_f = find_form(T[net->out_t], FORM_I32, 0, 0);
-        st.name = "output:" + tname(net, net->out_t);
+        st.name = "output:" + tname(net, net->out_t); st.kernel = "f8::output_kernel";
         st.bytes_per_img = (double)T[net->out_t].H * T[net->out_t].W * (T[net->out_t].Cs + T[net->out_t].C) * 4;
         net->steps.push_back(st);
     }
@@ -745,6 +752,13 @@ int f8_net_launch_info(const f8_net* net, int i, int N, char* name, size_t name_
     if (name && name_cap) { snprintf(name, name_cap, "%s", st.name.c_str()); }
     if (alg_bytes) *alg_bytes = st.bytes_per_img * N + st.bytes_const;
     if (alg_ops) *alg_ops = st.ops_per_img * N;
+    return F8_OK;
+}
+
+int f8_net_launch_kernel(const f8_net* net, int i, char* buf, size_t cap) {
+    if (!net || !net->finalized) return fail(F8_ERR_STATE, "f8_net_launch_kernel: not finalized");
+    if (i < 0 || i >= (int)net->steps.size()) return fail(F8_ERR_INVALID, "f8_net_launch_kernel: index");
+    if (buf && cap) snprintf(buf, cap, "%s", net->steps[i].kernel.c_str());
     return F8_OK;
 }
 

@@ -1,0 +1,77 @@
+"""Batch sharding across the GPUs of one node: one process per GPU, RCCL over xGMI.
+
+The path shards naturally — images are independent, the ≤ 26 MB of packed weights are replicated
+per GPU — so ranks run their contiguous slice of the batch with no data-path collective.  The one
+exchange step is an all-gather of the per-rank logits (fp32 [n/world, classes], ≈ 0.5 MB per rank
+at 128 images), which replaces the reference's `DataParallel` gather
+(/root/reference/fix_train.py:269) and metric all-reduce (fix_train.py:705-707,
+myutils/distributed.py:79-87).  At that size the collective is latency-bound; ring vs direct over
+the 7 xGMI links does not matter.
+
+`torch.distributed` backend "nccl" is RCCL on ROCm; the CPU tests drive the same code over gloo.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Join the process group the launcher (torchrun / torch.distributed.run) described in the env.
+    Returns (rank, world_size, local_rank).  Single-process runs need no group."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def shard_bounds(n_total: int, world: int, rank: int):
+    """Contiguous slice [lo, hi) of a batch of n_total images owned by `rank`; the first
+    n_total % world ranks take one extra image (ragged batches are legal)."""
+    base, extra = divmod(n_total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class ShardedForward:
+    """Data-parallel forward: `forward_local` maps this rank's images to fp32 logits (on the GPU:
+    `F8Net.run`); the logits of all ranks are all-gathered in rank order."""
+
+    def __init__(self, forward_local, num_classes: int, group=None):
+        self.forward_local = forward_local
+        self.num_classes = num_classes
+        self.group = group
+
+    @property
+    def world(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def gather(self, local_logits, n_total=None):
+        """All-gather per-rank logits [n_r, classes] -> [sum n_r, classes] on every rank."""
+        world = self.world
+        if world == 1:
+            return local_logits
+        n_local = local_logits.shape[0]
+        if n_total is None or n_total == n_local * world:
+            out = local_logits.new_empty((n_local * world, self.num_classes))
+            dist.all_gather_into_tensor(out, local_logits.contiguous(), group=self.group)
+            return out
+        # ragged shards: pad to the largest shard, gather, drop the padding
+        sizes = [shard_bounds(n_total, world, r) for r in range(world)]
+        cap = max(hi - lo for lo, hi in sizes)
+        padded = local_logits.new_zeros((cap, self.num_classes))
+        padded[:n_local] = local_logits
+        out = local_logits.new_empty((cap * world, self.num_classes))
+        dist.all_gather_into_tensor(out, padded, group=self.group)
+        return torch.cat([out[r * cap: r * cap + (hi - lo)] for r, (lo, hi) in enumerate(sizes)])
+
+    def __call__(self, x_local, n_total=None):
+        return self.gather(self.forward_local(x_local), n_total)

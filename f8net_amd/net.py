@@ -126,6 +126,11 @@ class F8Net:
         check(self._L.f8_net_launch_info(self._h, i, N, name, 256, ctypes.byref(b), ctypes.byref(o)))
         return name.value.decode(), b.value, o.value
 
+    def launch_kernel(self, i):
+        buf = ctypes.create_string_buffer(256)
+        check(self._L.f8_net_launch_kernel(self._h, i, buf, 256))
+        return buf.value.decode()
+
     # ---- execution (torch = device memory + stream plumbing) ---------------------------------
     def upload(self):
         check(self._L.f8_net_upload(self._h))

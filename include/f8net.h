@@ -167,6 +167,9 @@ int f8_net_run_profiled(f8_net* net, const int32_t* input_dev, void* output_dev,
 int f8_net_launch_info(const f8_net* net, int i, int N, char* name, size_t name_cap,
                        double* alg_bytes, double* alg_ops);
 
+/* Device kernel symbol of launch i as rocprofv3 --kernel-trace prints it (without the argument list). */
+int f8_net_launch_kernel(const f8_net* net, int i, char* buf, size_t cap);
+
 /* Attach a label (e.g. the state_dict key) to the node that produced tensor `t`. */
 int f8_net_set_label(f8_net* net, int t, const char* label);
 
