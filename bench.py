@@ -55,6 +55,7 @@ def cpu_baseline(spec, params, x_np, x_fl, ref_logits):
 
 
 def main():
+    global BS
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
@@ -72,7 +73,6 @@ def main():
     from f8net_amd import synth, topology
     from f8net_amd.net import build_net
 
-    global BS
     BS = args.bs
     rank, world, local_rank = f8dist.init_from_env()
     if world != args.gpus:

@@ -38,8 +38,6 @@ struct ConvArgs {
     int32_t relu1;                         // ReLU after the residual add
     int32_t* out32;                        // NHWC int32 (stride coutP) or nullptr
     QuantOut q[2];
-    // dense [M][ldo] float32 / int32 output with a real-cout guard (linear logits), or nullptr
-    void* outd; int32_t ldo, cout_real, outd_float;
 };
 
 // Depthwise 3x3 (groups == C), NHWC int8 in, VALU.
@@ -66,8 +64,8 @@ struct AvgArgs {                           // FXQAvgPool2d sum over H*W, NHWC in
     QuantOut q[2];
 };
 
-struct AddArgs {                           // standalone align-add (when it cannot be fused)
-    const int32_t* a; const int32_t* b; size_t n;
+struct AddArgs {                           // standalone align-add (when it cannot be fused) / requant
+    const int32_t* a; const int32_t* b; int32_t M, Cs;   // M pixels x Cs channels, int32 in I32T layout
     int32_t a_shl, b_shl, relu;
     int32_t* out32;
     QuantOut q[2];
@@ -88,7 +86,7 @@ struct OutArgs {                           // NHWC int32 -> NCHW int32 / float32
 struct ConvTile { int bm, bn, bk; };
 
 // Tile choice for a conv; returns false if no kernel instance fits (ck % bk).
-bool pick_conv_tile(int M, int coutP, int ck, bool has_pad, ConvTile* t);
+bool pick_conv_tile(int M, int coutP, int ck, bool has_res, ConvTile* t);
 int  conv_grid(const ConvTile& t, int M, int coutP);
 
 hipError_t launch_conv(const ConvArgs& a, const ConvTile& t, hipStream_t s);

@@ -14,6 +14,7 @@
 // folded into the packed bias on the host (f8_net.cpp: pack_conv_weights).  Everything is mod 2^32,
 // so the identity is exact under wrap-around.
 #include "f8_internal.h"
+#include <cstdlib>
 
 namespace f8 {
 
@@ -44,6 +45,17 @@ __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d) {
            ((unsigned)d << 24);
 }
 
+// int32 tensors live in an MFMA-fragment-tiled layout ("I32T"), not NHWC: blocks of 32 pixels x 32
+// channels (4 KB), inside a block the order is [g = (c%32)/8][lane = ((c/4)&1)*32 + m%32][c%4] — exactly
+// the accumulator layout of v_mfma_i32_32x32x32_i8 — so that a wave's residual read / int32 write of
+// one accumulator group is ONE contiguous 1 KB transaction (64 lanes x 16 B) instead of 32 scattered
+// 32-byte pieces.  m = linear pixel index n*P*Q + p*Q + q; rows are padded to a multiple of 32.
+// Returns the int index of channel c (c % 4 == 0 for vector access) of pixel m.
+__device__ __forceinline__ size_t i32t_index(int m, int c, int Cs) {
+    return ((size_t)(m >> 5) * (size_t)(Cs >> 5) + (size_t)(c >> 5)) * 1024u +
+           (size_t)(((((c & 31) >> 3) * 64 + ((c >> 2) & 1) * 32 + (m & 31)) << 2) + (c & 3));
+}
+
 __device__ __forceinline__ int clamp_sym31(int v) {   // clamp_(max=2^31-1, min=-(2^31-1))
     return max(v, -2147483647);
 }
@@ -65,7 +77,7 @@ __device__ __forceinline__ int clamp_sym31(int v) {   // clamp_(max=2^31-1, min=
 // Pipeline: global -> registers (next K step in flight during the MFMAs) -> XOR -> LDS, two LDS
 // buffers, one barrier per K step.
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int BK, int WPX, int WCO, bool HAS_PAD>
+template <int BM, int BN, int BK, int WPX, int WCO, bool HAS_PAD, bool HAS_RES>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     static_assert(WPX * WCO == 4, "4 waves");
     constexpr int CPR = BK / 16;                  // chunks per row
@@ -144,6 +156,28 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
 
+    // Residual operand: ALL of the wave tile's int32 rows are requested before the K loop, so their
+    // HBM latency overlaps the operand staging and the MFMAs (the in-place out32 store of the same
+    // addresses comes later from the same lane).  16 B per lane per (cout tile, pixel tile, group).
+    v4i rv[HAS_RES ? TCO : 1][HAS_RES ? TPX : 1][4];
+    if (HAS_RES) {
+#pragma unroll
+        for (int i = 0; i < TCO; ++i)
+#pragma unroll
+            for (int j = 0; j < TPX; ++j) {
+                const int cot = co0 + wco * (BN / WCO) + i * 32;
+                const int m = m0 + wpx * (BM / WPX) + j * 32 + l31;
+                // whole 32-pixel tiles exist in the (row-padded) I32T buffer: guard per tile, not per lane
+                const bool ld = (m - l31 < a.M) && (cot < a.coutP);
+                const int32_t* rp = a.res + i32t_index(m, cot, a.coutP) + 4 * 32 * lh;   // + g*256
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    v4i z = {0, 0, 0, 0};
+                    rv[i][j][g] = ld ? *(const v4i*)(rp + g * 256) : z;
+                }
+            }
+    }
+
     v4i xr[XL], wr[WL];
     const int nk = a.ktot / BK;
     // K-step state (wave-uniform): tap row/col, channel offset inside the tap
@@ -209,8 +243,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: bias -> ReLU -> [align + residual + clamp -> ReLU] -> int32 / requant int8 / dense
-    const bool has_res = a.res != nullptr;
+    // ---- epilogue: bias -> ReLU -> [align + residual + clamp -> ReLU] -> int32 / requantised int8
+    // ReLUs are branch-free floors (INT32_MIN = no ReLU).
+    const int floor0 = a.relu0 ? 0 : INT32_MIN, floor1 = a.relu1 ? 0 : INT32_MIN;
 #pragma unroll
     for (int i = 0; i < TCO; ++i) {
         const int cot = co0 + wco * (BN / WCO) + i * 32;   // first cout of this 32-wide MFMA tile
@@ -223,65 +258,43 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
             const int m = m0 + wpx * (BM / WPX) + j * 32 + l31;
             const bool ok = m < a.M;
             const size_t rowo = (size_t)m * (size_t)a.coutP;
-            unsigned d0[4], d1[4];
+            int y[4][4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = cot + 8 * g + 4 * lh;
-                int y[4];
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = (int)((unsigned)acc[i][j][4 * g + e] + (unsigned)bv[g][e]);
-                if (a.relu0) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) y[e] = max(y[e], 0);
-                }
-                if (has_res) {
-                    v4i rv = {0, 0, 0, 0};
-                    if (ok) rv = *(const v4i*)(a.res + rowo + co);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const unsigned s = ((unsigned)y[e] << a.acc_shl) + ((unsigned)rv[e] << a.res_shl);
-                        y[e] = clamp_sym31((int)s);
-                        if (a.relu1) y[e] = max(y[e], 0);
+                for (int e = 0; e < 4; ++e) {
+                    int v = max((int)((unsigned)acc[i][j][4 * g + e] + (unsigned)bv[g][e]), floor0);
+                    if (HAS_RES) {
+                        const unsigned s = ((unsigned)v << a.acc_shl) + ((unsigned)rv[i][j][g][e] << a.res_shl);
+                        v = max(clamp_sym31((int)s), floor1);
                     }
+                    y[g][e] = v;
                 }
-                if (a.out32 && ok) {
-                    v4i o = {y[0], y[1], y[2], y[3]};
-                    *(v4i*)(a.out32 + rowo + co) = o;
-                }
-                if (a.outd && ok) {
+            if (a.out32 && (m - l31 < a.M)) {              // I32T: 4 x 1 KB contiguous per wave
+                int32_t* op = a.out32 + i32t_index(m, cot, a.coutP) + 4 * 32 * lh;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (co + e < a.cout_real) {
-                            const size_t o = (size_t)m * (size_t)a.ldo + (size_t)(co + e);
-                            if (a.outd_float) ((float*)a.outd)[o] = (float)y[e];
-                            else ((int*)a.outd)[o] = y[e];
-                        }
+                for (int g = 0; g < 4; ++g) {
+                    v4i o = {y[g][0], y[g][1], y[g][2], y[g][3]};
+                    *(v4i*)(op + g * 256) = o;
                 }
-                if (a.q[0].ptr)
-                    d0[g] = pack4(requant1(y[0], a.q[0].n, a.q[0].lo, a.q[0].hi), requant1(y[1], a.q[0].n, a.q[0].lo, a.q[0].hi),
-                                  requant1(y[2], a.q[0].n, a.q[0].lo, a.q[0].hi), requant1(y[3], a.q[0].n, a.q[0].lo, a.q[0].hi));
-                if (a.q[1].ptr)
-                    d1[g] = pack4(requant1(y[0], a.q[1].n, a.q[1].lo, a.q[1].hi), requant1(y[1], a.q[1].n, a.q[1].lo, a.q[1].hi),
-                                  requant1(y[2], a.q[1].n, a.q[1].lo, a.q[1].hi), requant1(y[3], a.q[1].n, a.q[1].lo, a.q[1].hi));
             }
             // int8 rows: lanes l and l+32 hold interleaved 4-channel groups of one pixel
             //   lower: d[0]=c0-3  d[1]=c8-11  d[2]=c16-19 d[3]=c24-27
             //   upper: d[0]=c4-7  d[1]=c12-15 d[2]=c20-23 d[3]=c28-31
             // two half-swaps give each lane 16 contiguous channel bytes (lower c0-15, upper c16-31).
-            if (a.q[0].ptr) {
-                auto s0 = __builtin_amdgcn_permlane32_swap(d0[0], d0[2], false, false);
-                auto s1 = __builtin_amdgcn_permlane32_swap(d0[1], d0[3], false, false);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (!a.q[k].ptr) continue;                 // wave-uniform
+                unsigned d[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    d[g] = pack4(requant1(y[g][0], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(y[g][1], a.q[k].n, a.q[k].lo, a.q[k].hi),
+                                 requant1(y[g][2], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(y[g][3], a.q[k].n, a.q[k].lo, a.q[k].hi));
+                auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+                auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
                 if (ok) {
                     v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
-                    *(v4i*)(a.q[0].ptr + rowo + cot + 16 * lh) = o;
-                }
-            }
-            if (a.q[1].ptr) {
-                auto s0 = __builtin_amdgcn_permlane32_swap(d1[0], d1[2], false, false);
-                auto s1 = __builtin_amdgcn_permlane32_swap(d1[1], d1[3], false, false);
-                if (ok) {
-                    v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
-                    *(v4i*)(a.q[1].ptr + rowo + cot + 16 * lh) = o;
+                    *(v4i*)(a.q[k].ptr + rowo + cot + 16 * lh) = o;
                 }
             }
         }
@@ -332,8 +345,9 @@ __global__ void __launch_bounds__(256) dwconv3x3_kernel(const DwArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] = max(acc[e], 0);
         }
-        const size_t o = (((size_t)n * a.P + p) * a.Q + q) * a.Cs + c;
-        if (a.out32) { v4i v = {acc[0], acc[1], acc[2], acc[3]}; *(v4i*)(a.out32 + o) = v; }
+        const int mo = (n * a.P + p) * a.Q + q;
+        const size_t o = (size_t)mo * a.Cs + c;
+        if (a.out32) { v4i v = {acc[0], acc[1], acc[2], acc[3]}; *(v4i*)(a.out32 + i32t_index(mo, c, a.Cs)) = v; }
 #pragma unroll
         for (int k = 0; k < 2; ++k)
             if (a.q[k].ptr)
@@ -367,26 +381,27 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const PoolArgs a) {
             for (int s = 0; s < a.k; ++s) {
                 const int w = w0 + s;
                 if ((unsigned)w >= (unsigned)a.W) continue;
-                const size_t off = (((size_t)n * a.H + h) * a.W + w) * a.Cs + c;
+                const int mi = (n * a.H + h) * a.W + w;
                 if (a.in_is_i8) {
-                    const unsigned xv = *(const unsigned*)((const int8_t*)a.x + off);
+                    const unsigned xv = *(const unsigned*)((const int8_t*)a.x + (size_t)mi * a.Cs + c);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int xe = a.in_signed ? (int)(signed char)(xv >> (8 * e)) : (int)((xv >> (8 * e)) & 0xffu);
                         mx[e] = max(mx[e], xe);
                     }
                 } else {
-                    const v4i xv = *(const v4i*)((const int32_t*)a.x + off);
+                    const v4i xv = *(const v4i*)((const int32_t*)a.x + i32t_index(mi, c, a.Cs));
                     mx[0] = max(mx[0], xv.x); mx[1] = max(mx[1], xv.y);
                     mx[2] = max(mx[2], xv.z); mx[3] = max(mx[3], xv.w);
                 }
             }
         }
-        const size_t o = (((size_t)n * a.P + p) * a.Q + q) * a.Cs + c;
+        const int mo = (n * a.P + p) * a.Q + q;
+        const size_t o = (size_t)mo * a.Cs + c;
         if (a.in_is_i8) {
             *(unsigned*)(a.q[0].ptr + o) = pack4(mx[0], mx[1], mx[2], mx[3]);
         } else {
-            if (a.out32) { v4i v = {mx[0], mx[1], mx[2], mx[3]}; *(v4i*)(a.out32 + o) = v; }
+            if (a.out32) { v4i v = {mx[0], mx[1], mx[2], mx[3]}; *(v4i*)(a.out32 + i32t_index(mo, c, a.Cs)) = v; }
 #pragma unroll
             for (int k = 0; k < 2; ++k)
                 if (a.q[k].ptr)
@@ -404,16 +419,15 @@ __global__ void __launch_bounds__(256) avgpool_kernel(const AvgArgs a) {
     if (idx >= a.N * cgs) return;
     const int cg = idx % cgs, n = idx / cgs, c = cg << 2;
     long long s[4] = {0, 0, 0, 0};
-    const int32_t* xp = a.x + (size_t)n * a.HW * a.Cs + c;
     for (int i = 0; i < a.HW; ++i) {
-        const v4i v = *(const v4i*)(xp + (size_t)i * a.Cs);
+        const v4i v = *(const v4i*)(a.x + i32t_index(n * a.HW + i, c, a.Cs));
         s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
     }
     int t[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) t[e] = (int)(unsigned)(unsigned long long)s[e];
     const size_t o = (size_t)n * a.Cs + c;
-    if (a.out32) { v4i v = {t[0], t[1], t[2], t[3]}; *(v4i*)(a.out32 + o) = v; }
+    if (a.out32) { v4i v = {t[0], t[1], t[2], t[3]}; *(v4i*)(a.out32 + i32t_index(n, c, a.Cs)) = v; }
 #pragma unroll
     for (int k = 0; k < 2; ++k)
         if (a.q[k].ptr)
@@ -422,25 +436,29 @@ __global__ void __launch_bounds__(256) avgpool_kernel(const AvgArgs a) {
                       requant1(t[2], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(t[3], a.q[k].n, a.q[k].lo, a.q[k].hi));
 }
 
-// Stand-alone residual join (only when it cannot ride in a conv epilogue).  4 elements / thread.
+// Stand-alone residual join (only when it cannot ride in a conv epilogue) and stand-alone requant
+// (b == nullptr; third and later int8 formats of one tensor).  One thread = one pixel x 4 channels.
 __global__ void __launch_bounds__(256) add_kernel(const AddArgs a) {
-    const size_t n4 = a.n >> 2;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const v4i av = ((const v4i*)a.a)[i];
+    const int cgs = a.Cs >> 2;
+    const size_t total = (size_t)a.M * cgs;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cgs) << 2, m = (int)(idx / cgs);
+        const size_t it = i32t_index(m, c, a.Cs);
+        const v4i av = *(const v4i*)(a.a + it);
         int y[4] = {av.x, av.y, av.z, av.w};
-        if (a.b) {   // b == nullptr: pure requant of an int32 tensor (third and later int8 formats)
-            const v4i bv = ((const v4i*)a.b)[i];
+        if (a.b) {
+            const v4i bv = *(const v4i*)(a.b + it);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 y[e] = clamp_sym31((int)(((unsigned)av[e] << a.a_shl) + ((unsigned)bv[e] << a.b_shl)));
                 if (a.relu) y[e] = max(y[e], 0);
             }
         }
-        if (a.out32) { v4i v = {y[0], y[1], y[2], y[3]}; ((v4i*)a.out32)[i] = v; }
+        if (a.out32) { v4i v = {y[0], y[1], y[2], y[3]}; *(v4i*)(a.out32 + it) = v; }
 #pragma unroll
         for (int k = 0; k < 2; ++k)
             if (a.q[k].ptr)
-                ((unsigned*)a.q[k].ptr)[i] =
+                *(unsigned*)(a.q[k].ptr + (size_t)m * a.Cs + c) =
                     pack4(requant1(y[0], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(y[1], a.q[k].n, a.q[k].lo, a.q[k].hi),
                           requant1(y[2], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(y[3], a.q[k].n, a.q[k].lo, a.q[k].hi));
     }
@@ -469,9 +487,8 @@ __global__ void __launch_bounds__(256) input_kernel(const InArgs a) {
             for (int c = a.C; c < a.Cs8; ++c) o[c] = 0;
         }
         if (a.out32) {
-            int32_t* o = a.out32 + (((size_t)n * a.H + h) * a.W + w) * a.Cs32;
-            for (int c = 0; c < a.C; ++c) o[c] = xp[c * plane];
-            for (int c = a.C; c < a.Cs32; ++c) o[c] = 0;
+            const int m = (n * a.H + h) * a.W + w;
+            for (int c = 0; c < a.Cs32; ++c) a.out32[i32t_index(m, c, a.Cs32)] = c < a.C ? xp[c * plane] : 0;
         }
     }
 }
@@ -485,7 +502,7 @@ __global__ void __launch_bounds__(256) output_kernel(const OutArgs a) {
         size_t t = idx / a.HW;
         const int c = (int)(t % a.C);
         const int n = (int)(t / a.C);
-        const int v = a.x[((size_t)n * a.HW + i) * a.Cs + c];
+        const int v = a.x[i32t_index(n * a.HW + i, c, a.Cs)];
         if (a.as_float) ((float*)a.out)[idx] = (float)v;
         else ((int*)a.out)[idx] = v;
     }
@@ -515,16 +532,22 @@ static inline int grid_for(size_t work, int block = 256, int cap = 256 * 8 * 4) 
     return (int)g;
 }
 
-bool pick_conv_tile(int M, int coutP, int ck, bool has_pad, ConvTile* t) {
-    (void)has_pad;
+bool pick_conv_tile(int M, int coutP, int ck, bool has_res, ConvTile* t) {
     if (ck % 32 != 0 || coutP % 32 != 0) return false;
     t->bk = (ck % 64 == 0) ? 64 : 32;
     t->bn = coutP >= 96 ? 128 : (coutP > 32 ? 64 : 32);
     t->bm = 128;
+    // residual-carrying epilogues hold the int32 operand in registers: the 64-wide tile keeps
+    // 4 waves/SIMD resident instead of 2, which is what a streaming epilogue needs
+    if (has_res && t->bn == 128) t->bn = 64;
     // not enough workgroups for 256 CUs: shrink the tile (bm first: keeps cout reuse of X rows)
     auto tiles = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((coutP + bn - 1) / bn); };
     if (tiles(t->bm, t->bn) < 512 && t->bn >= 64) t->bm = 64;
     if (tiles(t->bm, t->bn) < 512 && t->bn == 128) t->bn = 64;
+    // experiment hooks (tuning only)
+    if (const char* e = getenv(has_res ? "F8_RES_BN" : "F8_BN")) { const int v = atoi(e); if (v == 32 || v == 64 || v == 128) t->bn = v; }
+    if (const char* e = getenv(has_res ? "F8_RES_BM" : "F8_BM")) { const int v = atoi(e); if (v == 64 || v == 128) t->bm = v; }
+    if (t->bm == 64 && t->bn == 32) t->bn = 64;
     return true;
 }
 
@@ -534,8 +557,11 @@ int conv_grid(const ConvTile& t, int M, int coutP) {
 
 template <int BM, int BN, int BK, int WPX, int WCO>
 static hipError_t launch_conv_t(const ConvArgs& a, int grid, hipStream_t s) {
-    if (a.pad > 0) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, true>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, false>), dim3(grid), dim3(256), 0, s, a);
+    const bool pad = a.pad > 0, res = a.res != nullptr;
+    if (pad && res) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, true, true>), dim3(grid), dim3(256), 0, s, a);
+    else if (pad) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, true, false>), dim3(grid), dim3(256), 0, s, a);
+    else if (res) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, false, true>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, false, false>), dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -574,7 +600,7 @@ hipError_t launch_avgpool(const AvgArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_add(const AddArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(add_kernel, dim3(grid_for(a.n >> 2)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for((size_t)a.M * (a.Cs >> 2))), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_input(const InArgs& a, hipStream_t s) {

@@ -49,6 +49,7 @@ enum FormKind { FORM_I32 = 0, FORM_I8 = 1, FORM_STEM = 2 };
 struct Form {
     int kind; int n; int sgn;          // I8: requant shift + signedness of the consumer format
     size_t bytes_per_img = 0;
+    size_t slack = 0;                  // I32T: rows padded to a multiple of 32 pixels
     size_t off = 0;                    // arena offset (max_batch sized)
     int first = -1, last = -1;         // step lifetime
     int Hp = 0, Wp = 0, pad = 0;       // STEM
@@ -445,8 +446,8 @@ int f8_net_finalize(f8_net* net, int max_batch) {
     {
         Tensor& O = T[net->out_t];
         const Node& p = ND[O.prod];
-        if (p.kind == N_LINEAR && O.consumers.empty()) O.dense_out = true;
-        else add_form(O, FORM_I32, 0, 0);
+        (void)p;
+        add_form(O, FORM_I32, 0, 0);
     }
     for (int i = nn - 1; i >= 0; --i) {
         Node& nd = ND[i];
@@ -546,7 +547,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 else {
                     pack_conv_weights(net, nd, s);
                     const int M1 = T[nd.out].H * T[nd.out].W;
-                    if (!pick_conv_tile(M1 * max_batch, nd.coutP, nd.ck, nd.cd.pad > 0 && !nd.stem, &nd.tile))
+                    if (!pick_conv_tile(M1 * max_batch, nd.coutP, nd.ck, nd.fused_add >= 0, &nd.tile))
                         return fail(F8_ERR_UNSUPPORTED, "finalize: no conv kernel instance for ck=%d coutP=%d", nd.ck, nd.coutP);
                 }
                 if (nd.fused_add >= 0) {
@@ -579,8 +580,8 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 if (nd.depthwise) snprintf(buf, sizeof buf, "f8::dwconv3x3_kernel<%s>", d.input_signed ? "true" : "false");
                 else {
                     const int wpx = (nd.tile.bm == 128 && nd.tile.bn <= 64) ? 4 : 2, wco = 4 / wpx;
-                    snprintf(buf, sizeof buf, "f8::conv_igemm_kernel<%d, %d, %d, %d, %d, %s>", nd.tile.bm, nd.tile.bn, nd.tile.bk, wpx, wco,
-                             (d.pad > 0 && !nd.stem) ? "true" : "false");
+                    snprintf(buf, sizeof buf, "f8::conv_igemm_kernel<%d, %d, %d, %d, %d, %s, %s>", nd.tile.bm, nd.tile.bn, nd.tile.bk, wpx, wco,
+                             (d.pad > 0 && !nd.stem) ? "true" : "false", st.res_t >= 0 ? "true" : "false");
                 }
                 st.kernel = buf;
                 break;
@@ -672,7 +673,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
     };
     for (auto& t : T)
         for (auto& F : t.forms) {
-            if (F.kind == FORM_I32) F.bytes_per_img = (size_t)t.H * t.W * t.Cs * 4;
+            if (F.kind == FORM_I32) { F.bytes_per_img = (size_t)t.H * t.W * t.Cs * 4; F.slack = (size_t)32 * t.Cs * 4; }
             else if (F.kind == FORM_I8) F.bytes_per_img = (size_t)t.H * t.W * t.Cs;
             else F.bytes_per_img = (size_t)F.Hp * F.Wp * 4;
         }
@@ -700,12 +701,12 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                         continue;
                     }
                 }
-                F.off = alloc(F.bytes_per_img * max_batch);
+                F.off = alloc(F.bytes_per_img * max_batch + F.slack);
             }
         // forms dying at this step
         for (size_t ti = 0; ti < T.size(); ++ti)
             for (auto& F : T[ti].forms)
-                if (F.kind != FORM_STEM && F.last == (int)si && F.first >= 0) release(F.off, F.bytes_per_img * max_batch);
+                if (F.kind != FORM_STEM && F.last == (int)si && F.first >= 0) release(F.off, F.bytes_per_img * max_batch + F.slack);
     }
     net->arena_bytes = top;
     for (auto& t : T)
@@ -825,7 +826,6 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             a.relu0 = st.relu0;
             if (st.res_t >= 0) { a.res = (const int32_t*)(A + T[st.res_t].forms[st.res_f].off); a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1; }
             fill_out(&a.out32, a.q);
-            if (st.dense) { a.outd = output; a.ldo = d.cout; a.cout_real = d.cout; a.outd_float = net->out_float; }
             e = launch_conv(a, nd.tile, s);
             break;
         }
@@ -845,7 +845,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             AddArgs a{};
             a.a = (const int32_t*)(A + sT.forms[st.src_f].off);
             a.b = st.kind == S_ADD ? (const int32_t*)(A + T[st.res_t].forms[st.res_f].off) : nullptr;
-            a.n = (size_t)N * sT.H * sT.W * sT.Cs; a.a_shl = st.acc_shl; a.b_shl = st.res_shl; a.relu = st.relu1;
+            a.M = N * sT.H * sT.W; a.Cs = sT.Cs; a.a_shl = st.acc_shl; a.b_shl = st.res_shl; a.relu = st.relu1;
             fill_out(&a.out32, a.q);
             e = launch_add(a, s);
             break;
