@@ -525,10 +525,11 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 st.kind = S_INPUT;
                 Tensor& o = T[nd.out];
                 if (o.forms.empty()) add_form(o, FORM_I32, 0, 0);
-                for (auto& F : o.forms)
-                    if (F.kind == FORM_I8 && F.n != 0)
-                        return fail(F8_ERR_UNSUPPORTED, "finalize: a conv with quant_input=1 directly on the network input "
-                                    "(the reference feeds head-format integers, fix_train.py:683-692)");
+                // int8 formats that need a real shift (quant_input=1 on the network input) go through the
+                // int32 form + a stand-alone requant; the n == 0 format is a plain narrowing in the input kernel
+                for (size_t f = 0; f < o.forms.size(); ++f)
+                    if (o.forms[f].kind == FORM_I8 && o.forms[f].n != 0) extra.push_back((int)f);
+                if (!extra.empty()) add_form(o, FORM_I32, 0, 0);
                 st.out.t = nd.out;
                 st.name = "input"; st.kernel = "f8::input_kernel";
                 double b = (double)o.C * o.H * o.W * 4;
@@ -796,7 +797,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             const Tensor& o = T[st.out.t];
             InArgs a{}; a.x = input; a.N = N; a.C = o.C; a.H = o.H; a.W = o.W;
             for (auto& F : o.forms) {
-                if (F.kind == FORM_I8) { a.out8 = (int8_t*)(A + F.off); a.Cs8 = o.Cs; }
+                if (F.kind == FORM_I8) { if (F.n == 0) { a.out8 = (int8_t*)(A + F.off); a.Cs8 = o.Cs; } }
                 else if (F.kind == FORM_I32) { a.out32 = (int32_t*)(A + F.off); a.Cs32 = o.Cs; }
                 else { a.stem = (int8_t*)(A + F.off); a.Hp = F.Hp; a.Wp = F.Wp; a.pad = F.pad; }
             }

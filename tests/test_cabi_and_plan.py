@@ -1,0 +1,125 @@
+"""Host-side checks that need no GPU: the C-ABI library loads and exports every symbol the header
+declares; graph validation mirrors the reference's asserts; the planner fuses what DESIGN.md says."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from f8net_amd import _lib, synth, topology
+from f8net_amd.net import F8Net, build_net
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'f8net.h')).read()
+    declared = set(re.findall(r'\b(f8_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'f8_status'}
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(L, name), f'libf8net.so does not export {name}'
+    bound = {s[0] for s in _lib.SYMBOLS}
+    assert declared == bound, f'binding and header disagree: {declared ^ bound}'
+    assert _lib.lib().f8_version() >= 100
+    assert _lib.lib().f8_status_string(-1) == b'invalid argument'
+
+
+def test_no_torch_types_in_abi():
+    hdr = open(os.path.join(ROOT, 'include', 'f8net.h')).read()
+    code = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)          # strip comments
+    assert 'torch' not in code.lower() and 'at::' not in code and '#include <hip' not in code
+
+
+def test_builder_rejects_what_the_reference_asserts():
+    net = F8Net()
+    t = net.input(64, 8, 8, 10)
+    w = np.zeros((64, 64, 1, 1), np.int32)
+    with pytest.raises(_lib.F8Error):      # signed fl must be <= 7 (fix_quant_ops.py:93-94)
+        net.conv(t, w, None, stride=1, pad=0, groups=1, weight_fl=7, input_fl=8, input_signed=True)
+    with pytest.raises(_lib.F8Error):      # unsigned fl must be <= 8
+        net.conv(t, w, None, stride=1, pad=0, groups=1, weight_fl=7, input_fl=9, input_signed=False)
+    w_bad = w.copy()
+    w_bad[0, 0, 0, 0] = 300                # not an 8-bit weight
+    with pytest.raises(_lib.F8Error):
+        net.conv(t, w_bad, None, stride=1, pad=0, groups=1, weight_fl=7, input_fl=4, input_signed=False)
+    with pytest.raises(_lib.F8Error):      # groups other than 1 / depthwise
+        net.conv(t, np.zeros((64, 32, 3, 3), np.int32), None, stride=1, pad=1, groups=2, weight_fl=7,
+                 input_fl=4, input_signed=False)
+    with pytest.raises(_lib.F8Error):      # cin mismatch
+        net.conv(t, np.zeros((64, 32, 1, 1), np.int32), None, stride=1, pad=0, groups=1, weight_fl=7,
+                 input_fl=4, input_signed=False)
+    a = net.conv(t, w, None, stride=1, pad=0, groups=1, weight_fl=7, input_fl=4, input_signed=False)
+    with pytest.raises(_lib.F8Error):      # avgpool fraclen > 32 (fix_quant_ops.py:129)
+        net.avgpool_sum(a, 30)
+    with pytest.raises(_lib.F8Error):
+        net.finalize(4)                    # no output marked
+    net.output(a, as_float=False)
+    net.finalize(4)
+    with pytest.raises(_lib.F8Error):
+        net.finalize(4)                    # twice
+
+
+def test_run_without_gpu_fails_loudly():
+    """No CPU fallback: with no device the run call must raise, not compute on the host."""
+    torch = pytest.importorskip('torch')
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    spec = topology.get('resnet18')
+    net = build_net(spec, synth.make_params(spec, 1), max_batch=1, hw=32)
+    x = torch.zeros((1, 3, 32, 32), dtype=torch.int32)
+    with pytest.raises(ValueError):
+        net.run(x)
+    from f8net_amd import ops
+    with pytest.raises(ValueError):
+        ops.int_op_only_fix_quant(x, 8, 4, 6, True)
+    assert _lib.lib().f8_device_count() == 0
+    rc = _lib.lib().f8_net_upload(net._h)
+    assert rc < 0 and b'hip' in _lib.lib().f8_last_error().lower()
+
+
+@pytest.mark.parametrize('arch,launches', [('resnet18', 25), ('resnet50', 58), ('mobilenet_v1', 31), ('mobilenet_v2', 56)])
+def test_plan_fuses_requant_relu_residual(arch, launches):
+    spec = topology.get(arch)
+    net = build_net(spec, synth.make_params(spec, 1), max_batch=8, hw=224)
+    plan = net.describe()
+    assert net.num_launches == launches, plan
+    # no stand-alone add / requant launches: every residual join rides in a conv epilogue
+    assert 'add:' not in plan and 'requant:' not in plan
+    n_res_blocks = sum(1 for b in spec.blocks if b.residual)
+    assert plan.count('_res:') == n_res_blocks
+    # one launch per conv + input + pools + output
+    assert plan.count('conv') + plan.count('dwconv') >= len(spec.convs())
+    assert net.weight_bytes > 0 and net.arena_bytes > 0
+
+
+def test_plan_keeps_int32_only_where_semantics_need_it():
+    spec = topology.get('resnet50', normalize=True)
+    net = build_net(spec, synth.make_params(spec, 1234, topology.R50_NVIDIA_FRACLENS), max_batch=128, hw=224)
+    lines = net.describe().splitlines()
+    body0 = [l for l in lines if '.body.0 ' in l or '.body.2 ' in l]
+    assert body0 and all('i32=0' in l for l in body0)          # inside a block: int8 only
+    res = [l for l in lines if '_res:' in l]
+    assert len(res) == 16
+    # the stem emits int8 straight into an int8 max-pool (requant commutes with max)
+    assert any('maxpool_i8' in l for l in lines)
+    # algorithmic bytes are reported per launch and sum to less than the structural model
+    total = sum(net.launch_info(i, 128)[1] for i in range(net.num_launches)) / 128
+    assert 40e6 < total < 93.444e6
+
+
+def test_two_consumer_formats_and_fallback():
+    """A tensor read by convs with different input_fraclen gets one int8 form per format; a third
+    format falls back to an int32 form + stand-alone requant."""
+    net = F8Net()
+    t = net.input(32, 8, 8, 8)
+    w = np.ones((32, 32, 1, 1), np.int32)
+    a = net.conv(t, w, None, stride=1, pad=0, groups=1, weight_fl=5, input_fl=8, input_signed=False, quant_input=False)
+    outs = [net.conv(a, w, None, stride=1, pad=0, groups=1, weight_fl=5, input_fl=fl, input_signed=False) for fl in (3, 4, 5)]
+    s = net.add(outs[0], outs[1])
+    s = net.add(s, outs[2])
+    net.output(s, as_float=False)
+    net.finalize(2)
+    plan = net.describe()
+    assert plan.count('requant:') == 1, plan
