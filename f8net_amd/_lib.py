@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libf8net.so')
+LIB_PATH = os.environ.get('F8NET_LIB') or os.path.join(_HERE, 'libf8net.so')   # override: tuning experiments only
 
 F8_OK = 0
 

@@ -12,6 +12,7 @@ struct QuantOut {
     int8_t* ptr;      // NHWC int8, row stride ld (bytes); nullptr = absent
     int32_t n;        // shift (> 0 right with round-half-even, <= 0 left)
     int32_t lo, hi;   // clamp bounds: [-127,127] or [0,255]
+    uint32_t bias_xor; // 0x80808080 for unsigned formats (stored biased: x ^ 0x80), 0 for signed
 };
 
 // Implicit-GEMM int8 convolution / linear on v_mfma_i32_32x32x32_i8.
@@ -20,16 +21,18 @@ struct QuantOut {
 struct ConvArgs {
     const int8_t* x;  uint32_t x_bytes;
     const int8_t* w;  uint32_t w_bytes;    // packed [coutP][ktot], K-contiguous
-    const int32_t* bias;                   // [coutP], offset-corrected (see pack_conv_weights)
+    const int32_t* bias;                   // [ncls][coutP] border-class bias table (see pack_conv_weights)
+    const uint8_t* rowcls; const uint8_t* colcls;   // class of output row p / col q; ncc = #col classes
+    int32_t ncc;                           // 0: single class (no padding, or signed input)
     int32_t M;                             // N*P*Q output pixels
     int32_t PQ, Q;
+    uint32_t mPQ, mQ; int32_t s1PQ, s2PQ, s1Q, s2Q;   // magic numbers for m / PQ and rem / Q (fast_div)
     int32_t sN, sP, sQ;                    // input byte strides: per image, per output row, per output col
     int32_t origin;                        // byte offset of tap (0,0) at p=q=0 (negative with padding)
     int32_t H, W, stride, pad, kh, kw;
     int32_t CK;                            // bytes per tap (multiple of BK)
     int32_t tapH, tapW;                    // byte offset per tap row / col
     int32_t ktot;                          // kh*kw*CK
-    uint32_t xor_mask;                     // 0x80808080 for unsigned inputs, 0 for signed
     int32_t coutP;                         // padded cout = row stride of NHWC outputs (elements)
     // epilogue
     int32_t relu0;                         // ReLU directly after the conv
@@ -73,6 +76,7 @@ struct AddArgs {                           // standalone align-add (when it cann
 
 struct InArgs {                            // network input: int32 NCHW -> NHWC forms
     const int32_t* x; int32_t N, C, H, W;
+    uint32_t xor8;                         // 0x80808080 when the int8 consumer format is unsigned (biased storage)
     int8_t* out8;  int32_t Cs8;            // NHWC int8 (Cs8-channel rows), or
     int8_t* stem;  int32_t Hp, Wp, pad;    // zero-haloed NHWC4 for the stem conv
     int32_t* out32; int32_t Cs32;

@@ -9,10 +9,10 @@
 //   residual      : /root/reference/models/fix_resnet.py:40-54 (align shift, wrapping add, clamp)
 // Unsigned (0..255) activations meet a signed-only MFMA through the offset identity
 //   sum w*x = sum w*(x-128) + 128*sum w     (x-128 == x ^ 0x80 as int8)
-// The XOR is applied in registers between the global load and the LDS write; out-of-image taps are
-// fetched through the buffer range check (returns 0 -> XOR -> -128 == real 0), and 128*sum(w) is
-// folded into the packed bias on the host (f8_net.cpp: pack_conv_weights).  Everything is mod 2^32,
-// so the identity is exact under wrap-around.
+// Unsigned int8 tensors are STORED biased (x ^ 0x80) by their producers, so operands go from HBM to
+// LDS untouched; 128*sum(w) over the taps that lie inside the image is folded into a per-border-class
+// bias table on the host (f8_net.cpp: pack_conv_weights).  Everything is mod 2^32, so the identity
+// is exact under wrap-around.
 #include "f8_internal.h"
 #include <cstdlib>
 
@@ -24,20 +24,38 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 static constexpr unsigned kOOB = 0x80000000u;   // voffset sentinel: beyond any buffer (< 2 GiB each)
 
+// clamp via v_med3_i32 (lo <= hi)
+__device__ __forceinline__ int med3i(int v, int lo, int hi) {
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+}
+
 // int_op_only_fix_quant on one value; n, lo, hi are wave-uniform.
-// n > 0: q = (v + 2^(n-1)) >> n, with the LSB cleared on an exact tie (== ((r >> (n+1)) << 1)).
+// n > 0: q = (v + 2^(n-1)) >> n, with the LSB cleared on an exact tie (== ((r >> (n+1)) << 1)):
+//        tie <=> low n bits of r = v + 2^(n-1) are all zero.  Branch-free on purpose (a data-dependent
+//        `if` here makes hipcc emit an exec-mask branch per value).
+__device__ __forceinline__ int requant_shr(int v, int n, unsigned half, unsigned mask, int lo, int hi) {
+    const unsigned r = (unsigned)v + half;
+    const int keep = ((r & mask) == 0u) ? ~1 : ~0;
+    return med3i(((int)r >> n) & keep, lo, hi);
+}
+__device__ __forceinline__ int requant_shl(int v, int n, int lo, int hi) {   // n <= 0
+    return med3i((int)((unsigned)v << (-n)), lo, hi);
+}
 __device__ __forceinline__ int requant1(int v, int n, int lo, int hi) {
-    int q;
     if (n > 0) {
         const unsigned half = 1u << (n - 1);
-        const unsigned mask = (half << 1) - 1u;
-        const int r = (int)((unsigned)v + half);
-        q = r >> n;
-        if (((unsigned)v & mask) == half) q &= ~1;
-    } else {
-        q = (int)((unsigned)v << (-n));
+        return requant_shr(v, n, half, (half << 1) - 1u, lo, hi);
     }
-    return min(max(q, lo), hi);
+    return requant_shl(v, n, lo, hi);
+}
+
+// q = n / d for a divisor known on the host: q = (t + ((n - t) >> sh1)) >> sh2, t = mulhi(n, magic)
+// (round-up method, exact for every 32-bit n; host: f8_net.cpp make_magic)
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic, int sh1, int sh2) {
+    const unsigned t = __umulhi(n, magic);
+    return (t + ((n - t) >> sh1)) >> sh2;
 }
 
 __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d) {
@@ -65,7 +83,7 @@ __device__ __forceinline__ int clamp_sym31(int v) {   // clamp_(max=2^31-1, min=
 //
 // Block: 256 threads = 4 waves arranged WPX x WCO; tile BM pixels x BN couts, K step BK bytes.
 // MFMA roles: A = weights (rows = cout), B = activations (cols = pixels), so that a lane's 4
-// consecutive accumulator registers are 4 consecutive output channels of ONE pixel (NHWC-friendly):
+// consecutive accumulator registers are 4 consecutive output channels of ONE pixel:
 //   D reg r of lane l: cout = (r&3) + 8*(r>>2) + 4*(l>>5), pixel = l&31.
 // Both operands are read from LDS as 16-byte K-contiguous chunks (lane l: row l&31, chunk
 // 2*kk + (l>>5)); whatever the hardware's internal k order is, it is the same for A and B, and the
@@ -74,26 +92,38 @@ __device__ __forceinline__ int clamp_sym31(int v) {   // clamp_(max=2^31-1, min=
 // LDS image: rows of BK bytes; 16-byte chunk c of row r is stored at chunk c ^ f(r),
 // f(r) = (r / (256/BK)) % (BK/16): the 16 lanes of a ds_read_b128 service group (distinct rows
 // mod 16, same logical chunk) then cover all 64 banks exactly once.
-// Pipeline: global -> registers (next K step in flight during the MFMAs) -> XOR -> LDS, two LDS
-// buffers, one barrier per K step.
+//
+// Operand staging is LDS-direct (`buffer_load_dwordx4 ... lds`): each wave instruction deposits
+// 64 x 16 B = 1 KB into consecutive LDS slots, the swizzle is applied on the SOURCE side (lane ->
+// (row, chunk ^ f(row))), out-of-image taps and tile tails are fetched through the buffer range
+// check (the DMA writes zeros).  STAGES tiles are in flight in an LDS ring; the K loop has ONE
+// barrier per step and counted `s_waitcnt vmcnt(N)` so that later stages stay in flight across it.
+// No data is transformed in flight, which is why unsigned activations are STORED biased (x ^ 0x80,
+// i.e. x - 128 as int8) and the zero padding (biased 0 == real 128) is repaired by a per-border-class
+// bias: bias[class][cout] = b + 128 * sum over the class's in-image taps of w  (host: pack_conv_weights).
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int BK, int WPX, int WCO, bool HAS_PAD, bool HAS_RES>
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+template <int BM, int BN, int BK, int WPX, int WCO, bool HAS_PAD, bool HAS_RES, int STAGES>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     static_assert(WPX * WCO == 4, "4 waves");
+    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
     constexpr int CPR = BK / 16;                  // chunks per row
     constexpr int RPB = 256 / BK;                 // rows per 256-byte bank row
-    constexpr int XCH = BM * CPR, WCH = BN * CPR; // 16-byte chunks per tile
+    constexpr int XCH = BM * CPR, WCH = BN * CPR; // 16-byte slots per tile
     constexpr int XL = (XCH + 255) / 256, WL = (WCH + 255) / 256;
+    constexpr int NLD = XL + WL;                  // DMA instructions per thread per stage (upper bound)
     constexpr int TPX = BM / WPX / 32, TCO = BN / WCO / 32;
     constexpr int KK = BK / 32;
     constexpr int XBYTES = BM * BK, TILE = (BM + BN) * BK;
     static_assert(TPX >= 1 && TCO >= 1, "wave tile");
+    static_assert(STAGES * TILE <= 65536, "static LDS");
 
-    __shared__ __attribute__((aligned(16))) char lds[2 * TILE];
+    __shared__ __attribute__((aligned(16))) char lds[STAGES * TILE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 3;
     const int wpx = wave / WCO, wco = wave % WCO;
 
     // XCD-aware tile order: consecutive tiles (cout-tile fastest, then pixel-tile) stay on one XCD,
@@ -111,54 +141,11 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
 
-    // ---- per-thread gather descriptors (K-loop invariant)
-    unsigned xbase[XL], xlds[XL], wbase[WL], wlds[WL];
-    int xh0[XL], xw0[XL];   // top-left input coordinate of each gathered row (HAS_PAD only)
-#pragma unroll
-    for (int i = 0; i < XL; ++i) {
-        const int idx = tid + i * 256;
-        const int row = idx / CPR, chunk = idx % CPR;
-        xlds[i] = row * BK + ((chunk ^ ((row / RPB) % CPR)) << 4);
-        const int m = m0 + row;
-        xh0[i] = xw0[i] = -(1 << 24);
-        xbase[i] = kOOB;
-        if (idx < XCH && m < a.M) {
-            const int n = m / a.PQ, rem = m - n * a.PQ;
-            const int p = rem / a.Q, q = rem - p * a.Q;
-            xbase[i] = (unsigned)(n * a.sN + p * a.sP + q * a.sQ + a.origin + chunk * 16);
-            xh0[i] = p * a.stride - a.pad;
-            xw0[i] = q * a.stride - a.pad;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < WL; ++j) {
-        const int idx = tid + j * 256;
-        const int row = idx / CPR, chunk = idx % CPR;
-        wlds[j] = XBYTES + row * BK + ((chunk ^ ((row / RPB) % CPR)) << 4);
-        // rows past coutP fall outside the buffer and read as 0
-        wbase[j] = (idx < WCH) ? (unsigned)((co0 + row) * a.ktot + chunk * 16) : kOOB;
-    }
-
-    // ---- per-lane fragment addresses
     const int l31 = lane & 31, lh = lane >> 5;
-    const int fl = (l31 / RPB) % CPR;
-    unsigned coff[KK];
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk) coff[kk] = (unsigned)(((kk * 2 + lh) ^ fl) << 4);
-    const unsigned xfrag0 = (unsigned)((wpx * (BM / WPX) + l31) * BK);
-    const unsigned wfrag0 = (unsigned)(XBYTES + (wco * (BN / WCO) + l31) * BK);
 
-    v16i acc[TCO][TPX];
-#pragma unroll
-    for (int i = 0; i < TCO; ++i)
-#pragma unroll
-        for (int j = 0; j < TPX; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
-
-    // Residual operand: ALL of the wave tile's int32 rows are requested before the K loop, so their
-    // HBM latency overlaps the operand staging and the MFMAs (the in-place out32 store of the same
-    // addresses comes later from the same lane).  16 B per lane per (cout tile, pixel tile, group).
+    // ---- residual operand: ALL of the wave tile's int32 rows are requested before anything else, so
+    // their HBM latency overlaps the operand staging and the MFMAs (the in-place out32 store of the
+    // same addresses comes later from the same lane).  I32T layout: 1 KB contiguous per access.
     v4i rv[HAS_RES ? TCO : 1][HAS_RES ? TPX : 1][4];
     if (HAS_RES) {
 #pragma unroll
@@ -178,54 +165,120 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
             }
     }
 
-    v4i xr[XL], wr[WL];
-    const int nk = a.ktot / BK;
-    // K-step state (wave-uniform): tap row/col, channel offset inside the tap
-    int tr = 0, ts = 0, c0 = 0;
+    // ---- per-thread gather descriptors (K-loop invariant).  Thread t owns LDS slots t + 256*i:
+    // row = slot / CPR, physical chunk = slot % CPR, which holds LOGICAL chunk (phys ^ f(row)).
+    unsigned xbase[XL], wbase[WL];
+    int xh0[XL], xw0[XL];   // top-left input coordinate of each gathered row (HAS_PAD only)
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx / CPR, chunk = (idx % CPR) ^ ((row / RPB) % CPR);
+        const int m = m0 + row;
+        xh0[i] = xw0[i] = -(1 << 24);
+        xbase[i] = kOOB;
+        if (idx < XCH && m < a.M) {
+            const int n = (int)fast_div((unsigned)m, a.mPQ, a.s1PQ, a.s2PQ), rem = m - n * a.PQ;
+            const int p = (int)fast_div((unsigned)rem, a.mQ, a.s1Q, a.s2Q), q = rem - p * a.Q;
+            xbase[i] = (unsigned)(n * a.sN + p * a.sP + q * a.sQ + a.origin + chunk * 16);
+            xh0[i] = p * a.stride - a.pad;
+            xw0[i] = q * a.stride - a.pad;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < WL; ++j) {
+        const int idx = tid + j * 256;
+        const int row = idx / CPR, chunk = (idx % CPR) ^ ((row / RPB) % CPR);
+        // rows past coutP fall outside the buffer and read as 0
+        wbase[j] = (idx < WCH) ? (unsigned)((co0 + row) * a.ktot + chunk * 16) : kOOB;
+    }
 
-    auto issue_loads = [&](int ks) {
+    // ---- per-lane fragment addresses
+    const int fl = (l31 / RPB) % CPR;
+    unsigned coff[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) coff[kk] = (unsigned)(((kk * 2 + lh) ^ fl) << 4);
+    const unsigned xfrag0 = (unsigned)((wpx * (BM / WPX) + l31) * BK);
+    const unsigned wfrag0 = (unsigned)(XBYTES + (wco * (BN / WCO) + l31) * BK);
+
+    v16i acc[TCO][TPX];
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int j = 0; j < TPX; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+    const int nk = a.ktot / BK;
+    // K-step state of the NEXT stage to issue (wave-uniform): tap row/col, channel offset in the tap
+    int tr = 0, ts = 0, c0 = 0, kiss = 0;
+
+    // Every thread issues exactly NLD DMA instructions per stage (waves without a slot for some
+    // instruction issue it anyway with an out-of-range offset into a scratch-free no-op? no: they skip
+    // it, and the counted waits below use the per-wave instruction count).
+    auto issue_stage = [&](int slot) {
+        char* base = lds + slot * TILE;
         const unsigned koffx = (unsigned)(tr * a.tapH + ts * a.tapW + c0);
 #pragma unroll
         for (int i = 0; i < XL; ++i) {
             unsigned off = xbase[i] + koffx;
-            if (HAS_PAD)   // out-of-image tap: fetch through the range check (reads 0)
+            if (HAS_PAD)   // out-of-image tap: fetched through the range check (DMA writes 0)
                 off = ((unsigned)(xh0[i] + tr) < (unsigned)a.H && (unsigned)(xw0[i] + ts) < (unsigned)a.W) ? off : kOOB;
-            if (i * 256 + 255 < XCH || tid + i * 256 < XCH)
-                xr[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+            if ((i * 256 + wave * 64) < XCH)      // wave-uniform
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(base + i * 4096 + wave * 1024),
+                                                         16, off, 0, 0, 0);
         }
-        const unsigned koffw = (unsigned)(ks * BK);
+        const unsigned koffw = (unsigned)(kiss * BK);
 #pragma unroll
-        for (int j = 0; j < WL; ++j)
-            if (j * 256 + 255 < WCH || tid + j * 256 < WCH)
-                wr[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, wbase[j] + koffw, 0, 0);
-        // advance to the next K step
+        for (int j = 0; j < WL; ++j) {
+            const unsigned woff = wbase[j] + koffw;   // (a captured-array element passed directly to the builtin
+                                                      //  makes hipcc 7.2 drop the kernel's host stub: keep it a scalar)
+            if ((j * 256 + wave * 64) < WCH)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(base + XBYTES + j * 4096 + wave * 1024),
+                                                         16, woff, 0, 0, 0);
+        }
+        ++kiss;
         c0 += BK;
         if (c0 == a.CK) {
             c0 = 0; ++ts;
             if (ts == a.kw) { ts = 0; ++tr; }
         }
     };
-    auto stage_to_lds = [&](int buf) {
-        char* base = lds + buf * TILE;
+    // DMA instructions THIS wave issues per stage (compile-time per wave index is not available, so
+    // take the count for wave 0 when all waves are equal, else the exact per-wave value at run time)
+    constexpr bool UNIFORM_LD = (XCH % 256 == 0) && (WCH % 256 == 0);
+    int my_ld = 0;
+    if (!UNIFORM_LD) {
 #pragma unroll
-        for (int i = 0; i < XL; ++i)
-            if (i * 256 + 255 < XCH || tid + i * 256 < XCH) {
-                v4i v = xr[i];
-                v.x ^= (int)a.xor_mask; v.y ^= (int)a.xor_mask; v.z ^= (int)a.xor_mask; v.w ^= (int)a.xor_mask;
-                *(v4i*)(base + xlds[i]) = v;
-            }
+        for (int i = 0; i < XL; ++i) my_ld += ((i * 256 + wave * 64) < XCH) ? 1 : 0;
 #pragma unroll
-        for (int j = 0; j < WL; ++j)
-            if (j * 256 + 255 < WCH || tid + j * 256 < WCH) *(v4i*)(base + wlds[j]) = wr[j];
+        for (int j = 0; j < WL; ++j) my_ld += ((j * 256 + wave * 64) < WCH) ? 1 : 0;
+    }
+    // wait until at most `ahead` later stages of this wave's DMA are still in flight
+    auto wait_ahead = [&](int ahead) {
+        if (UNIFORM_LD) {
+            if (ahead >= 2 && STAGES >= 4) wait_vmcnt<2 * NLD>();
+            else if (ahead >= 1 && STAGES >= 3) wait_vmcnt<1 * NLD>();
+            else wait_vmcnt<0>();
+        } else {
+            // ragged tiles (some waves own fewer slots): counts differ per wave; my_ld in {0,1,2,..}
+            const int n = ahead * my_ld;
+            if (n >= 4) wait_vmcnt<4>(); else if (n == 3) wait_vmcnt<3>(); else if (n == 2) wait_vmcnt<2>();
+            else if (n == 1) wait_vmcnt<1>(); else wait_vmcnt<0>();
+        }
     };
 
-    issue_loads(0);
-    stage_to_lds(0);
-    __syncthreads();
+    // prologue: STAGES-1 tiles in flight
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) issue_stage(s);
+
     for (int ks = 0; ks < nk; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < nk) issue_loads(ks + 1);
-        const char* base = lds + buf * TILE;
+        // stages issued so far: min(nk, ks + STAGES - 1); stage ks must have landed
+        const int issued = (ks + STAGES - 1 < nk) ? ks + STAGES - 1 : nk;
+        wait_ahead(issued - 1 - ks);
+        __builtin_amdgcn_s_barrier();     // all waves' DMA for stage ks landed; slot (ks-1)%STAGES is free
+        if (ks + STAGES - 1 < nk) issue_stage((ks + STAGES - 1) % STAGES);
+        const char* base = lds + (ks % STAGES) * TILE;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             v4i wf[TCO], xf[TPX];
@@ -239,37 +292,41 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
                 for (int j = 0; j < TPX; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xf[j], acc[i][j], 0, 0, 0);
         }
-        if (ks + 1 < nk) stage_to_lds(buf ^ 1);
-        __syncthreads();
     }
 
-    // ---- epilogue: bias -> ReLU -> [align + residual + clamp -> ReLU] -> int32 / requantised int8
+    // ---- epilogue: class bias -> ReLU -> [align + residual + clamp -> ReLU] -> int32 / requantised int8
     // ReLUs are branch-free floors (INT32_MIN = no ReLU).
     const int floor0 = a.relu0 ? 0 : INT32_MIN, floor1 = a.relu1 ? 0 : INT32_MIN;
 #pragma unroll
-    for (int i = 0; i < TCO; ++i) {
-        const int cot = co0 + wco * (BN / WCO) + i * 32;   // first cout of this 32-wide MFMA tile
-        if (cot >= a.coutP) continue;                      // wave-uniform
-        v4i bv[4];
+    for (int j = 0; j < TPX; ++j) {
+        const int m = m0 + wpx * (BM / WPX) + j * 32 + l31;
+        const bool ok = m < a.M;
+        const size_t rowo = (size_t)m * (size_t)a.coutP;
+        // border class of this lane's pixel (which taps fell outside the image)
+        const int32_t* bias = a.bias;
+        if (a.ncc > 0 && ok) {
+            const int n = (int)fast_div((unsigned)m, a.mPQ, a.s1PQ, a.s2PQ), rem = m - n * a.PQ;
+            const int p = (int)fast_div((unsigned)rem, a.mQ, a.s1Q, a.s2Q), q = rem - p * a.Q;
+            bias += (size_t)((int)a.rowcls[p] * a.ncc + (int)a.colcls[q]) * (size_t)a.coutP;
+        }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bv[g] = *(const v4i*)(a.bias + cot + 8 * g + 4 * lh);
-#pragma unroll
-        for (int j = 0; j < TPX; ++j) {
-            const int m = m0 + wpx * (BM / WPX) + j * 32 + l31;
-            const bool ok = m < a.M;
-            const size_t rowo = (size_t)m * (size_t)a.coutP;
+        for (int i = 0; i < TCO; ++i) {
+            const int cot = co0 + wco * (BN / WCO) + i * 32;   // first cout of this 32-wide MFMA tile
+            if (cot >= a.coutP) continue;                      // wave-uniform
             int y[4][4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < 4; ++g) {
+                const v4i bv = *(const v4i*)(bias + cot + 8 * g + 4 * lh);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    int v = max((int)((unsigned)acc[i][j][4 * g + e] + (unsigned)bv[g][e]), floor0);
+                    int v = max((int)((unsigned)acc[i][j][4 * g + e] + (unsigned)bv[e]), floor0);
                     if (HAS_RES) {
                         const unsigned s = ((unsigned)v << a.acc_shl) + ((unsigned)rv[i][j][g][e] << a.res_shl);
                         v = max(clamp_sym31((int)s), floor1);
                     }
                     y[g][e] = v;
                 }
+            }
             if (a.out32 && (m - l31 < a.M)) {              // I32T: 4 x 1 KB contiguous per wave
                 int32_t* op = a.out32 + i32t_index(m, cot, a.coutP) + 4 * 32 * lh;
 #pragma unroll
@@ -286,10 +343,19 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
             for (int k = 0; k < 2; ++k) {
                 if (!a.q[k].ptr) continue;                 // wave-uniform
                 unsigned d[4];
+                const int qn = a.q[k].n, qlo = a.q[k].lo, qhi = a.q[k].hi;
+                if (qn > 0) {                              // wave-uniform: the common case, right shift
+                    const unsigned half = 1u << (qn - 1), mask = (half << 1) - 1u;
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    d[g] = pack4(requant1(y[g][0], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(y[g][1], a.q[k].n, a.q[k].lo, a.q[k].hi),
-                                 requant1(y[g][2], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(y[g][3], a.q[k].n, a.q[k].lo, a.q[k].hi));
+                    for (int g = 0; g < 4; ++g)
+                        d[g] = pack4(requant_shr(y[g][0], qn, half, mask, qlo, qhi), requant_shr(y[g][1], qn, half, mask, qlo, qhi),
+                                     requant_shr(y[g][2], qn, half, mask, qlo, qhi), requant_shr(y[g][3], qn, half, mask, qlo, qhi)) ^ a.q[k].bias_xor;
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        d[g] = pack4(requant_shl(y[g][0], qn, qlo, qhi), requant_shl(y[g][1], qn, qlo, qhi),
+                                     requant_shl(y[g][2], qn, qlo, qhi), requant_shl(y[g][3], qn, qlo, qhi)) ^ a.q[k].bias_xor;
+                }
                 auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
                 auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
                 if (ok) {
@@ -323,6 +389,7 @@ __global__ void __launch_bounds__(256) dwconv3x3_kernel(const DwArgs a) {
             acc[0] = b.x; acc[1] = b.y; acc[2] = b.z; acc[3] = b.w;
         }
         const int h0 = p * a.stride - a.pad, w0 = q * a.stride - a.pad;
+        const unsigned in_xor = SIGNED_IN ? 0u : 0x80808080u;   // unsigned tensors are stored biased
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int h = h0 + r;
@@ -331,7 +398,7 @@ __global__ void __launch_bounds__(256) dwconv3x3_kernel(const DwArgs a) {
             for (int s = 0; s < 3; ++s) {
                 const int w = w0 + s;
                 if ((unsigned)w >= (unsigned)a.W) continue;
-                const unsigned xv = *(const unsigned*)(a.x + (((size_t)n * a.H + h) * a.W + w) * a.Cs + c);
+                const unsigned xv = *(const unsigned*)(a.x + (((size_t)n * a.H + h) * a.W + w) * a.Cs + c) ^ in_xor;
                 const unsigned wv = *(const unsigned*)(a.w + (r * 3 + s) * a.Cs + c);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -353,14 +420,14 @@ __global__ void __launch_bounds__(256) dwconv3x3_kernel(const DwArgs a) {
             if (a.q[k].ptr)
                 *(unsigned*)(a.q[k].ptr + o) =
                     pack4(requant1(acc[0], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(acc[1], a.q[k].n, a.q[k].lo, a.q[k].hi),
-                          requant1(acc[2], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(acc[3], a.q[k].n, a.q[k].lo, a.q[k].hi));
+                          requant1(acc[2], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(acc[3], a.q[k].n, a.q[k].lo, a.q[k].hi)) ^ a.q[k].bias_xor;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Max-pool (NHWC).  int32 input: exact max, then any of {int32, two requantised int8} outputs.
 // int8 input (already in the single consumer format; requant is monotone so pooling commutes with
-// it exactly): per-byte max, signed or unsigned.
+// it exactly): per-byte signed max — unsigned tensors are stored biased (x ^ 0x80), which preserves order.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) maxpool_kernel(const PoolArgs a) {
     const int cgs = a.Cs >> 2;
@@ -386,8 +453,7 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const PoolArgs a) {
                     const unsigned xv = *(const unsigned*)((const int8_t*)a.x + (size_t)mi * a.Cs + c);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int xe = a.in_signed ? (int)(signed char)(xv >> (8 * e)) : (int)((xv >> (8 * e)) & 0xffu);
-                        mx[e] = max(mx[e], xe);
+                        mx[e] = max(mx[e], (int)(signed char)(xv >> (8 * e)));   // biased u8 keeps its order as s8
                     }
                 } else {
                     const v4i xv = *(const v4i*)((const int32_t*)a.x + i32t_index(mi, c, a.Cs));
@@ -407,7 +473,7 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const PoolArgs a) {
                 if (a.q[k].ptr)
                     *(unsigned*)(a.q[k].ptr + o) =
                         pack4(requant1(mx[0], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(mx[1], a.q[k].n, a.q[k].lo, a.q[k].hi),
-                              requant1(mx[2], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(mx[3], a.q[k].n, a.q[k].lo, a.q[k].hi));
+                              requant1(mx[2], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(mx[3], a.q[k].n, a.q[k].lo, a.q[k].hi)) ^ a.q[k].bias_xor;
         }
     }
 }
@@ -433,7 +499,7 @@ __global__ void __launch_bounds__(256) avgpool_kernel(const AvgArgs a) {
         if (a.q[k].ptr)
             *(unsigned*)(a.q[k].ptr + o) =
                 pack4(requant1(t[0], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(t[1], a.q[k].n, a.q[k].lo, a.q[k].hi),
-                      requant1(t[2], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(t[3], a.q[k].n, a.q[k].lo, a.q[k].hi));
+                      requant1(t[2], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(t[3], a.q[k].n, a.q[k].lo, a.q[k].hi)) ^ a.q[k].bias_xor;
 }
 
 // Stand-alone residual join (only when it cannot ride in a conv epilogue) and stand-alone requant
@@ -460,7 +526,7 @@ __global__ void __launch_bounds__(256) add_kernel(const AddArgs a) {
             if (a.q[k].ptr)
                 *(unsigned*)(a.q[k].ptr + (size_t)m * a.Cs + c) =
                     pack4(requant1(y[0], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(y[1], a.q[k].n, a.q[k].lo, a.q[k].hi),
-                          requant1(y[2], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(y[3], a.q[k].n, a.q[k].lo, a.q[k].hi));
+                          requant1(y[2], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(y[3], a.q[k].n, a.q[k].lo, a.q[k].hi)) ^ a.q[k].bias_xor;
     }
 }
 
@@ -479,12 +545,13 @@ __global__ void __launch_bounds__(256) input_kernel(const InArgs a) {
         if (a.stem) {
             int v[4] = {0, 0, 0, 0};
             for (int c = 0; c < a.C; ++c) v[c] = xp[c * plane];
-            *(unsigned*)(a.stem + ((((size_t)n * a.Hp + h + a.pad) * a.Wp) + w + a.pad) * 4) = pack4(v[0], v[1], v[2], v[3]);
+            *(unsigned*)(a.stem + ((((size_t)n * a.Hp + h + a.pad) * a.Wp) + w + a.pad) * 4) = pack4(v[0], v[1], v[2], v[3]) ^ a.xor8;
         }
         if (a.out8) {
             int8_t* o = a.out8 + (((size_t)n * a.H + h) * a.W + w) * a.Cs8;
-            for (int c = 0; c < a.C; ++c) o[c] = (int8_t)xp[c * plane];
-            for (int c = a.C; c < a.Cs8; ++c) o[c] = 0;
+            const int8_t bx = (int8_t)(a.xor8 & 0xff);
+            for (int c = 0; c < a.C; ++c) o[c] = (int8_t)(xp[c * plane]) ^ bx;
+            for (int c = a.C; c < a.Cs8; ++c) o[c] = bx;
         }
         if (a.out32) {
             const int m = (n * a.H + h) * a.W + w;
@@ -557,11 +624,21 @@ int conv_grid(const ConvTile& t, int M, int coutP) {
 
 template <int BM, int BN, int BK, int WPX, int WCO>
 static hipError_t launch_conv_t(const ConvArgs& a, int grid, hipStream_t s) {
+    constexpr int TILE = (BM + BN) * BK;
+#ifdef F8_FORCE_STAGES
+    constexpr int ST = F8_FORCE_STAGES;
+#else
+    // measured on ResNet-50 (profiles/): ring depth 2/3/4 = 49.9k/49.5k/48.5k img/s — these layers are bound by
+    // per-workgroup instruction issue and start-up, not by steady-state latency, so the smaller LDS
+    // footprint (more resident workgroups) wins
+    constexpr int ST = 2;
+#endif
+    static_assert(ST * TILE <= 65536, "static LDS");
     const bool pad = a.pad > 0, res = a.res != nullptr;
-    if (pad && res) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, true, true>), dim3(grid), dim3(256), 0, s, a);
-    else if (pad) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, true, false>), dim3(grid), dim3(256), 0, s, a);
-    else if (res) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, false, true>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, false, false>), dim3(grid), dim3(256), 0, s, a);
+    if (pad && res) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, true, true, ST>), dim3(grid), dim3(256), 0, s, a);
+    else if (pad) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, true, false, ST>), dim3(grid), dim3(256), 0, s, a);
+    else if (res) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, false, true, ST>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, false, false, ST>), dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

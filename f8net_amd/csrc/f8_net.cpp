@@ -75,6 +75,7 @@ struct Node {
     int fused_add = -1;                // conv: add node carried
     bool stem = false, depthwise = false;
     size_t w_off = 0, b_off = 0; int coutP = 0, ck = 0, ktot = 0;
+    size_t rc_off = 0, cc_off = 0; int ncc = 0;      // border-class tables (0 = single class)
     ConvTile tile{};
 };
 enum StepKind { S_INPUT, S_CONV, S_DW, S_ADD, S_MAXPOOL, S_AVGPOOL, S_REQUANT, S_OUTPUT };
@@ -101,7 +102,7 @@ struct f8_net {
     std::vector<Step> steps;
     std::vector<uint8_t> wblob;
     size_t arena_bytes = 0;
-    size_t stem_zero_off = 0, stem_zero_bytes = 0;
+    size_t stem_zero_off = 0, stem_zero_bytes = 0; int stem_zero_val = 0;   // halo = biased zero
     // device
     char* d_arena = nullptr; char* d_w = nullptr; bool uploaded = false;
     hipEvent_t* events = nullptr; int n_events = 0;
@@ -145,9 +146,20 @@ int consumer_format(const Tensor& src, const f8_conv_desc& d, int* n, const char
     return 0;
 }
 
+// round-up magic for unsigned division by d >= 1:  n / d == (t + ((n - t) >> sh1)) >> sh2,
+// t = mulhi(n, magic); exact for all 32-bit n (Granlund-Montgomery, branch-free form)
+void make_magic(uint32_t d, uint32_t* magic, int32_t* sh1, int32_t* sh2) {
+    int l = 0;
+    while ((1ull << l) < d) ++l;                       // l = ceil(log2 d)
+    *magic = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    *sh1 = l < 1 ? l : 1;
+    *sh2 = l > 1 ? l - 1 : 0;
+}
+
 void set_q(QuantOut& q, char* base, const Form& f) {
     q.ptr = (int8_t*)(base + f.off); q.n = f.n;
     q.lo = f.sgn ? -127 : 0; q.hi = f.sgn ? 127 : 255;
+    q.bias_xor = f.sgn ? 0u : 0x80808080u;      // unsigned int8 tensors are stored biased (x ^ 0x80)
 }
 
 }  // namespace
@@ -344,12 +356,16 @@ int f8_net_set_label(f8_net* net, int t, const char* label) {
 }
 
 // ------------------------------------------------------------------------------ planner
-static void pack_conv_weights(f8_net* net, Node& nd, const Tensor& src) {
+static void pack_conv_weights(f8_net* net, Node& nd, const Tensor& src, const Tensor& dst) {
     // Packed layout: [coutP][taps][CK] int8, K-contiguous per output channel, zero padded.
     // Generic: tap = (r,s), CK = Cs(src) channels.  Stem (cin <= 4, source = network input held as
-    // zero-haloed NHWC4): one "tap" per kernel ROW, CK = 32 bytes = 8 pixels x 4 channels of which
+    // haloed NHWC4): one "tap" per kernel ROW, CK = 32 bytes = 8 pixels x 4 channels of which
     // the first kw pixels / cin channels carry weights.
-    // Bias is offset-corrected for unsigned inputs: b' = b + 128 * sum_k w  (kernel header).
+    // Bias: unsigned inputs are stored biased (x - 128), so b' = b + 128 * sum of w over the taps that
+    // lie INSIDE the image.  Zero padding is fetched as biased 0 (= real 128) and must not be
+    // corrected for taps outside; which taps are outside depends only on the output row / column, so
+    // rows and columns are classified by their in-image tap mask and the table is
+    // bias[rowclass * ncc + colclass][cout].  Signed inputs / unpadded convs have one class.
     const f8_conv_desc& d = nd.cd;
     const int k = d.kernel;
     nd.coutP = round_up(d.cout, 32);
@@ -357,25 +373,66 @@ static void pack_conv_weights(f8_net* net, Node& nd, const Tensor& src) {
     else { nd.ck = src.Cs; nd.ktot = k * k * src.Cs; }
     nd.w_off = round_up_z(net->wblob.size(), 256);
     const size_t wbytes = (size_t)nd.coutP * nd.ktot;
-    nd.b_off = round_up_z(nd.w_off + wbytes, 256);
-    net->wblob.resize(nd.b_off + (size_t)nd.coutP * 4, 0);
-    int8_t* wp = (int8_t*)net->wblob.data() + nd.w_off;
+    net->wblob.resize(nd.w_off + wbytes, 0);
+    // per-tap weight sums
+    std::vector<long long> tapsum((size_t)d.cout * k * k, 0);
+    {
+        int8_t* wp = (int8_t*)net->wblob.data() + nd.w_off;
+        for (int o = 0; o < d.cout; ++o)
+            for (int c = 0; c < d.cin; ++c)
+                for (int r = 0; r < k; ++r)
+                    for (int s = 0; s < k; ++s) {
+                        const int8_t v = nd.w[(((size_t)o * d.cin + c) * k + r) * k + s];
+                        tapsum[((size_t)o * k + r) * k + s] += v;
+                        size_t idx;
+                        if (nd.stem) idx = (size_t)o * nd.ktot + (size_t)r * 32 + (size_t)s * 4 + c;
+                        else idx = (size_t)o * nd.ktot + ((size_t)(r * k + s)) * src.Cs + c;
+                        wp[idx] = v;
+                    }
+    }
+    // classes
+    std::vector<uint32_t> rmasks, cmasks;
+    std::vector<uint8_t> rowcls(dst.H, 0), colcls(dst.W, 0);
+    const bool classes = !d.input_signed && d.pad > 0 && !nd.stem;
+    if (classes) {
+        auto classify = [&](int n_out, int n_in, std::vector<uint32_t>& masks, std::vector<uint8_t>& cls) {
+            for (int p = 0; p < n_out; ++p) {
+                uint32_t mk = 0;
+                for (int r = 0; r < k; ++r) { const int h = p * d.stride - d.pad + r; if (h >= 0 && h < n_in) mk |= 1u << r; }
+                size_t id = 0;
+                while (id < masks.size() && masks[id] != mk) ++id;
+                if (id == masks.size()) masks.push_back(mk);
+                cls[p] = (uint8_t)id;
+            }
+        };
+        classify(dst.H, src.H, rmasks, rowcls);
+        classify(dst.W, src.W, cmasks, colcls);
+    } else {
+        rmasks.push_back((1u << k) - 1); cmasks.push_back((1u << k) - 1);
+    }
+    nd.ncc = classes ? (int)cmasks.size() : 0;
+    const size_t ncls = rmasks.size() * cmasks.size();
+    nd.b_off = round_up_z(net->wblob.size(), 256);
+    net->wblob.resize(nd.b_off + ncls * (size_t)nd.coutP * 4, 0);
     int32_t* bp = (int32_t*)(net->wblob.data() + nd.b_off);
-    for (int o = 0; o < d.cout; ++o) {
-        long long sum = 0;
-        for (int c = 0; c < d.cin; ++c)
-            for (int r = 0; r < k; ++r)
-                for (int s = 0; s < k; ++s) {
-                    const int8_t v = nd.w[(((size_t)o * d.cin + c) * k + r) * k + s];
-                    sum += v;
-                    size_t idx;
-                    if (nd.stem) idx = (size_t)o * nd.ktot + (size_t)r * 32 + (size_t)s * 4 + c;
-                    else idx = (size_t)o * nd.ktot + ((size_t)(r * k + s)) * src.Cs + c;
-                    wp[idx] = v;
-                }
-        uint32_t b = (uint32_t)nd.bias[o];
-        if (!d.input_signed) b += (uint32_t)(128ll * sum);
-        bp[o] = (int32_t)b;
+    for (size_t rc = 0; rc < rmasks.size(); ++rc)
+        for (size_t cc = 0; cc < cmasks.size(); ++cc)
+            for (int o = 0; o < d.cout; ++o) {
+                long long sum = 0;
+                for (int r = 0; r < k; ++r)
+                    for (int s = 0; s < k; ++s)
+                        if (((rmasks[rc] >> r) & 1u) && ((cmasks[cc] >> s) & 1u)) sum += tapsum[((size_t)o * k + r) * k + s];
+                uint32_t b = (uint32_t)nd.bias[o];
+                if (!d.input_signed) b += (uint32_t)(128ll * sum);
+                bp[(rc * cmasks.size() + cc) * (size_t)nd.coutP + o] = (int32_t)b;
+            }
+    if (classes) {
+        nd.rc_off = round_up_z(net->wblob.size(), 256);
+        net->wblob.resize(nd.rc_off + rowcls.size(), 0);
+        memcpy(net->wblob.data() + nd.rc_off, rowcls.data(), rowcls.size());
+        nd.cc_off = round_up_z(net->wblob.size(), 256);
+        net->wblob.resize(nd.cc_off + colcls.size(), 0);
+        memcpy(net->wblob.data() + nd.cc_off, colcls.data(), colcls.size());
     }
 }
 
@@ -464,6 +521,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     (void)P;
                     const int f = add_form(s, FORM_STEM, 0, 0);
                     Form& F = s.forms[f];
+                    F.sgn = nd.cd.input_signed ? 1 : 0;
                     F.pad = nd.cd.pad;
                     F.Hp = s.H + 2 * nd.cd.pad;
                     F.Wp = round_up(std::max(s.W + 2 * nd.cd.pad, nd.cd.stride * (Q - 1) + 8), 2);
@@ -546,7 +604,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 st.relu0 = nd.cd.relu;
                 if (nd.depthwise) pack_dw_weights(net, nd, s);
                 else {
-                    pack_conv_weights(net, nd, s);
+                    pack_conv_weights(net, nd, s, T[nd.out]);
                     const int M1 = T[nd.out].H * T[nd.out].W;
                     if (!pick_conv_tile(M1 * max_batch, nd.coutP, nd.ck, nd.fused_add >= 0, &nd.tile))
                         return fail(F8_ERR_UNSUPPORTED, "finalize: no conv kernel instance for ck=%d coutP=%d", nd.ck, nd.coutP);
@@ -581,8 +639,9 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 if (nd.depthwise) snprintf(buf, sizeof buf, "f8::dwconv3x3_kernel<%s>", d.input_signed ? "true" : "false");
                 else {
                     const int wpx = (nd.tile.bm == 128 && nd.tile.bn <= 64) ? 4 : 2, wco = 4 / wpx;
-                    snprintf(buf, sizeof buf, "f8::conv_igemm_kernel<%d, %d, %d, %d, %d, %s, %s>", nd.tile.bm, nd.tile.bn, nd.tile.bk, wpx, wco,
-                             (d.pad > 0 && !nd.stem) ? "true" : "false", st.res_t >= 0 ? "true" : "false");
+                    const int stages = 2;   // keep in sync with launch_conv_t
+                    snprintf(buf, sizeof buf, "f8::conv_igemm_kernel<%d, %d, %d, %d, %d, %s, %s, %d>", nd.tile.bm, nd.tile.bn, nd.tile.bk, wpx, wco,
+                             (d.pad > 0 && !nd.stem) ? "true" : "false", st.res_t >= 0 ? "true" : "false", stages);
                 }
                 st.kernel = buf;
                 break;
@@ -684,6 +743,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
             if (F.kind == FORM_STEM) {
                 F.off = alloc(F.bytes_per_img * max_batch);
                 net->stem_zero_off = F.off; net->stem_zero_bytes = F.bytes_per_img * max_batch;
+                net->stem_zero_val = F.sgn ? 0 : 0x80;
             }
     for (size_t si = 0; si < net->steps.size(); ++si) {
         Step& st = net->steps[si];
@@ -773,7 +833,7 @@ int f8_net_upload(f8_net* net) {
     if ((e = hipMalloc((void**)&net->d_w, std::max<size_t>(net->wblob.size(), 256))) != hipSuccess) return hip_fail(e, "hipMalloc(weights)");
     if (!net->wblob.empty() && (e = hipMemcpy(net->d_w, net->wblob.data(), net->wblob.size(), hipMemcpyHostToDevice)) != hipSuccess)
         return hip_fail(e, "hipMemcpy(weights)");
-    if (net->stem_zero_bytes && (e = hipMemset(net->d_arena + net->stem_zero_off, 0, net->stem_zero_bytes)) != hipSuccess)
+    if (net->stem_zero_bytes && (e = hipMemset(net->d_arena + net->stem_zero_off, net->stem_zero_val, net->stem_zero_bytes)) != hipSuccess)
         return hip_fail(e, "hipMemset(stem halo)");
     if ((e = hipDeviceSynchronize()) != hipSuccess) return hip_fail(e, "upload sync");
     net->uploaded = true;
@@ -797,9 +857,9 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             const Tensor& o = T[st.out.t];
             InArgs a{}; a.x = input; a.N = N; a.C = o.C; a.H = o.H; a.W = o.W;
             for (auto& F : o.forms) {
-                if (F.kind == FORM_I8) { if (F.n == 0) { a.out8 = (int8_t*)(A + F.off); a.Cs8 = o.Cs; } }
+                if (F.kind == FORM_I8) { if (F.n == 0) { a.out8 = (int8_t*)(A + F.off); a.Cs8 = o.Cs; if (!F.sgn) a.xor8 = 0x80808080u; } }
                 else if (F.kind == FORM_I32) { a.out32 = (int32_t*)(A + F.off); a.Cs32 = o.Cs; }
-                else { a.stem = (int8_t*)(A + F.off); a.Hp = F.Hp; a.Wp = F.Wp; a.pad = F.pad; }
+                else { a.stem = (int8_t*)(A + F.off); a.Hp = F.Hp; a.Wp = F.Wp; a.pad = F.pad; if (!F.sgn) a.xor8 = 0x80808080u; }
             }
             e = launch_input(a, s);
             break;
@@ -813,8 +873,11 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             a.w = (const int8_t*)(net->d_w + nd.w_off); a.w_bytes = (uint32_t)((size_t)nd.coutP * nd.ktot);
             a.bias = (const int32_t*)(net->d_w + nd.b_off);
             a.PQ = oT.H * oT.W; a.Q = oT.W; a.M = N * a.PQ;
+            make_magic((uint32_t)a.PQ, &a.mPQ, &a.s1PQ, &a.s2PQ);
+            make_magic((uint32_t)a.Q, &a.mQ, &a.s1Q, &a.s2Q);
             a.stride = d.stride; a.kh = d.kernel; a.CK = nd.ck; a.ktot = nd.ktot; a.coutP = nd.coutP;
-            a.xor_mask = d.input_signed ? 0u : 0x80808080u;
+            a.ncc = nd.ncc;
+            if (nd.ncc > 0) { a.rowcls = (const uint8_t*)(net->d_w + nd.rc_off); a.colcls = (const uint8_t*)(net->d_w + nd.cc_off); }
             if (nd.stem) {
                 a.sN = (int)sF.bytes_per_img; a.sP = d.stride * sF.Wp * 4; a.sQ = d.stride * 4;
                 a.origin = 0; a.H = sF.Hp; a.W = sF.Wp; a.pad = 0; a.kw = 1;
@@ -856,6 +919,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             const Tensor& oT = T[nd.out];
             PoolArgs a{};
             a.x = A + sF.off; a.in_is_i8 = sF.kind == FORM_I8; a.in_signed = sF.sgn;
+            if (a.in_is_i8) { a.q[0].bias_xor = 0; }
             a.N = N; a.H = sT.H; a.W = sT.W; a.P = oT.H; a.Q = oT.W; a.Cs = sT.Cs; a.k = nd.pk; a.stride = nd.pstride; a.pad = nd.ppad;
             fill_out(&a.out32, a.q);
             e = launch_maxpool(a, s);
