@@ -102,6 +102,82 @@ __device__ __forceinline__ int clamp_sym31(int v) {   // clamp_(max=2^31-1, min=
 // i.e. x - 128 as int8) and the zero padding (biased 0 == real 128) is repaired by a per-border-class
 // bias: bias[class][cout] = b + 128 * sum over the class's in-image taps of w  (host: pack_conv_weights).
 // ---------------------------------------------------------------------------------------------
+// Fused epilogue of one BM x BN tile: class bias -> ReLU -> [align + residual + clamp -> ReLU] -> int32 (I32T)
+// and / or up to two requantised int8 (NHWC) outputs.  ReLUs are branch-free floors.
+template <int BM, int BN, int WPX, int WCO, bool HAS_RES, int TCO, int TPX>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, v16i (&acc)[TCO][TPX], v4i (&rv)[HAS_RES ? TCO : 1][HAS_RES ? TPX : 1][4],
+                                              int m0, int co0, int wpx, int wco, int l31, int lh) {
+    const int floor0 = a.relu0 ? 0 : INT32_MIN, floor1 = a.relu1 ? 0 : INT32_MIN;
+#pragma unroll
+    for (int j = 0; j < TPX; ++j) {
+        const int m = m0 + wpx * (BM / WPX) + j * 32 + l31;
+        const bool ok = m < a.M;
+        const size_t rowo = (size_t)m * (size_t)a.coutP;
+        // border class of this lane's pixel (which taps fell outside the image)
+        const int32_t* bias = a.bias;
+        if (a.ncc > 0 && ok) {
+            const int n = (int)fast_div((unsigned)m, a.mPQ, a.s1PQ, a.s2PQ), rem = m - n * a.PQ;
+            const int p = (int)fast_div((unsigned)rem, a.mQ, a.s1Q, a.s2Q), q = rem - p * a.Q;
+            bias += (size_t)((int)a.rowcls[p] * a.ncc + (int)a.colcls[q]) * (size_t)a.coutP;
+        }
+#pragma unroll
+        for (int i = 0; i < TCO; ++i) {
+            const int cot = co0 + wco * (BN / WCO) + i * 32;   // first cout of this 32-wide MFMA tile
+            if (cot >= a.coutP) continue;                      // wave-uniform
+            int y[4][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const v4i bv = *(const v4i*)(bias + cot + 8 * g + 4 * lh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int v = max((int)((unsigned)acc[i][j][4 * g + e] + (unsigned)bv[e]), floor0);
+                    if (HAS_RES) {
+                        const unsigned s = ((unsigned)v << a.acc_shl) + ((unsigned)rv[i][j][g][e] << a.res_shl);
+                        v = max(clamp_sym31((int)s), floor1);
+                    }
+                    y[g][e] = v;
+                }
+            }
+            if (a.out32 && (m - l31 < a.M)) {              // I32T: 4 x 1 KB contiguous per wave
+                int32_t* op = a.out32 + i32t_index(m, cot, a.coutP) + 4 * 32 * lh;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    v4i o = {y[g][0], y[g][1], y[g][2], y[g][3]};
+                    *(v4i*)(op + g * 256) = o;
+                }
+            }
+            // int8 rows: lanes l and l+32 hold interleaved 4-channel groups of one pixel
+            //   lower: d[0]=c0-3  d[1]=c8-11  d[2]=c16-19 d[3]=c24-27
+            //   upper: d[0]=c4-7  d[1]=c12-15 d[2]=c20-23 d[3]=c28-31
+            // two half-swaps give each lane 16 contiguous channel bytes (lower c0-15, upper c16-31).
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (!a.q[k].ptr) continue;                 // wave-uniform
+                unsigned d[4];
+                const int qn = a.q[k].n, qlo = a.q[k].lo, qhi = a.q[k].hi;
+                if (qn > 0) {                              // wave-uniform: the common case, right shift
+                    const unsigned half = 1u << (qn - 1), mask = (half << 1) - 1u;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        d[g] = pack4(requant_shr(y[g][0], qn, half, mask, qlo, qhi), requant_shr(y[g][1], qn, half, mask, qlo, qhi),
+                                     requant_shr(y[g][2], qn, half, mask, qlo, qhi), requant_shr(y[g][3], qn, half, mask, qlo, qhi)) ^ a.q[k].bias_xor;
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        d[g] = pack4(requant_shl(y[g][0], qn, qlo, qhi), requant_shl(y[g][1], qn, qlo, qhi),
+                                     requant_shl(y[g][2], qn, qlo, qhi), requant_shl(y[g][3], qn, qlo, qhi)) ^ a.q[k].bias_xor;
+                }
+                auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+                auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+                if (ok) {
+                    v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
+                    *(v4i*)(a.q[k].ptr + rowo + cot + 16 * lh) = o;
+                }
+            }
+        }
+    }
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
 template <int BM, int BN, int BK, int WPX, int WCO, bool HAS_PAD, bool HAS_RES, int STAGES>
@@ -277,8 +353,208 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
         const int issued = (ks + STAGES - 1 < nk) ? ks + STAGES - 1 : nk;
         wait_ahead(issued - 1 - ks);
         __builtin_amdgcn_s_barrier();     // all waves' DMA for stage ks landed; slot (ks-1)%STAGES is free
+#ifndef F8_ABL_NO_DMA
         if (ks + STAGES - 1 < nk) issue_stage((ks + STAGES - 1) % STAGES);
+#endif
         const char* base = lds + (ks % STAGES) * TILE;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            v4i wf[TCO], xf[TPX];
+#pragma unroll
+            for (int i = 0; i < TCO; ++i) wf[i] = *(const v4i*)(base + wfrag0 + i * 32 * BK + coff[kk]);
+#pragma unroll
+            for (int j = 0; j < TPX; ++j) xf[j] = *(const v4i*)(base + xfrag0 + j * 32 * BK + coff[kk]);
+#pragma unroll
+            for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                for (int j = 0; j < TPX; ++j)
+#ifndef F8_ABL_NO_MFMA
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xf[j], acc[i][j], 0, 0, 0);
+#else
+                    acc[i][j][0] += wf[i].x ^ xf[j].x;
+#endif
+        }
+    }
+#ifdef F8_ABL_NO_EPI
+    if (a.M > 0) {   // ablation: one dummy store per lane keeps the accumulators live, nothing else
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < TCO; ++i)
+#pragma unroll
+            for (int j = 0; j < TPX; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t ^= acc[i][j][r];
+        if (t == 0x12345678) a.q[0].ptr[tid] = (int8_t)t;
+        return;
+    }
+#endif
+
+    conv_epilogue<BM, BN, WPX, WCO, HAS_RES, TCO, TPX>(a, acc, rv, m0, co0, wpx, wco, l31, lh);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent variant (no residual operand): a fixed grid of workgroups, each walking a strided list
+// of tiles.  The DMA ring runs AHEAD ACROSS TILE BOUNDARIES, so a tile's first operands are already in
+// LDS when its predecessor's epilogue finishes: no per-workgroup start-up bubble, the epilogue's
+// VALU/stores overlap the next tile's loads, and the work is balanced in units of tiles rather than
+// in rounds of resident workgroups (784 tiles on 768 slots no longer cost two rounds).
+// Tile order: XCD x owns a contiguous chunk of the (pixel-tile major, cout-tile minor) tile list;
+// its workgroups take tiles chunk_base + w, + w + G/8, ... so concurrently running workgroups of one
+// XCD sit on adjacent tiles (shared X rows / 3x3 halos hit that XCD's L2).
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int BK, int WPX, int WCO, bool HAS_PAD, int STAGES>
+__global__ void __launch_bounds__(256) conv_igemm_persist_kernel(const ConvArgs a) {
+    static_assert(WPX * WCO == 4, "4 waves");
+    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
+    constexpr int CPR = BK / 16;
+    constexpr int RPB = 256 / BK;
+    constexpr int XCH = BM * CPR, WCH = BN * CPR;
+    constexpr int XL = (XCH + 255) / 256, WL = (WCH + 255) / 256;
+    constexpr int NLD = XL + WL;
+    constexpr int TPX = BM / WPX / 32, TCO = BN / WCO / 32;
+    constexpr int KK = BK / 32;
+    constexpr int XBYTES = BM * BK, TILE = (BM + BN) * BK;
+    static_assert(STAGES * TILE <= 65536, "static LDS");
+
+    __shared__ __attribute__((aligned(16))) char lds[STAGES * TILE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 3;
+    const int wpx = wave / WCO, wco = wave % WCO;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // ---- this workgroup's tile list
+    const int tilesN = (a.coutP + BN - 1) / BN;
+    const int tilesM = (a.M + BM - 1) / BM;
+    const int T = tilesM * tilesN;
+    const int G = gridDim.x, Gx = G >> 3;                 // host: G % 8 == 0
+    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
+    const int cb = (int)(((long long)T * xcd) >> 3), ce = (int)(((long long)T * (xcd + 1)) >> 3);
+    const int first = cb + w;
+    const int ntl = first < ce ? (ce - first + Gx - 1) / Gx : 0;
+    const int nk = a.ktot / BK;
+    const int total = ntl * nk;
+    if (total == 0) return;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+
+    // ---- issue-side state: gather descriptors of the tile whose stages are being requested
+    unsigned xbase[XL], wbase[WL];
+    int xh0[XL], xw0[XL];
+    int tr = 0, ts = 0, c0 = 0, kiss = 0;      // K position inside the issue tile
+    int ij = 0;                                 // index of the issue tile in my list
+    auto setup_issue_tile = [&](int t) {
+        const int tile_m = t / tilesN, tile_n = t - tile_m * tilesN;
+        const int m0 = tile_m * BM, co0 = tile_n * BN;
+#pragma unroll
+        for (int i = 0; i < XL; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / CPR, chunk = (idx % CPR) ^ ((row / RPB) % CPR);
+            const int m = m0 + row;
+            xh0[i] = xw0[i] = -(1 << 24);
+            xbase[i] = kOOB;
+            if (idx < XCH && m < a.M) {
+                const int n = (int)fast_div((unsigned)m, a.mPQ, a.s1PQ, a.s2PQ), rem = m - n * a.PQ;
+                const int p = (int)fast_div((unsigned)rem, a.mQ, a.s1Q, a.s2Q), q = rem - p * a.Q;
+                xbase[i] = (unsigned)(n * a.sN + p * a.sP + q * a.sQ + a.origin + chunk * 16);
+                xh0[i] = p * a.stride - a.pad;
+                xw0[i] = q * a.stride - a.pad;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WL; ++j) {
+            const int idx = tid + j * 256;
+            const int row = idx / CPR, chunk = (idx % CPR) ^ ((row / RPB) % CPR);
+            wbase[j] = (idx < WCH) ? (unsigned)((co0 + row) * a.ktot + chunk * 16) : kOOB;
+        }
+        tr = ts = c0 = kiss = 0;
+    };
+    auto issue_stage = [&](int slot) {
+        char* base = lds + slot * TILE;
+        const unsigned koffx = (unsigned)(tr * a.tapH + ts * a.tapW + c0);
+#pragma unroll
+        for (int i = 0; i < XL; ++i) {
+            unsigned off = xbase[i] + koffx;
+            if (HAS_PAD)
+                off = ((unsigned)(xh0[i] + tr) < (unsigned)a.H && (unsigned)(xw0[i] + ts) < (unsigned)a.W) ? off : kOOB;
+            if ((i * 256 + wave * 64) < XCH)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(base + i * 4096 + wave * 1024),
+                                                         16, off, 0, 0, 0);
+        }
+        const unsigned koffw = (unsigned)(kiss * BK);
+#pragma unroll
+        for (int j = 0; j < WL; ++j) {
+            const unsigned woff = wbase[j] + koffw;   // keep a scalar (see conv_igemm_kernel)
+            if ((j * 256 + wave * 64) < WCH)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(base + XBYTES + j * 4096 + wave * 1024),
+                                                         16, woff, 0, 0, 0);
+        }
+        ++kiss;
+        c0 += BK;
+        if (c0 == a.CK) {
+            c0 = 0; ++ts;
+            if (ts == a.kw) { ts = 0; ++tr; }
+        }
+        if (kiss == nk) {                       // crossed into my next tile
+            ++ij;
+            if (ij < ntl) setup_issue_tile(first + ij * Gx);
+        }
+    };
+    constexpr bool UNIFORM_LD = (XCH % 256 == 0) && (WCH % 256 == 0);
+    int my_ld = 0;
+    if (!UNIFORM_LD) {
+#pragma unroll
+        for (int i = 0; i < XL; ++i) my_ld += ((i * 256 + wave * 64) < XCH) ? 1 : 0;
+#pragma unroll
+        for (int j = 0; j < WL; ++j) my_ld += ((j * 256 + wave * 64) < WCH) ? 1 : 0;
+    }
+    // Counted wait.  Only DMA instructions are counted; epilogue stores issued since are NEWER than
+    // every pending DMA, so a count that ignores them can only wait for more than needed, never less.
+    auto wait_ahead = [&](int ahead) {
+        if (UNIFORM_LD) {
+            if (ahead >= 2 && STAGES >= 4) wait_vmcnt<2 * NLD>();
+            else if (ahead >= 1 && STAGES >= 3) wait_vmcnt<1 * NLD>();
+            else wait_vmcnt<0>();
+        } else {
+            const int n = ahead * my_ld;
+            if (n >= 4) wait_vmcnt<4>(); else if (n == 3) wait_vmcnt<3>(); else if (n == 2) wait_vmcnt<2>();
+            else if (n == 1) wait_vmcnt<1>(); else wait_vmcnt<0>();
+        }
+    };
+
+    // ---- per-lane fragment addresses
+    const int fl = (l31 / RPB) % CPR;
+    unsigned coff[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) coff[kk] = (unsigned)(((kk * 2 + lh) ^ fl) << 4);
+    const unsigned xfrag0 = (unsigned)((wpx * (BM / WPX) + l31) * BK);
+    const unsigned wfrag0 = (unsigned)(XBYTES + (wco * (BN / WCO) + l31) * BK);
+
+    v16i acc[TCO][TPX];
+    v4i rv[1][1][4];      // no residual in the persistent variant
+
+    setup_issue_tile(first);
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < total) issue_stage(s);
+
+    int cj = 0, ck = 0;                         // compute-side tile / K step
+    for (int step = 0; step < total; ++step) {
+        const int issued = (step + STAGES - 1 < total) ? step + STAGES - 1 : total;
+        wait_ahead(issued - 1 - step);
+        __builtin_amdgcn_s_barrier();
+        if (step + STAGES - 1 < total) issue_stage((step + STAGES - 1) % STAGES);
+        if (ck == 0) {
+#pragma unroll
+            for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                for (int j = 0; j < TPX; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+        }
+        const char* base = lds + (step % STAGES) * TILE;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             v4i wf[TCO], xf[TPX];
@@ -292,77 +568,11 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
                 for (int j = 0; j < TPX; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xf[j], acc[i][j], 0, 0, 0);
         }
-    }
-
-    // ---- epilogue: class bias -> ReLU -> [align + residual + clamp -> ReLU] -> int32 / requantised int8
-    // ReLUs are branch-free floors (INT32_MIN = no ReLU).
-    const int floor0 = a.relu0 ? 0 : INT32_MIN, floor1 = a.relu1 ? 0 : INT32_MIN;
-#pragma unroll
-    for (int j = 0; j < TPX; ++j) {
-        const int m = m0 + wpx * (BM / WPX) + j * 32 + l31;
-        const bool ok = m < a.M;
-        const size_t rowo = (size_t)m * (size_t)a.coutP;
-        // border class of this lane's pixel (which taps fell outside the image)
-        const int32_t* bias = a.bias;
-        if (a.ncc > 0 && ok) {
-            const int n = (int)fast_div((unsigned)m, a.mPQ, a.s1PQ, a.s2PQ), rem = m - n * a.PQ;
-            const int p = (int)fast_div((unsigned)rem, a.mQ, a.s1Q, a.s2Q), q = rem - p * a.Q;
-            bias += (size_t)((int)a.rowcls[p] * a.ncc + (int)a.colcls[q]) * (size_t)a.coutP;
-        }
-#pragma unroll
-        for (int i = 0; i < TCO; ++i) {
-            const int cot = co0 + wco * (BN / WCO) + i * 32;   // first cout of this 32-wide MFMA tile
-            if (cot >= a.coutP) continue;                      // wave-uniform
-            int y[4][4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const v4i bv = *(const v4i*)(bias + cot + 8 * g + 4 * lh);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    int v = max((int)((unsigned)acc[i][j][4 * g + e] + (unsigned)bv[e]), floor0);
-                    if (HAS_RES) {
-                        const unsigned s = ((unsigned)v << a.acc_shl) + ((unsigned)rv[i][j][g][e] << a.res_shl);
-                        v = max(clamp_sym31((int)s), floor1);
-                    }
-                    y[g][e] = v;
-                }
-            }
-            if (a.out32 && (m - l31 < a.M)) {              // I32T: 4 x 1 KB contiguous per wave
-                int32_t* op = a.out32 + i32t_index(m, cot, a.coutP) + 4 * 32 * lh;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    v4i o = {y[g][0], y[g][1], y[g][2], y[g][3]};
-                    *(v4i*)(op + g * 256) = o;
-                }
-            }
-            // int8 rows: lanes l and l+32 hold interleaved 4-channel groups of one pixel
-            //   lower: d[0]=c0-3  d[1]=c8-11  d[2]=c16-19 d[3]=c24-27
-            //   upper: d[0]=c4-7  d[1]=c12-15 d[2]=c20-23 d[3]=c28-31
-            // two half-swaps give each lane 16 contiguous channel bytes (lower c0-15, upper c16-31).
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                if (!a.q[k].ptr) continue;                 // wave-uniform
-                unsigned d[4];
-                const int qn = a.q[k].n, qlo = a.q[k].lo, qhi = a.q[k].hi;
-                if (qn > 0) {                              // wave-uniform: the common case, right shift
-                    const unsigned half = 1u << (qn - 1), mask = (half << 1) - 1u;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        d[g] = pack4(requant_shr(y[g][0], qn, half, mask, qlo, qhi), requant_shr(y[g][1], qn, half, mask, qlo, qhi),
-                                     requant_shr(y[g][2], qn, half, mask, qlo, qhi), requant_shr(y[g][3], qn, half, mask, qlo, qhi)) ^ a.q[k].bias_xor;
-                } else {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        d[g] = pack4(requant_shl(y[g][0], qn, qlo, qhi), requant_shl(y[g][1], qn, qlo, qhi),
-                                     requant_shl(y[g][2], qn, qlo, qhi), requant_shl(y[g][3], qn, qlo, qhi)) ^ a.q[k].bias_xor;
-                }
-                auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
-                auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
-                if (ok) {
-                    v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
-                    *(v4i*)(a.q[k].ptr + rowo + cot + 16 * lh) = o;
-                }
-            }
+        if (++ck == nk) {
+            const int t = first + cj * Gx;
+            const int tile_m = t / tilesN, tile_n = t - tile_m * tilesN;
+            conv_epilogue<BM, BN, WPX, WCO, false, TCO, TPX>(a, acc, rv, tile_m * BM, tile_n * BN, wpx, wco, l31, lh);
+            ck = 0; ++cj;
         }
     }
 }
@@ -602,6 +812,8 @@ static inline int grid_for(size_t work, int block = 256, int cap = 256 * 8 * 4) 
 bool pick_conv_tile(int M, int coutP, int ck, bool has_res, ConvTile* t) {
     if (ck % 32 != 0 || coutP % 32 != 0) return false;
     t->bk = (ck % 64 == 0) ? 64 : 32;
+    static const int bk128 = [] { const char* e = getenv("F8_BK128"); return e ? atoi(e) : 0; }();
+    if (bk128 && ck % 128 == 0 && coutP > 32) t->bk = 128;
     t->bn = coutP >= 96 ? 128 : (coutP > 32 ? 64 : 32);
     t->bm = 128;
     // residual-carrying epilogues hold the int32 operand in registers: the 64-wide tile keeps
@@ -622,19 +834,43 @@ int conv_grid(const ConvTile& t, int M, int coutP) {
     return ((M + t.bm - 1) / t.bm) * ((coutP + t.bn - 1) / t.bn);
 }
 
+static int g_num_cu = 0;
+static int num_cus() {
+    if (g_num_cu == 0) {
+        int dev = 0; hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) g_num_cu = p.multiProcessorCount;
+        if (g_num_cu <= 0) g_num_cu = 256;
+    }
+    return g_num_cu;
+}
+
 template <int BM, int BN, int BK, int WPX, int WCO>
 static hipError_t launch_conv_t(const ConvArgs& a, int grid, hipStream_t s) {
-    constexpr int TILE = (BM + BN) * BK;
 #ifdef F8_FORCE_STAGES
     constexpr int ST = F8_FORCE_STAGES;
 #else
-    // measured on ResNet-50 (profiles/): ring depth 2/3/4 = 49.9k/49.5k/48.5k img/s — these layers are bound by
-    // per-workgroup instruction issue and start-up, not by steady-state latency, so the smaller LDS
-    // footprint (more resident workgroups) wins
+    // measured on ResNet-50 (profiles/): ring depth 2/3/4 = 49.9k/49.5k/48.5k img/s for the one-tile-per-workgroup
+    // kernel — bound by per-workgroup instruction issue and start-up, not by steady-state latency, so the
+    // smaller LDS footprint (more resident workgroups) wins there
     constexpr int ST = 2;
 #endif
+    constexpr int TILE = (BM + BN) * BK;
     static_assert(ST * TILE <= 65536, "static LDS");
     const bool pad = a.pad > 0, res = a.res != nullptr;
+    static const int persist_mode = [] { const char* e = getenv("F8_PERSIST"); return e ? atoi(e) : 0; }();
+    if (!res && persist_mode) {
+        // persistent variant: fixed grid (multiple of 8 XCDs), deeper ring
+        constexpr int PST = (4 * TILE <= 65536) ? 4 : ((3 * TILE <= 65536) ? 3 : 2);
+        static const int wpc_env = [] { const char* e = getenv("F8_PERSIST_WPC"); return e ? atoi(e) : 0; }();
+        const int lds_wpc = 163840 / (PST * TILE);
+        int wpc = wpc_env > 0 ? wpc_env : (lds_wpc < 3 ? lds_wpc : 3);
+        if (wpc < 1) wpc = 1;
+        int g = num_cus() * wpc;
+        if (g > grid) g = (grid + 7) / 8 * 8;
+        if (pad) hipLaunchKernelGGL((conv_igemm_persist_kernel<BM, BN, BK, WPX, WCO, true, PST>), dim3(g), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_igemm_persist_kernel<BM, BN, BK, WPX, WCO, false, PST>), dim3(g), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     if (pad && res) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, true, true, ST>), dim3(grid), dim3(256), 0, s, a);
     else if (pad) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, true, false, ST>), dim3(grid), dim3(256), 0, s, a);
     else if (res) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, false, true, ST>), dim3(grid), dim3(256), 0, s, a);
@@ -646,6 +882,10 @@ hipError_t launch_conv(const ConvArgs& a, const ConvTile& t, hipStream_t s) {
     const int grid = conv_grid(t, a.M, a.coutP);
 #define F8_CASE(BM_, BN_, BK_, WPX_, WCO_) \
     if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_) return launch_conv_t<BM_, BN_, BK_, WPX_, WCO_>(a, grid, s);
+    F8_CASE(128, 128, 128, 2, 2)
+    F8_CASE(128, 64, 128, 4, 1)
+    F8_CASE(64, 128, 128, 2, 2)
+    F8_CASE(64, 64, 128, 2, 2)
     F8_CASE(128, 128, 64, 2, 2)
     F8_CASE(128, 64, 64, 4, 1)
     F8_CASE(128, 32, 64, 4, 1)

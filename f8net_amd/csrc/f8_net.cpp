@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -106,6 +107,7 @@ struct f8_net {
     // device
     char* d_arena = nullptr; char* d_w = nullptr; bool uploaded = false;
     hipEvent_t* events = nullptr; int n_events = 0;
+    hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t aux_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -156,8 +158,8 @@ void make_magic(uint32_t d, uint32_t* magic, int32_t* sh1, int32_t* sh2) {
     *sh2 = l > 1 ? l - 1 : 0;
 }
 
-void set_q(QuantOut& q, char* base, const Form& f) {
-    q.ptr = (int8_t*)(base + f.off); q.n = f.n;
+void set_q(QuantOut& q, char* ptr, const Form& f) {
+    q.ptr = (int8_t*)ptr; q.n = f.n;
     q.lo = f.sgn ? -127 : 0; q.hi = f.sgn ? 127 : 255;
     q.bias_xor = f.sgn ? 0u : 0x80808080u;      // unsigned int8 tensors are stored biased (x ^ 0x80)
 }
@@ -223,6 +225,8 @@ void f8_net_destroy(f8_net* net) {
         for (int i = 0; i < net->n_events; ++i) (void)hipEventDestroy(net->events[i]);
         delete[] net->events;
     }
+    for (int k = 0; k < 4; ++k) if (net->aux[k]) (void)hipStreamDestroy(net->aux[k]);
+    for (int k = 0; k < 5; ++k) if (net->aux_ev[k]) (void)hipEventDestroy(net->aux_ev[k]);
     delete net;
 }
 
@@ -639,9 +643,9 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 if (nd.depthwise) snprintf(buf, sizeof buf, "f8::dwconv3x3_kernel<%s>", d.input_signed ? "true" : "false");
                 else {
                     const int wpx = (nd.tile.bm == 128 && nd.tile.bn <= 64) ? 4 : 2, wco = 4 / wpx;
-                    const int stages = 2;   // keep in sync with launch_conv_t
-                    snprintf(buf, sizeof buf, "f8::conv_igemm_kernel<%d, %d, %d, %d, %d, %s, %s, %d>", nd.tile.bm, nd.tile.bn, nd.tile.bk, wpx, wco,
-                             (d.pad > 0 && !nd.stem) ? "true" : "false", st.res_t >= 0 ? "true" : "false", stages);
+                    // keep in sync with launch_conv_t (f8_kernels.hip)
+                    snprintf(buf, sizeof buf, "f8::conv_igemm_kernel<%d, %d, %d, %d, %d, %s, %s, 2>", nd.tile.bm, nd.tile.bn, nd.tile.bk, wpx, wco,
+                             (d.pad > 0 && !nd.stem) ? "true" : "false", st.res_t >= 0 ? "true" : "false");
                 }
                 st.kernel = buf;
                 break;
@@ -840,26 +844,30 @@ int f8_net_upload(f8_net* net) {
     return F8_OK;
 }
 
-static int run_step(f8_net* net, const Step& st, const int32_t* input, void* output, int N, hipStream_t s) {
+// Runs one launch for images [n0, n0 + N) of the batch (sub-batches are independent: every form is laid
+// out image-major, so a sub-batch is a pointer offset; I32T forms need n0 * H * W % 32 == 0, which the
+// caller guarantees).
+static int run_step(f8_net* net, const Step& st, const int32_t* input, void* output, int n0, int N, hipStream_t s) {
     auto& T = net->tensors;
     char* A = net->d_arena;
+    auto fp = [&](const Form& F) -> char* { return A + F.off + (size_t)n0 * F.bytes_per_img; };
     const Node& nd = net->nodes[st.node];
     auto fill_out = [&](int32_t** out32, QuantOut q[2]) {
         *out32 = nullptr; q[0].ptr = q[1].ptr = nullptr; q[0].n = q[1].n = 0; q[0].lo = q[1].lo = 0; q[0].hi = q[1].hi = 0;
         if (st.out.t < 0 || st.dense) return;
         const Tensor& o = T[st.out.t];
-        if (st.out.f32 >= 0) *out32 = (int32_t*)(A + o.forms[st.out.f32].off);
-        for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) set_q(q[k], A, o.forms[st.out.f8[k]]);
+        if (st.out.f32 >= 0) *out32 = (int32_t*)fp(o.forms[st.out.f32]);
+        for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) set_q(q[k], fp(o.forms[st.out.f8[k]]), o.forms[st.out.f8[k]]);
     };
     hipError_t e = hipSuccess;
     switch (st.kind) {
         case S_INPUT: {
             const Tensor& o = T[st.out.t];
-            InArgs a{}; a.x = input; a.N = N; a.C = o.C; a.H = o.H; a.W = o.W;
+            InArgs a{}; a.x = input + (size_t)n0 * o.C * o.H * o.W; a.N = N; a.C = o.C; a.H = o.H; a.W = o.W;
             for (auto& F : o.forms) {
-                if (F.kind == FORM_I8) { if (F.n == 0) { a.out8 = (int8_t*)(A + F.off); a.Cs8 = o.Cs; if (!F.sgn) a.xor8 = 0x80808080u; } }
-                else if (F.kind == FORM_I32) { a.out32 = (int32_t*)(A + F.off); a.Cs32 = o.Cs; }
-                else { a.stem = (int8_t*)(A + F.off); a.Hp = F.Hp; a.Wp = F.Wp; a.pad = F.pad; if (!F.sgn) a.xor8 = 0x80808080u; }
+                if (F.kind == FORM_I8) { if (F.n == 0) { a.out8 = (int8_t*)fp(F); a.Cs8 = o.Cs; if (!F.sgn) a.xor8 = 0x80808080u; } }
+                else if (F.kind == FORM_I32) { a.out32 = (int32_t*)fp(F); a.Cs32 = o.Cs; }
+                else { a.stem = (int8_t*)fp(F); a.Hp = F.Hp; a.Wp = F.Wp; a.pad = F.pad; if (!F.sgn) a.xor8 = 0x80808080u; }
             }
             e = launch_input(a, s);
             break;
@@ -869,7 +877,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             const Tensor& oT = T[nd.out];
             const f8_conv_desc& d = nd.cd;
             ConvArgs a{};
-            a.x = (const int8_t*)(A + sF.off); a.x_bytes = (uint32_t)(sF.bytes_per_img * N);
+            a.x = (const int8_t*)fp(sF); a.x_bytes = (uint32_t)(sF.bytes_per_img * N);
             a.w = (const int8_t*)(net->d_w + nd.w_off); a.w_bytes = (uint32_t)((size_t)nd.coutP * nd.ktot);
             a.bias = (const int32_t*)(net->d_w + nd.b_off);
             a.PQ = oT.H * oT.W; a.Q = oT.W; a.M = N * a.PQ;
@@ -888,7 +896,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
                 a.tapH = sT.W * sT.Cs; a.tapW = sT.Cs;
             }
             a.relu0 = st.relu0;
-            if (st.res_t >= 0) { a.res = (const int32_t*)(A + T[st.res_t].forms[st.res_f].off); a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1; }
+            if (st.res_t >= 0) { a.res = (const int32_t*)fp(T[st.res_t].forms[st.res_f]); a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1; }
             fill_out(&a.out32, a.q);
             e = launch_conv(a, nd.tile, s);
             break;
@@ -897,7 +905,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             const Tensor& sT = T[st.src_t]; const Form& sF = sT.forms[st.src_f];
             const Tensor& oT = T[nd.out];
             DwArgs a{};
-            a.x = (const int8_t*)(A + sF.off); a.w = (const int8_t*)(net->d_w + nd.w_off); a.bias = (const int32_t*)(net->d_w + nd.b_off);
+            a.x = (const int8_t*)fp(sF); a.w = (const int8_t*)(net->d_w + nd.w_off); a.bias = (const int32_t*)(net->d_w + nd.b_off);
             a.N = N; a.H = sT.H; a.W = sT.W; a.P = oT.H; a.Q = oT.W; a.Cs = sT.Cs; a.stride = nd.cd.stride; a.pad = nd.cd.pad;
             a.in_signed = nd.cd.input_signed; a.relu0 = st.relu0;
             fill_out(&a.out32, a.q);
@@ -907,8 +915,8 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
         case S_ADD: case S_REQUANT: {
             const Tensor& sT = T[st.src_t];
             AddArgs a{};
-            a.a = (const int32_t*)(A + sT.forms[st.src_f].off);
-            a.b = st.kind == S_ADD ? (const int32_t*)(A + T[st.res_t].forms[st.res_f].off) : nullptr;
+            a.a = (const int32_t*)fp(sT.forms[st.src_f]);
+            a.b = st.kind == S_ADD ? (const int32_t*)fp(T[st.res_t].forms[st.res_f]) : nullptr;
             a.M = N * sT.H * sT.W; a.Cs = sT.Cs; a.a_shl = st.acc_shl; a.b_shl = st.res_shl; a.relu = st.relu1;
             fill_out(&a.out32, a.q);
             e = launch_add(a, s);
@@ -918,7 +926,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             const Tensor& sT = T[st.src_t]; const Form& sF = sT.forms[st.src_f];
             const Tensor& oT = T[nd.out];
             PoolArgs a{};
-            a.x = A + sF.off; a.in_is_i8 = sF.kind == FORM_I8; a.in_signed = sF.sgn;
+            a.x = fp(sF); a.in_is_i8 = sF.kind == FORM_I8; a.in_signed = sF.sgn;
             if (a.in_is_i8) { a.q[0].bias_xor = 0; }
             a.N = N; a.H = sT.H; a.W = sT.W; a.P = oT.H; a.Q = oT.W; a.Cs = sT.Cs; a.k = nd.pk; a.stride = nd.pstride; a.pad = nd.ppad;
             fill_out(&a.out32, a.q);
@@ -928,7 +936,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
         case S_AVGPOOL: {
             const Tensor& sT = T[st.src_t];
             AvgArgs a{};
-            a.x = (const int32_t*)(A + sT.forms[st.src_f].off); a.N = N; a.HW = sT.H * sT.W; a.Cs = sT.Cs;
+            a.x = (const int32_t*)fp(sT.forms[st.src_f]); a.N = N; a.HW = sT.H * sT.W; a.Cs = sT.Cs;
             fill_out(&a.out32, a.q);
             e = launch_avgpool(a, s);
             break;
@@ -936,14 +944,33 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
         case S_OUTPUT: {
             const Tensor& sT = T[st.src_t];
             OutArgs a{};
-            a.x = (const int32_t*)(A + sT.forms[st.src_f].off); a.N = N; a.C = sT.C; a.HW = sT.H * sT.W; a.Cs = sT.Cs;
-            a.out = output; a.as_float = net->out_float;
+            a.x = (const int32_t*)fp(sT.forms[st.src_f]); a.N = N; a.C = sT.C; a.HW = sT.H * sT.W; a.Cs = sT.Cs;
+            a.out = (char*)output + (size_t)n0 * sT.C * sT.H * sT.W * 4; a.as_float = net->out_float;
             e = launch_output(a, s);
             break;
         }
     }
     if (e != hipSuccess) return hip_fail(e, st.name.c_str());
     return F8_OK;
+}
+
+// Cuts the batch into up to F8_SPLIT (default 2, max 4) sub-batches; every I32T form needs each cut at a
+// multiple of 32 pixels.  Returns the number of parts and their starts in cut[0..parts].
+static int split_batch(const f8_net* net, int N, int cut[5]) {
+    static const int want = [] { const char* e = getenv("F8_SPLIT"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+    cut[0] = 0; cut[1] = N;
+    if (want < 2 || N < 2) return 1;
+    int gran = 1;
+    for (auto& t : net->tensors)
+        for (auto& F : t.forms)
+            if (F.kind == FORM_I32 && ((size_t)t.H * t.W) % 32 != 0) gran = 32;
+    int parts = want;
+    while (parts > 1 && (N / parts) / gran * gran == 0) --parts;
+    if (parts < 2) return 1;
+    const int per = (N / parts) / gran * gran;
+    for (int p = 0; p < parts; ++p) cut[p] = p * per;
+    cut[parts] = N;
+    return parts;
 }
 
 static int run_common(f8_net* net, const int32_t* input, void* output, int N, void* stream, float* ms, int cap) {
@@ -954,24 +981,67 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int ns = (int)net->steps.size();
+    int cut[5];
+    const int parts = split_batch(net, N, cut);
     if (ms) {
+        // profiled: the sub-batches back to back on the caller's stream, one event pair per launch
         if (cap < ns) return fail(F8_ERR_INVALID, "f8_net_run_profiled: ms capacity %d < %d launches", cap, ns);
-        if (net->n_events < ns + 1) {
+        const int ne = parts * (ns + 1);
+        if (net->n_events < ne) {
             if (net->events) { for (int i = 0; i < net->n_events; ++i) (void)hipEventDestroy(net->events[i]); delete[] net->events; }
-            net->events = new hipEvent_t[ns + 1]; net->n_events = ns + 1;
-            for (int i = 0; i <= ns; ++i) { hipError_t e = hipEventCreate(&net->events[i]); if (e != hipSuccess) return hip_fail(e, "hipEventCreate"); }
+            net->events = new hipEvent_t[ne]; net->n_events = ne;
+            for (int i = 0; i < ne; ++i) { hipError_t e = hipEventCreate(&net->events[i]); if (e != hipSuccess) return hip_fail(e, "hipEventCreate"); }
         }
-        (void)hipEventRecord(net->events[0], s);
-    }
-    for (int i = 0; i < ns; ++i) {
-        rc = run_step(net, net->steps[i], input, output, N, s);
-        if (rc) return rc;
-        if (ms) (void)hipEventRecord(net->events[i + 1], s);
-    }
-    if (ms) {
+        for (int p = 0; p < parts; ++p) {
+            hipEvent_t* ev = net->events + p * (ns + 1);
+            (void)hipEventRecord(ev[0], s);
+            for (int i = 0; i < ns; ++i) {
+                rc = run_step(net, net->steps[i], input, output, cut[p], cut[p + 1] - cut[p], s);
+                if (rc) return rc;
+                (void)hipEventRecord(ev[i + 1], s);
+            }
+        }
         hipError_t e = hipStreamSynchronize(s);
         if (e != hipSuccess) return hip_fail(e, "f8_net_run_profiled: sync");
-        for (int i = 0; i < ns; ++i) (void)hipEventElapsedTime(&ms[i], net->events[i], net->events[i + 1]);
+        for (int i = 0; i < ns; ++i) {
+            ms[i] = 0.f;
+            for (int p = 0; p < parts; ++p) {
+                float t = 0.f;
+                (void)hipEventElapsedTime(&t, net->events[p * (ns + 1) + i], net->events[p * (ns + 1) + i + 1]);
+                ms[i] += t;
+            }
+        }
+        return F8_OK;
+    }
+    if (parts == 1) {
+        for (int i = 0; i < ns; ++i) {
+            rc = run_step(net, net->steps[i], input, output, 0, N, s);
+            if (rc) return rc;
+        }
+        return F8_OK;
+    }
+    // independent sub-batches on internal streams: while one is in a layer's tail / epilogue phase the
+    // others keep the CUs busy.  Fork from and join to the caller's stream with events (no host sync).
+    if (!net->aux[0]) {
+        for (int k = 0; k < 4; ++k) {
+            hipError_t e = hipStreamCreateWithFlags(&net->aux[k], hipStreamNonBlocking);
+            if (e != hipSuccess) return hip_fail(e, "hipStreamCreate");
+        }
+        for (int k = 0; k < 5; ++k) {
+            hipError_t e = hipEventCreateWithFlags(&net->aux_ev[k], hipEventDisableTiming);
+            if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
+        }
+    }
+    (void)hipEventRecord(net->aux_ev[0], s);
+    for (int k = 0; k < parts; ++k) (void)hipStreamWaitEvent(net->aux[k], net->aux_ev[0], 0);
+    for (int i = 0; i < ns; ++i)
+        for (int p = 0; p < parts; ++p) {
+            rc = run_step(net, net->steps[i], input, output, cut[p], cut[p + 1] - cut[p], net->aux[p]);
+            if (rc) return rc;
+        }
+    for (int k = 0; k < parts; ++k) {
+        (void)hipEventRecord(net->aux_ev[1 + k], net->aux[k]);
+        (void)hipStreamWaitEvent(s, net->aux_ev[1 + k], 0);
     }
     return F8_OK;
 }
