@@ -134,8 +134,10 @@ def main():
             e = by_kernel.setdefault(k, {'ms': 0.0, 'bytes': 0.0, 'ops': 0.0, 'launches': 0})
             e['ms'] += ms[i]; e['bytes'] += nbytes; e['ops'] += nops; e['launches'] += 1
             rows.append((i, name, ms[i], nbytes, nops))
+        parts = net.num_parts(BS)       # each planned launch is issued once per sub-batch
         dom = max(by_kernel, key=lambda k: by_kernel[k]['ms'])
         d = by_kernel[dom]
+        d_launches = d['launches'] * parts
         achieved = d['bytes'] / (d['ms'] * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
@@ -160,12 +162,12 @@ def main():
             'config': {'workload': f'{spec.arch} fix_quant INT8 int_op_only forward, bs={BS} per GPU, 224x224, '
                                    f'NVIDIA-pretrained fraclens (normalize: True), int32 NCHW input resident in HBM',
                        'global_batch': BS * world, 'parallelism': f'dp{world} (batch shards + RCCL all-gather of logits)',
-                       'launches_per_step': n_l},
-            'roofline': {'bound': 'hbm', 'kernel': dom, 'launches_per_step': d['launches'],
+                       'launches_per_step': n_l * parts, 'sub_batches': parts},
+            'roofline': {'bound': 'hbm', 'kernel': dom, 'launches_per_step': d_launches,
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                         'avg_launch_us': round(1e3 * d['ms'] / d['launches'], 2),
-                         'alg_bytes_per_launch': round(d['bytes'] / d['launches'], 0),
+                         'avg_launch_us': round(1e3 * d['ms'] / d_launches, 2),
+                         'alg_bytes_per_launch': round(d['bytes'] / d_launches, 0),
                          'kernel_share_of_step': round(d['ms'] / total_ms, 3)},
             'whole_net': {'sum_kernel_ms': round(total_ms, 4),
                           'mfma_int8_frac_of_peak': round(value / world * R50_OPS_PER_IMG / 1e12 / MFMA_I8_PEAK_TOPS, 4),

@@ -58,6 +58,7 @@ SYMBOLS = [
     ('f8_net_output_fraclen', _i, [_vp]),
     ('f8_net_output_elems', _sz, [_vp]),
     ('f8_net_upload', _i, [_vp]),
+    ('f8_net_num_parts', _i, [_vp, _i]),
     ('f8_net_run', _i, [_vp, _vp, _vp, _i, _vp]),
     ('f8_net_run_profiled', _i, [_vp, _vp, _vp, _i, _vp, ctypes.POINTER(ctypes.c_float), _i]),
     ('f8_net_launch_info', _i, [_vp, _i, _i, ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_double),

@@ -41,6 +41,7 @@ struct ConvArgs {
     int32_t relu1;                         // ReLU after the residual add
     int32_t* out32;                        // NHWC int32 (stride coutP) or nullptr
     QuantOut q[2];
+    void* trace;                           // tuning builds (F8_TRACE) only; nullptr otherwise
 };
 
 // Depthwise 3x3 (groups == C), NHWC int8 in, VALU.

@@ -222,6 +222,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     // ---- residual operand: ALL of the wave tile's int32 rows are requested before anything else, so
     // their HBM latency overlaps the operand staging and the MFMAs (the in-place out32 store of the
     // same addresses comes later from the same lane).  I32T layout: 1 KB contiguous per access.
+#ifdef F8_TRACE
+    unsigned long long t_start = __builtin_readcyclecounter(), t_pro = 0, t_first = 0, t_loop = 0;
+#endif
     v4i rv[HAS_RES ? TCO : 1][HAS_RES ? TPX : 1][4];
     if (HAS_RES) {
 #pragma unroll
@@ -347,12 +350,18 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < nk) issue_stage(s);
+#ifdef F8_TRACE
+    t_pro = __builtin_readcyclecounter();
+#endif
 
     for (int ks = 0; ks < nk; ++ks) {
         // stages issued so far: min(nk, ks + STAGES - 1); stage ks must have landed
         const int issued = (ks + STAGES - 1 < nk) ? ks + STAGES - 1 : nk;
         wait_ahead(issued - 1 - ks);
         __builtin_amdgcn_s_barrier();     // all waves' DMA for stage ks landed; slot (ks-1)%STAGES is free
+#ifdef F8_TRACE
+        if (ks == 0) t_first = __builtin_readcyclecounter();
+#endif
 #ifndef F8_ABL_NO_DMA
         if (ks + STAGES - 1 < nk) issue_stage((ks + STAGES - 1) % STAGES);
 #endif
@@ -389,7 +398,21 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     }
 #endif
 
+#ifdef F8_TRACE
+    t_loop = __builtin_readcyclecounter();
+#endif
     conv_epilogue<BM, BN, WPX, WCO, HAS_RES, TCO, TPX>(a, acc, rv, m0, co0, wpx, wco, l31, lh);
+#ifdef F8_TRACE
+    if (a.trace && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end = __builtin_readcyclecounter();
+        unsigned long long* tp = (unsigned long long*)a.trace + (size_t)blockIdx.x * 8;
+        tp[0] = t_start; tp[1] = t_pro; tp[2] = t_first; tp[3] = t_loop; tp[4] = t_end;
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        tp[5] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -878,8 +901,42 @@ static hipError_t launch_conv_t(const ConvArgs& a, int grid, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_conv(const ConvArgs& a, const ConvTile& t, hipStream_t s) {
+#ifdef F8_TRACE
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+static unsigned long long* g_trace_buf = nullptr;
+static int g_trace_launch = 0;
+#endif
+
+hipError_t launch_conv(const ConvArgs& a0, const ConvTile& t, hipStream_t s) {
+    ConvArgs a = a0;
     const int grid = conv_grid(t, a.M, a.coutP);
+#ifdef F8_TRACE
+    static const int want = [] { const char* e = getenv("F8_TRACE_LAUNCH"); return e ? atoi(e) : -1; }();
+    const bool tracing = (g_trace_launch++ == want);
+    if (tracing) {
+        if (!g_trace_buf) (void)hipMalloc((void**)&g_trace_buf, (size_t)1 << 24);
+        (void)hipMemsetAsync(g_trace_buf, 0, (size_t)grid * 64, s);
+        a.trace = g_trace_buf;
+    }
+    struct Dump { bool on; int grid; hipStream_t s; ~Dump() {
+        if (!on) return;
+        (void)hipStreamSynchronize(s);
+        std::vector<unsigned long long> h((size_t)grid * 8);
+        (void)hipMemcpy(h.data(), g_trace_buf, h.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t1 = 0; double pro = 0, first = 0, loop = 0, epi = 0; int n = 0;
+        for (int i = 0; i < grid; ++i) { auto* p = &h[(size_t)i * 8]; if (!p[4]) continue; ++n; t0 = std::min(t0, p[0]); t1 = std::max(t1, p[4]);
+            pro += p[1] - p[0]; first += p[2] - p[1]; loop += p[3] - p[2]; epi += p[4] - p[3]; }
+        fprintf(stderr, "[trace] grid %d traced %d span %llu cyc | avg per WG: prologue %.0f  first-wait %.0f  loop %.0f  epilogue+drain %.0f  (cycles)\n",
+                grid, n, t1 - t0, pro / n, first / n, loop / n, epi / n);
+        // start-time histogram (in 1/8 of span)
+        int hist[8] = {0}, hend[8] = {0};
+        for (int i = 0; i < grid; ++i) { auto* p = &h[(size_t)i * 8]; if (!p[4]) continue; hist[std::min<unsigned long long>(7, (p[0] - t0) * 8 / (t1 - t0 + 1))]++; hend[std::min<unsigned long long>(7, (p[4] - t0) * 8 / (t1 - t0 + 1))]++; }
+        fprintf(stderr, "[trace] WG starts per eighth of span:"); for (int k = 0; k < 8; ++k) fprintf(stderr, " %d", hist[k]);
+        fprintf(stderr, " | ends:"); for (int k = 0; k < 8; ++k) fprintf(stderr, " %d", hend[k]); fprintf(stderr, "\n");
+    } } dump{tracing, grid, s};
+#endif
 #define F8_CASE(BM_, BN_, BK_, WPX_, WCO_) \
     if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_) return launch_conv_t<BM_, BN_, BK_, WPX_, WCO_>(a, grid, s);
     F8_CASE(128, 128, 128, 2, 2)

@@ -1020,6 +1020,17 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
         }
         return F8_OK;
     }
+    // F8_SPLIT_STREAMS=0: same launches, serialised on the caller's stream (used for rocprofv3 runs so
+    // that per-kernel durations are not inflated by the overlap of the two sub-batches)
+    static const int use_streams = [] { const char* e = getenv("F8_SPLIT_STREAMS"); return e ? atoi(e) : 1; }();
+    if (!use_streams) {
+        for (int p = 0; p < parts; ++p)
+            for (int i = 0; i < ns; ++i) {
+                rc = run_step(net, net->steps[i], input, output, cut[p], cut[p + 1] - cut[p], s);
+                if (rc) return rc;
+            }
+        return F8_OK;
+    }
     // independent sub-batches on internal streams: while one is in a layer's tail / epilogue phase the
     // others keep the CUs busy.  Fork from and join to the caller's stream with events (no host sync).
     if (!net->aux[0]) {
@@ -1044,6 +1055,12 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
         (void)hipStreamWaitEvent(s, net->aux_ev[1 + k], 0);
     }
     return F8_OK;
+}
+
+int f8_net_num_parts(const f8_net* net, int N) {
+    if (!net || !net->finalized) return fail(F8_ERR_STATE, "f8_net_num_parts: not finalized");
+    int cut[5];
+    return split_batch(net, N, cut);
 }
 
 int f8_net_run(f8_net* net, const int32_t* input, void* output, int N, void* stream) {

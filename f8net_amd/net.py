@@ -126,6 +126,9 @@ class F8Net:
         check(self._L.f8_net_launch_info(self._h, i, N, name, 256, ctypes.byref(b), ctypes.byref(o)))
         return name.value.decode(), b.value, o.value
 
+    def num_parts(self, N):
+        return check(self._L.f8_net_num_parts(self._h, int(N)))
+
     def launch_kernel(self, i):
         buf = ctypes.create_string_buffer(256)
         check(self._L.f8_net_launch_kernel(self._h, i, buf, 256))

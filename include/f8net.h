@@ -157,8 +157,13 @@ int f8_net_upload(f8_net* net);
  * output_dev: float32 or int32 [N, output_elems].  Asynchronous on `stream`. */
 int f8_net_run(f8_net* net, const int32_t* input_dev, void* output_dev, int N, void* stream);
 
-/* Same, bracketing every launch with HIP events on `stream`; ms[i] = duration of launch i
- * (i < f8_net_num_launches).  Synchronises the stream before returning. */
+/* f8_net_run cuts a batch of N into this many independent sub-batches (1..4) that it runs on
+ * internal streams forked from / joined to `stream` (no host synchronisation); every planned launch
+ * is therefore issued this many times per run, each over N / parts images. */
+int f8_net_num_parts(const f8_net* net, int N);
+
+/* Same, bracketing every launch with HIP events on `stream`; ms[i] = duration of launch i summed over
+ * the sub-batches, which run back to back on `stream` here (i < f8_net_num_launches).  Synchronises the stream before returning. */
 int f8_net_run_profiled(f8_net* net, const int32_t* input_dev, void* output_dev, int N,
                         void* stream, float* ms, int cap);
 

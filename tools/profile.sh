@@ -6,6 +6,8 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# serialise the two sub-batches: per-kernel durations then match bench.py's live (sequential, HIP-event) measurement
+export F8_SPLIT_STREAMS=0
 CMD="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $CMD > $OUT/pmc_fetch.log 2>&1
