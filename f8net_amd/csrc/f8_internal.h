@@ -88,6 +88,20 @@ struct OutArgs {                           // NHWC int32 -> NCHW int32 / float32
     void* out; int32_t as_float;
 };
 
+// One launch for a ResNet bottleneck identity block (f8_fused.hip).
+struct FusedArgs {
+    const int8_t* x8; uint32_t x_bytes;    // block input, int8 NHWC [N*H*W][C] in body.0's input format
+    const int32_t* xr;                     // block input, int32 I32T (residual operand)
+    const int8_t* w0; const int8_t* w2; const int8_t* w4; uint32_t w0_bytes, w2_bytes, w4_bytes;   // [MID][C], [MID][9][MID], [C][MID]
+    const int32_t* b0; const int32_t* b2; const int32_t* b4;                                        // offset-corrected biases
+    int32_t N, H, W, C, MID, R, tiles_per_img;
+    int32_t n1, lo1, hi1; uint32_t xor1;   // requant body.0 output -> body.2 input format
+    int32_t n2, lo2, hi2; uint32_t xor2;   // requant body.2 output -> body.4 input format
+    int32_t relu_a, relu_b;                // ReLU after body.0 / body.2
+    int32_t acc_shl, res_shl, relu1;       // residual join
+    int32_t* out32; QuantOut q[2];
+};
+
 struct ConvTile { int bm, bn, bk; };
 
 // Tile choice for a conv; returns false if no kernel instance fits (ck % bk).
@@ -95,6 +109,8 @@ bool pick_conv_tile(int M, int coutP, int ck, bool has_res, ConvTile* t);
 int  conv_grid(const ConvTile& t, int M, int coutP);
 
 hipError_t launch_conv(const ConvArgs& a, const ConvTile& t, hipStream_t s);
+hipError_t launch_fused_bottleneck(const FusedArgs& a, hipStream_t s);
+bool fused_bottleneck_supported(int C, int MID, int H, int W, int* R);
 hipError_t launch_dwconv(const DwArgs& a, hipStream_t s);
 hipError_t launch_maxpool(const PoolArgs& a, hipStream_t s);
 hipError_t launch_avgpool(const AvgArgs& a, hipStream_t s);

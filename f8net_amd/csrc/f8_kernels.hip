@@ -13,95 +13,11 @@
 // LDS untouched; 128*sum(w) over the taps that lie inside the image is folded into a per-border-class
 // bias table on the host (f8_net.cpp: pack_conv_weights).  Everything is mod 2^32, so the identity
 // is exact under wrap-around.
-#include "f8_internal.h"
+#include "f8_device.h"
 #include <cstdlib>
 
 namespace f8 {
 
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-static constexpr unsigned kOOB = 0x80000000u;   // voffset sentinel: beyond any buffer (< 2 GiB each)
-
-// clamp via v_med3_i32 (lo <= hi)
-__device__ __forceinline__ int med3i(int v, int lo, int hi) {
-    int r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
-    return r;
-}
-
-// int_op_only_fix_quant on one value; n, lo, hi are wave-uniform.
-// n > 0: q = (v + 2^(n-1)) >> n, with the LSB cleared on an exact tie (== ((r >> (n+1)) << 1)):
-//        tie <=> low n bits of r = v + 2^(n-1) are all zero.  Branch-free on purpose (a data-dependent
-//        `if` here makes hipcc emit an exec-mask branch per value).
-__device__ __forceinline__ int requant_shr(int v, int n, unsigned half, unsigned mask, int lo, int hi) {
-    const unsigned r = (unsigned)v + half;
-    const int keep = ((r & mask) == 0u) ? ~1 : ~0;
-    return med3i(((int)r >> n) & keep, lo, hi);
-}
-__device__ __forceinline__ int requant_shl(int v, int n, int lo, int hi) {   // n <= 0
-    return med3i((int)((unsigned)v << (-n)), lo, hi);
-}
-__device__ __forceinline__ int requant1(int v, int n, int lo, int hi) {
-    if (n > 0) {
-        const unsigned half = 1u << (n - 1);
-        return requant_shr(v, n, half, (half << 1) - 1u, lo, hi);
-    }
-    return requant_shl(v, n, lo, hi);
-}
-
-// q = n / d for a divisor known on the host: q = (t + ((n - t) >> sh1)) >> sh2, t = mulhi(n, magic)
-// (round-up method, exact for every 32-bit n; host: f8_net.cpp make_magic)
-__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic, int sh1, int sh2) {
-    const unsigned t = __umulhi(n, magic);
-    return (t + ((n - t) >> sh1)) >> sh2;
-}
-
-__device__ __forceinline__ unsigned pack4(int a, int b, int c, int d) {
-    return ((unsigned)a & 0xffu) | (((unsigned)b & 0xffu) << 8) | (((unsigned)c & 0xffu) << 16) |
-           ((unsigned)d << 24);
-}
-
-// int32 tensors live in an MFMA-fragment-tiled layout ("I32T"), not NHWC: blocks of 32 pixels x 32
-// channels (4 KB), inside a block the order is [g = (c%32)/8][lane = ((c/4)&1)*32 + m%32][c%4] — exactly
-// the accumulator layout of v_mfma_i32_32x32x32_i8 — so that a wave's residual read / int32 write of
-// one accumulator group is ONE contiguous 1 KB transaction (64 lanes x 16 B) instead of 32 scattered
-// 32-byte pieces.  m = linear pixel index n*P*Q + p*Q + q; rows are padded to a multiple of 32.
-// Returns the int index of channel c (c % 4 == 0 for vector access) of pixel m.
-__device__ __forceinline__ size_t i32t_index(int m, int c, int Cs) {
-    return ((size_t)(m >> 5) * (size_t)(Cs >> 5) + (size_t)(c >> 5)) * 1024u +
-           (size_t)(((((c & 31) >> 3) * 64 + ((c >> 2) & 1) * 32 + (m & 31)) << 2) + (c & 3));
-}
-
-__device__ __forceinline__ int clamp_sym31(int v) {   // clamp_(max=2^31-1, min=-(2^31-1))
-    return max(v, -2147483647);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Implicit-GEMM convolution on v_mfma_i32_32x32x32_i8.
-//
-// Block: 256 threads = 4 waves arranged WPX x WCO; tile BM pixels x BN couts, K step BK bytes.
-// MFMA roles: A = weights (rows = cout), B = activations (cols = pixels), so that a lane's 4
-// consecutive accumulator registers are 4 consecutive output channels of ONE pixel:
-//   D reg r of lane l: cout = (r&3) + 8*(r>>2) + 4*(l>>5), pixel = l&31.
-// Both operands are read from LDS as 16-byte K-contiguous chunks (lane l: row l&31, chunk
-// 2*kk + (l>>5)); whatever the hardware's internal k order is, it is the same for A and B, and the
-// integer sum over k is order-independent.
-//
-// LDS image: rows of BK bytes; 16-byte chunk c of row r is stored at chunk c ^ f(r),
-// f(r) = (r / (256/BK)) % (BK/16): the 16 lanes of a ds_read_b128 service group (distinct rows
-// mod 16, same logical chunk) then cover all 64 banks exactly once.
-//
-// Operand staging is LDS-direct (`buffer_load_dwordx4 ... lds`): each wave instruction deposits
-// 64 x 16 B = 1 KB into consecutive LDS slots, the swizzle is applied on the SOURCE side (lane ->
-// (row, chunk ^ f(row))), out-of-image taps and tile tails are fetched through the buffer range
-// check (the DMA writes zeros).  STAGES tiles are in flight in an LDS ring; the K loop has ONE
-// barrier per step and counted `s_waitcnt vmcnt(N)` so that later stages stay in flight across it.
-// No data is transformed in flight, which is why unsigned activations are STORED biased (x ^ 0x80,
-// i.e. x - 128 as int8) and the zero padding (biased 0 == real 128) is repaired by a per-border-class
-// bias: bias[class][cout] = b + 128 * sum over the class's in-image taps of w  (host: pack_conv_weights).
-// ---------------------------------------------------------------------------------------------
 // Fused epilogue of one BM x BN tile: class bias -> ReLU -> [align + residual + clamp -> ReLU] -> int32 (I32T)
 // and / or up to two requantised int8 (NHWC) outputs.  ReLUs are branch-free floors.
 template <int BM, int BN, int WPX, int WCO, bool HAS_RES, int TCO, int TPX>
@@ -177,8 +93,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, v16i (&acc)[TCO
         }
     }
 }
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
 template <int BM, int BN, int BK, int WPX, int WCO, bool HAS_PAD, bool HAS_RES, int STAGES>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {

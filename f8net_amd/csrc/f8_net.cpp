@@ -75,11 +75,14 @@ struct Node {
     int fused_into = -1;               // add: conv node that carries it
     int fused_add = -1;                // conv: add node carried
     bool stem = false, depthwise = false;
+    int absorbed_by = -1;              // conv swallowed by a fused bottleneck launch (node id of its last conv)
+    int fb_a = -1, fb_b = -1, fb_R = 0;  // last conv of a fused bottleneck: its first two convs, rows per tile
+    bool no_classes = false;           // pack a single bias class (the consumer kernel pads with real zeros itself)
     size_t w_off = 0, b_off = 0; int coutP = 0, ck = 0, ktot = 0;
     size_t rc_off = 0, cc_off = 0; int ncc = 0;      // border-class tables (0 = single class)
     ConvTile tile{};
 };
-enum StepKind { S_INPUT, S_CONV, S_DW, S_ADD, S_MAXPOOL, S_AVGPOOL, S_REQUANT, S_OUTPUT };
+enum StepKind { S_INPUT, S_CONV, S_DW, S_ADD, S_MAXPOOL, S_AVGPOOL, S_REQUANT, S_OUTPUT, S_FUSED };
 struct OutSel { int t = -1; int f32 = -1; int f8[2] = {-1, -1}; };
 struct Step {
     int kind; int node;
@@ -397,7 +400,7 @@ static void pack_conv_weights(f8_net* net, Node& nd, const Tensor& src, const Te
     // classes
     std::vector<uint32_t> rmasks, cmasks;
     std::vector<uint8_t> rowcls(dst.H, 0), colcls(dst.W, 0);
-    const bool classes = !d.input_signed && d.pad > 0 && !nd.stem;
+    const bool classes = !d.input_signed && d.pad > 0 && !nd.stem && !nd.no_classes;
     if (classes) {
         auto classify = [&](int n_out, int n_in, std::vector<uint32_t>& masks, std::vector<uint8_t>& cls) {
             for (int p = 0; p < n_out; ++p) {
@@ -503,6 +506,33 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         }
     }
 
+    // ---- 1b. whole-block fusion: 1x1(ReLU) -> 3x3 pad 1 (ReLU) -> 1x1 + residual with the block input,
+    //          all stride 1, intermediates read by nobody else  ->  one launch (f8_fused.hip)
+    static const int fuse_blocks = [] { const char* e = getenv("F8_FUSE_BLOCKS"); return e ? atoi(e) : 1; }();
+    for (int i = 0; fuse_blocks && i < nn; ++i) {
+        Node& c = ND[i];
+        if (c.kind != N_CONV || c.fused_add < 0 || c.cd.groups != 1 || c.cd.kernel != 1 || c.cd.stride != 1 || c.cd.pad != 0 || c.cd.relu) continue;
+        const Tensor& tb = T[c.a];
+        if (tb.consumers.size() != 1 || c.a == net->out_t || !c.cd.quant_input) continue;
+        Node& b = ND[tb.prod];
+        if (b.kind != N_CONV || b.fused_add >= 0 || b.cd.groups != 1 || b.cd.kernel != 3 || b.cd.stride != 1 || b.cd.pad != 1 || !b.cd.quant_input) continue;
+        const Tensor& ta = T[b.a];
+        if (ta.consumers.size() != 1 || b.a == net->out_t) continue;
+        Node& a0 = ND[ta.prod];
+        if (a0.kind != N_CONV || a0.fused_add >= 0 || a0.cd.groups != 1 || a0.cd.kernel != 1 || a0.cd.stride != 1 || a0.cd.pad != 0) continue;
+        const Node& ad = ND[c.fused_add];
+        const int other = (ad.a == c.out) ? ad.b : ad.a;
+        if (other != a0.a) continue;                          // residual operand must be the block input
+        const Tensor& x = T[a0.a];
+        if (ND[x.prod].kind == N_INPUT) continue;
+        const int C = a0.cd.cin, MID = a0.cd.cout;
+        if (c.cd.cout != C || b.cd.cin != MID || b.cd.cout != MID || c.cd.cin != MID) continue;
+        int R = 0;
+        if (!fused_bottleneck_supported(C, MID, x.H, x.W, &R)) continue;
+        a0.absorbed_by = i; b.absorbed_by = i; b.no_classes = true;
+        c.fb_a = ta.prod; c.fb_b = tb.prod; c.fb_R = R;
+    }
+
     // ---- 2. which forms does each tensor need?  (reverse order: consumers before producers)
     {
         Tensor& O = T[net->out_t];
@@ -518,6 +548,16 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 int n = 0;
                 consumer_format(s, nd.cd, &n, "finalize");
                 nd.depthwise = nd.cd.groups != 1;
+                if (nd.fb_a >= 0 || (nd.absorbed_by >= 0 && ND[nd.absorbed_by].fb_b == i)) {
+                    // source lives in LDS inside the fused launch: no HBM form.  (The block's first conv
+                    // still reads the block input from HBM and falls through to the generic case.)
+                    if (nd.fused_add >= 0) {
+                        const Node& ad = ND[nd.fused_add];
+                        const int other = (ad.a == nd.out) ? ad.b : ad.a;
+                        add_form(T[other], FORM_I32, 0, 0);
+                    }
+                    break;
+                }
                 nd.stem = !nd.depthwise && nd.cd.cin <= 4 && ND[s.prod].kind == N_INPUT && nd.cd.kernel <= 8 &&
                           s.consumers.size() == 1 && nd.a != net->out_t;
                 if (nd.stem) {
@@ -579,6 +619,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
     for (int i = 0; i < nn; ++i) {
         Node& nd = ND[i];
         if (nd.kind == N_ADD && nd.fused_into >= 0) continue;
+        if (nd.kind == N_CONV && nd.absorbed_by >= 0) continue;
         Step st; st.node = i;
         std::vector<int> extra;
         int out_t = nd.out;
@@ -600,6 +641,38 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 break;
             }
             case N_CONV: case N_LINEAR: {
+                if (nd.fb_a >= 0) {
+                    // ---- fused bottleneck block: nd is its last conv
+                    Node& na = ND[nd.fb_a]; Node& nb = ND[nd.fb_b];
+                    Tensor& x = T[na.a];
+                    st.kind = S_FUSED;
+                    st.src_t = na.a;
+                    int n0 = 0; consumer_format(x, na.cd, &n0, "finalize");
+                    st.src_f = find_form(x, FORM_I8, n0, na.cd.input_signed ? 1 : 0);
+                    pack_conv_weights(net, na, x, T[na.out]);
+                    pack_conv_weights(net, nb, T[nb.a], T[nb.out]);
+                    pack_conv_weights(net, nd, T[nd.a], T[nd.out]);
+                    const Node& ad = ND[nd.fused_add];
+                    st.res_t = na.a; st.res_f = find_form(x, FORM_I32, 0, 0);
+                    const int dfl = T[nd.out].fl - x.fl;
+                    st.acc_shl = dfl < 0 ? -dfl : 0; st.res_shl = dfl > 0 ? dfl : 0;
+                    st.relu1 = ad.relu;
+                    out_t = ad.out;
+                    select_outputs(net, out_t, &st.out, &extra);
+                    Tensor& o = T[out_t];
+                    const double px = (double)x.H * x.W;
+                    st.ops_per_img = 2.0 * px * ((double)na.cd.cin * na.cd.cout + 9.0 * nb.cd.cin * nb.cd.cout + (double)nd.cd.cin * nd.cd.cout);
+                    double b = px * x.Cs * (1 + 4);                                 // int8 input + int32 residual, once each
+                    if (st.out.f32 >= 0) b += px * o.Cs * 4;
+                    for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += px * o.Cs;
+                    st.bytes_per_img = b;
+                    st.bytes_const = (double)na.coutP * (na.ktot + 4) + (double)nb.coutP * (nb.ktot + 4) + (double)nd.coutP * (nd.ktot + 4);
+                    st.name = "fused_bottleneck_R" + std::to_string(nd.fb_R) + ":" + tname(net, na.out) + "+" + tname(net, nb.out) + "+" + tname(net, nd.out);
+                    char kb[160];
+                    snprintf(kb, sizeof kb, "f8::fused_bottleneck_kernel<%d, %d, %d, %d>", na.cd.cin, na.cd.cout, x.W, nd.fb_R);
+                    st.kernel = kb;
+                    break;
+                }
                 Tensor& s = T[nd.a];
                 st.kind = nd.depthwise ? S_DW : S_CONV;
                 st.src_t = nd.a;
@@ -759,7 +832,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 // in-place residual: out32 of a conv/add step may overwrite a residual operand that dies here
                 // (each thread reads its element before writing it; same NHWC geometry)
                 if (F.kind == FORM_I32 && (int)ti == st.out.t && (int)f == st.out.f32 && st.res_t >= 0 &&
-                    (st.kind == S_CONV || st.kind == S_ADD)) {
+                    (st.kind == S_CONV || st.kind == S_ADD || st.kind == S_FUSED)) {
                     Form& R = T[st.res_t].forms[st.res_f];
                     if (R.last == (int)si && R.bytes_per_img == F.bytes_per_img && R.kind == FORM_I32) {
                         F.off = R.off; R.last = -2;   // ownership moves to F
@@ -899,6 +972,31 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             if (st.res_t >= 0) { a.res = (const int32_t*)fp(T[st.res_t].forms[st.res_f]); a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1; }
             fill_out(&a.out32, a.q);
             e = launch_conv(a, nd.tile, s);
+            break;
+        }
+        case S_FUSED: {
+            const Node& na = net->nodes[nd.fb_a]; const Node& nb = net->nodes[nd.fb_b];
+            const Tensor& x = T[st.src_t]; const Form& xF = x.forms[st.src_f];
+            FusedArgs a{};
+            a.x8 = (const int8_t*)fp(xF); a.x_bytes = (uint32_t)(xF.bytes_per_img * N);
+            a.xr = (const int32_t*)fp(T[st.res_t].forms[st.res_f]);
+            a.w0 = (const int8_t*)(net->d_w + na.w_off); a.w0_bytes = (uint32_t)((size_t)na.coutP * na.ktot);
+            a.w2 = (const int8_t*)(net->d_w + nb.w_off); a.w2_bytes = (uint32_t)((size_t)nb.coutP * nb.ktot);
+            a.w4 = (const int8_t*)(net->d_w + nd.w_off); a.w4_bytes = (uint32_t)((size_t)nd.coutP * nd.ktot);
+            a.b0 = (const int32_t*)(net->d_w + na.b_off); a.b2 = (const int32_t*)(net->d_w + nb.b_off); a.b4 = (const int32_t*)(net->d_w + nd.b_off);
+            a.N = N; a.H = x.H; a.W = x.W; a.C = na.cd.cin; a.MID = na.cd.cout; a.R = nd.fb_R;
+            a.tiles_per_img = (x.H + nd.fb_R - 1) / nd.fb_R;
+            auto fmt = [&](const Node& cons, const Tensor& src, int32_t* n, int32_t* lo, int32_t* hi, uint32_t* x_or) {
+                int nn = 0; consumer_format(src, cons.cd, &nn, "run");
+                *n = nn; *lo = cons.cd.input_signed ? -127 : 0; *hi = cons.cd.input_signed ? 127 : 255;
+                *x_or = cons.cd.input_signed ? 0u : 0x80808080u;
+            };
+            fmt(nb, T[nb.a], &a.n1, &a.lo1, &a.hi1, &a.xor1);
+            fmt(nd, T[nd.a], &a.n2, &a.lo2, &a.hi2, &a.xor2);
+            a.relu_a = na.cd.relu; a.relu_b = nb.cd.relu;
+            a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1;
+            fill_out(&a.out32, a.q);
+            e = launch_fused_bottleneck(a, s);
             break;
         }
         case S_DW: {
