@@ -10,7 +10,8 @@
 // Why fuse: unfused, the three convs are three launches whose small ones are latency / issue bound
 // while the residual-carrying one is HBM bound; fused, the MFMA work of all three hides under the
 // residual stream of the block, the two int8 intermediates never touch HBM and two launches per block
-// disappear.
+// disappear.  The block stays HBM-bound: its floor is (int8 in + int32 residual in + int32/int8 out)
+// / HBM bandwidth.
 //
 // Work unit: R output rows x full width W of ONE image (so only a vertical halo exists).
 //   P1  mid1 for rows p0-1 .. p0+R (halo rows recomputed), GEMM [(R+2)*W px] x [MID] x K=C,
@@ -19,48 +20,61 @@
 //       biased zero, so the 3x3 needs no border classes.
 //   P2  3x3 from the patch (tap = constant LDS offset), weights streamed; result -> LDS mid2.
 //   P3  1x1 MID->C in chunks of 64 output channels: weights streamed, residual chunk prefetched one
-//       chunk ahead, fused epilogue (align, add, clamp, ReLU, int32 + int8 stores).
-// 256 threads = 4 waves; MFMA v_mfma_i32_32x32x32_i8 with A = weights, B = activations as in
-// conv_igemm_kernel; all LDS rows are XOR-swizzled per 16-byte chunk (see f8_kernels.hip).
+//       chunk ahead (the first one before P2's epilogue), fused epilogue (align, add, clamp, ReLU,
+//       int32 + int8 stores).
+// 512 threads = 8 waves in a 4 (pixel tiles) x 2 (channel tiles) grid; MFMA v_mfma_i32_32x32x32_i8 with
+// A = weights, B = activations as in conv_igemm_kernel; all LDS rows are XOR-swizzled per 16-byte
+// chunk (see f8_kernels.hip).  LDS is dynamic (up to ~120 KB for MID = 256).
 #include "f8_device.h"
+#include <cstdlib>
 
 namespace f8 {
 
-template <int ROWB> struct Swz {                       // rows of ROWB bytes (64 or 128)
-    static constexpr int CPR = ROWB / 16, RPB = 256 / ROWB;
-    static __device__ __forceinline__ int f(int row) { return (row / RPB) % CPR; }
+template <int ROWB> struct Swz {                       // rows of ROWB bytes; LDS bank rows are 256 bytes
+    static constexpr int CPR = ROWB / 16;
+    static __device__ __forceinline__ int f(int row) {
+        if (ROWB >= 256) return row % 16;               // a row spans whole bank rows: spread rows over the 16 slots
+        return (row / (256 / ROWB)) % CPR;
+    }
     static __device__ __forceinline__ unsigned off(int row, int chunk) { return (unsigned)(row * ROWB + ((chunk ^ f(row)) << 4)); }
 };
 
 template <int C, int MID, int W, int R>
-__global__ void __launch_bounds__(256) fused_bottleneck_kernel(const FusedArgs a) {
-    static_assert(MID == 64, "instantiated for MID = 64 (stage 0); MID = 128 needs dynamic LDS");
-    constexpr int PW = W + 2, PR = R + 2;
-    constexpr int PATCH_PX = PR * PW;
-    constexpr int P1_PX = PR * W;                        // mid1 pixels computed (no halo columns)
-    constexpr int NP1 = (P1_PX + 31) / 32;               // px tiles of P1
+struct FusedCfg {
+    static constexpr int PW = W + 2, PR = R + 2;
+    static constexpr int PATCH_PX = PR * PW;
+    static constexpr int P1_PX = PR * W;
+    static constexpr int NP1 = (P1_PX + 31) / 32;
+    static constexpr int OUT_PX = R * W;
+    static constexpr int NPO = (OUT_PX + 31) / 32;
+    static constexpr int CM = MID / 32;
+    static constexpr int X1_ROWS = NP1 * 32;
+    static constexpr int X1_BYTES = X1_ROWS * 64, W_BYTES = MID * 64;
+    static constexpr int RING = X1_BYTES + W_BYTES;
+    static constexpr int PATCH_BYTES = (PATCH_PX * MID + 255) / 256 * 256, MID2_BYTES = 4 * 32 * MID;
+    static constexpr int LDS_BYTES = PATCH_BYTES + MID2_BYTES + 2 * RING;
+};
+
+template <int C, int MID, int W, int R>
+__global__ void __launch_bounds__(512) fused_bottleneck_kernel(const FusedArgs a) {
+    using Cfg = FusedCfg<C, MID, W, R>;
+    constexpr int PW = Cfg::PW;
+    constexpr int P1_PX = Cfg::P1_PX, NP1 = Cfg::NP1, OUT_PX = Cfg::OUT_PX, NPO = Cfg::NPO, CM = Cfg::CM;
+    static_assert(NPO <= 4 && NP1 <= 8, "4 pixel-tile groups");
+    static_assert(CM % 2 == 0, "2 channel-tile groups");
     constexpr int NP1W = (NP1 + 3) / 4;                  // px tiles per wave in P1
-    constexpr int OUT_PX = R * W;
-    constexpr int NPO = (OUT_PX + 31) / 32;
-    static_assert(NPO == 4, "one output px tile per wave");
-    constexpr int CM = MID / 32;                         // co tiles of mid
+    constexpr int CMW = CM / 2;                          // co tiles per wave in P1 / P2
     constexpr int NK1 = C / 64;                          // P1 K steps
-    constexpr int NK2 = 9 * (MID / 64);                  // P2 K steps
+    constexpr int NK2 = 9 * (MID / 64);                  // P2 K steps (tap-major, 64-byte channel chunks)
     constexpr int NC3 = C / 64;                          // P3 chunks of 64 output channels
     constexpr int KK3 = MID / 32;
-    constexpr int X1_ROWS = NP1 * 32;
-    constexpr int X1_BYTES = X1_ROWS * 64, W_BYTES = MID * 64;
-    constexpr int RING = X1_BYTES + W_BYTES;             // largest stage (P1); P2/P3 stages use its first W_BYTES.. bytes
-    constexpr int PATCH_BYTES = PATCH_PX * MID, MID2_BYTES = NPO * 32 * MID;
-    static_assert(PATCH_BYTES % 16 == 0, "alignment");
-    static_assert(PATCH_BYTES + MID2_BYTES + 2 * RING <= 65536, "static LDS");
-    constexpr int XS1 = X1_ROWS * 4;                     // 16-byte slots of the P1 X tile
-    constexpr int XL1 = (XS1 + 255) / 256;
-    constexpr int WS = MID * 4, WL = (WS + 255) / 256;   // W0 / W2 tile slots (rows of 64 B)
-    constexpr int W4S = 64 * (MID / 16), W4L = (W4S + 255) / 256;
-    static_assert(WS == 256 && W4S == 256, "one weight slot per thread");
+    constexpr int X1_BYTES = Cfg::X1_BYTES, RING = Cfg::RING;
+    constexpr int PATCH_BYTES = Cfg::PATCH_BYTES, MID2_BYTES = Cfg::MID2_BYTES;
+    constexpr int XS1 = Cfg::X1_ROWS * 4, XL1 = (XS1 + 511) / 512;     // P1 X tile slots
+    constexpr int WS = MID * 4, WL = (WS + 511) / 512;                  // W0 / W2 tile slots (rows of 64 B); the W4 tile has the same count
+    static_assert(NC3 % 2 == 0, "chunk loop is unrolled by two (residual ping-pong)");
 
-    __shared__ __attribute__((aligned(16))) char lds[PATCH_BYTES + MID2_BYTES + 2 * RING];
+    extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const patch = lds;
     char* const mid2 = lds + PATCH_BYTES;
     char* const ring = lds + PATCH_BYTES + MID2_BYTES;
@@ -70,7 +84,8 @@ __global__ void __launch_bounds__(256) fused_bottleneck_kernel(const FusedArgs a
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 3;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;
+    const int wa = wave >> 1, wb = wave & 1;             // pixel-tile group (0..3), channel-tile group (0..1)
     const int l31 = lane & 31, lh = lane >> 5;
 
     // ---- tile: XCD-aware order (consecutive tiles = vertically adjacent row groups share halo rows in L2)
@@ -94,57 +109,75 @@ __global__ void __launch_bounds__(256) fused_bottleneck_kernel(const FusedArgs a
     {
         const unsigned z = a.xor1;
         const v4i zv = {(int)z, (int)z, (int)z, (int)z};
-        for (int o = tid * 16; o < PATCH_BYTES; o += 256 * 16) *(v4i*)(patch + o) = zv;
+        for (int o = tid * 16; o < PATCH_BYTES; o += 512 * 16) *(v4i*)(patch + o) = zv;
     }
 
-    // ---- P1 gather descriptors
+    // ---- gather descriptors
     unsigned xb1[XL1];
 #pragma unroll
     for (int i = 0; i < XL1; ++i) {
-        const int idx = tid + i * 256;
+        const int idx = tid + i * 512;
         const int row = idx >> 2, chunk = (idx & 3) ^ S64::f(row);
         const int pr = row / W;                          // patch row of this P1 pixel
         const int hrow = p0 - 1 + pr;
         const bool ok = idx < XS1 && row < P1_PX && hrow >= 0 && hrow < a.H;
         xb1[i] = ok ? (unsigned)((gp1 + row) * C + chunk * 16) : kOOB;
     }
-    const int wrow = tid >> 2, wchunk = (tid & 3) ^ S64::f(wrow);     // weight tile slot (rows of 64 B)
-    const unsigned w0b = (unsigned)(wrow * C + wchunk * 16);
-    const unsigned w2b = (unsigned)(wrow * (9 * MID) + wchunk * 16);
-    const int w4row = tid / (MID / 16), w4chunk = (tid % (MID / 16)) ^ SM::f(w4row);
-    const unsigned w4b = (unsigned)(w4row * MID + w4chunk * 16);
+    unsigned w0b[WL], w2b[WL], w4b[WL];
+#pragma unroll
+    for (int j = 0; j < WL; ++j) {
+        const int idx = tid + j * 512;
+        const int row = idx >> 2, chunk = (idx & 3) ^ S64::f(row);             // rows of 64 B (W0 / W2 tiles)
+        w0b[j] = (unsigned)(row * C + chunk * 16);
+        w2b[j] = (unsigned)(row * (9 * MID) + chunk * 16);
+        const int r4 = idx / (MID / 16), c4 = (idx % (MID / 16)) ^ SM::f(r4);  // rows of MID B (W4 tile)
+        w4b[j] = (unsigned)(r4 * MID + c4 * 16);
+    }
 
     auto issue_p1 = [&](int ks, int slot) {
         char* base = ring + slot * RING;
 #pragma unroll
         for (int i = 0; i < XL1; ++i) {
             const unsigned off = xb1[i] == kOOB ? kOOB : xb1[i] + (unsigned)(ks * 64);
-            if ((i * 256 + wave * 64) < XS1)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(base + i * 4096 + wave * 1024), 16, off, 0, 0, 0);
+            if ((i * 512 + wave * 64) < XS1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(base + i * 8192 + wave * 1024), 16, off, 0, 0, 0);
         }
-        const unsigned woff = w0b + (unsigned)(ks * 64);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw0, (__attribute__((address_space(3))) void*)(base + X1_BYTES + wave * 1024), 16, woff, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < WL; ++j) {
+            const unsigned woff = w0b[j] + (unsigned)(ks * 64);
+            if ((j * 512 + wave * 64) < WS)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw0, (__attribute__((address_space(3))) void*)(base + X1_BYTES + j * 8192 + wave * 1024), 16, woff, 0, 0, 0);
+        }
     };
-    auto issue_w2 = [&](int j, int slot) {               // step j: tap j / (MID/64), 64-byte chunk j % (MID/64)
+    auto issue_w2 = [&](int j2, int slot) {              // step j2: bytes [j2*64, j2*64+64) of every W2 row (tap-major K)
         char* base = ring + slot * RING;
-        const unsigned woff = w2b + (unsigned)(j * 64);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw2, (__attribute__((address_space(3))) void*)(base + wave * 1024), 16, woff, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < WL; ++j) {
+            const unsigned woff = w2b[j] + (unsigned)(j2 * 64);
+            if ((j * 512 + wave * 64) < WS)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw2, (__attribute__((address_space(3))) void*)(base + j * 8192 + wave * 1024), 16, woff, 0, 0, 0);
+        }
     };
     auto issue_w4 = [&](int c, int slot) {               // 64 output channels x MID bytes
         char* base = ring + slot * RING;
-        const unsigned woff = w4b + (unsigned)(c * 64 * MID);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw4, (__attribute__((address_space(3))) void*)(base + wave * 1024), 16, woff, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < WL; ++j) {
+            const unsigned woff = w4b[j] + (unsigned)(c * 64 * MID);
+            if ((j * 512 + wave * 64) < WS)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw4, (__attribute__((address_space(3))) void*)(base + j * 8192 + wave * 1024), 16, woff, 0, 0, 0);
+        }
     };
 
     // =========================================================================================
     // P1: mid1 = requant(relu(W0 . x8 + b0)) on (R+2) x W pixels  ->  patch
+    //     wave (wa, wb): px tiles {wa, wa+4}, co tiles {wb*CMW .. wb*CMW+CMW-1}
     // =========================================================================================
     {
-        v16i acc[NP1W][CM];
+        v16i acc[NP1W][CMW];
 #pragma unroll
         for (int j = 0; j < NP1W; ++j)
 #pragma unroll
-            for (int i = 0; i < CM; ++i)
+            for (int i = 0; i < CMW; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][i][r] = 0;
         unsigned cof[2];
@@ -160,20 +193,20 @@ __global__ void __launch_bounds__(256) fused_bottleneck_kernel(const FusedArgs a
             const char* base = ring + (ks & 1) * RING;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                v4i wf[CM], xf[NP1W];
+                v4i wf[CMW], xf[NP1W];
 #pragma unroll
-                for (int i = 0; i < CM; ++i) wf[i] = *(const v4i*)(base + X1_BYTES + (i * 32 + l31) * 64 + cof[kk]);
+                for (int i = 0; i < CMW; ++i) wf[i] = *(const v4i*)(base + X1_BYTES + ((wb * CMW + i) * 32 + l31) * 64 + cof[kk]);
 #pragma unroll
                 for (int j = 0; j < NP1W; ++j) {
-                    const int pt = wave + 4 * j;
+                    const int pt = wa + 4 * j;
                     if (pt < NP1) xf[j] = *(const v4i*)(base + (pt * 32 + l31) * 64 + cof[kk]);
                 }
 #pragma unroll
                 for (int j = 0; j < NP1W; ++j) {
-                    const int pt = wave + 4 * j;
+                    const int pt = wa + 4 * j;
                     if (pt < NP1)
 #pragma unroll
-                        for (int i = 0; i < CM; ++i) acc[j][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xf[j], acc[j][i], 0, 0, 0);
+                        for (int i = 0; i < CMW; ++i) acc[j][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xf[j], acc[j][i], 0, 0, 0);
                 }
             }
         }
@@ -184,7 +217,7 @@ __global__ void __launch_bounds__(256) fused_bottleneck_kernel(const FusedArgs a
         const int floor0 = a.relu_a ? 0 : INT32_MIN;
 #pragma unroll
         for (int j = 0; j < NP1W; ++j) {
-            const int pt = wave + 4 * j;
+            const int pt = wa + 4 * j;
             if (pt >= NP1) continue;                     // wave-uniform
             const int pix = pt * 32 + l31;
             const int pr = pix / W, pc = pix - pr * W;
@@ -192,11 +225,12 @@ __global__ void __launch_bounds__(256) fused_bottleneck_kernel(const FusedArgs a
             const bool ok = pix < P1_PX && hrow >= 0 && hrow < a.H;
             const int ppx = pr * PW + pc + 1;
 #pragma unroll
-            for (int i = 0; i < CM; ++i) {
+            for (int i = 0; i < CMW; ++i) {
+                const int cot = (wb * CMW + i) * 32;
                 unsigned d[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const v4i bv = *(const v4i*)(a.b0 + i * 32 + 8 * g + 4 * lh);
+                    const v4i bv = *(const v4i*)(a.b0 + cot + 8 * g + 4 * lh);
                     int y[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) y[e] = requant1(max((int)((unsigned)acc[j][i][4 * g + e] + (unsigned)bv[e]), floor0), a.n1, a.lo1, a.hi1);
@@ -206,21 +240,31 @@ __global__ void __launch_bounds__(256) fused_bottleneck_kernel(const FusedArgs a
                 auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
                 if (ok) {
                     v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
-                    *(v4i*)(patch + SM::off(ppx, i * 2 + lh)) = o;
+                    *(v4i*)(patch + SM::off(ppx, cot / 16 + lh)) = o;
                 }
             }
         }
     }
 
+    // ---- output pixel of this lane (px tile wa) and the residual stream of its (px tile, co tile wb)
+    const int opix = wa * 32 + l31;
+    const bool opix_ok = opix < rows_out * W;
+    const int m = m_tile + opix;                         // global output pixel
+    const int mc = opix_ok ? m : m_tile;                 // padding lanes: any valid pixel (loads only)
+    v4i rv[4], rn[4];                                    // residual of the current / next 64-channel chunk (this wave: 32 ch)
+    auto load_res = [&](v4i (&dst)[4], int c) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[g] = *(const v4i*)(a.xr + i32t_index(mc, c * 64 + wb * 32 + 8 * g + 4 * lh, C));
+    };
+
     // =========================================================================================
     // P2: mid2 = requant(relu(conv3x3(mid1) + b2)) on R x W pixels  ->  mid2
+    //     wave (wa, wb): px tile wa, co tiles {wb*CMW ..}
     // =========================================================================================
-    const int opix = wave * 32 + l31;                    // this lane's output pixel in the tile
-    const bool opix_ok = opix < rows_out * W;
     {
-        v16i acc[CM];
+        v16i acc[CMW];
 #pragma unroll
-        for (int i = 0; i < CM; ++i)
+        for (int i = 0; i < CMW; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0;
         const int oc = opix < OUT_PX ? opix : OUT_PX - 1;   // padding lanes read a valid pixel, result unused
@@ -231,7 +275,8 @@ __global__ void __launch_bounds__(256) fused_bottleneck_kernel(const FusedArgs a
         for (int kk = 0; kk < 2; ++kk) cof[kk] = (unsigned)(((kk * 2 + lh) ^ S64::f(l31)) << 4);
 
         constexpr int S0 = NK1 & 1;                      // ring slot of W2 step 0
-        int tr = 0, ts = 0;
+        constexpr int CH = MID / 64;                     // 64-byte channel chunks per tap
+        int tr = 0, ts = 0, tc = 0;
         for (int j = 0; j < NK2; ++j) {
             wait_vmcnt<0>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -241,26 +286,28 @@ __global__ void __launch_bounds__(256) fused_bottleneck_kernel(const FusedArgs a
             const int ppx = bpx + tr * PW + ts;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                const v4i xf = *(const v4i*)(patch + SM::off(ppx, kk * 2 + lh));
+                const v4i xf = *(const v4i*)(patch + SM::off(ppx, tc * 4 + kk * 2 + lh));
 #pragma unroll
-                for (int i = 0; i < CM; ++i) {
-                    const v4i wf = *(const v4i*)(base + (i * 32 + l31) * 64 + cof[kk]);
+                for (int i = 0; i < CMW; ++i) {
+                    const v4i wf = *(const v4i*)(base + ((wb * CMW + i) * 32 + l31) * 64 + cof[kk]);
                     acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, xf, acc[i], 0, 0, 0);
                 }
             }
-            if (++ts == 3) { ts = 0; ++tr; }
+            if (++tc == CH) { tc = 0; if (++ts == 3) { ts = 0; ++tr; } }
         }
         asm volatile("" ::: "memory");
         issue_w4(0, (S0 + NK2) & 1);
-        asm volatile("" ::: "memory");   // the bias / residual loads below must stay behind this DMA (counted wait in P3)
+        asm volatile("" ::: "memory");   // the loads below must stay behind this DMA (counted wait in P3)
+        load_res(rv, 0);
 
         const int floor0 = a.relu_b ? 0 : INT32_MIN;
 #pragma unroll
-        for (int i = 0; i < CM; ++i) {
+        for (int i = 0; i < CMW; ++i) {
+            const int cot = (wb * CMW + i) * 32;
             unsigned d[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const v4i bv = *(const v4i*)(a.b2 + i * 32 + 8 * g + 4 * lh);
+                const v4i bv = *(const v4i*)(a.b2 + cot + 8 * g + 4 * lh);
                 int y[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = requant1(max((int)((unsigned)acc[i][4 * g + e] + (unsigned)bv[e]), floor0), a.n2, a.lo2, a.hi2);
@@ -269,101 +316,77 @@ __global__ void __launch_bounds__(256) fused_bottleneck_kernel(const FusedArgs a
             auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
             auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
             v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
-            *(v4i*)(mid2 + SM::off(opix, i * 2 + lh)) = o;
+            *(v4i*)(mid2 + SM::off(opix, cot / 16 + lh)) = o;
         }
     }
 
     // =========================================================================================
     // P3: y = clamp((W4 . mid2 + b4) << sa + (x << sr)) [ReLU]  ->  y32 (I32T) / int8 copies
+    //     wave (wa, wb): px tile wa, co tile wb of each 64-channel chunk
     // =========================================================================================
     {
         constexpr int S0 = (NK1 + NK2) & 1;
-        const int m = m_tile + opix;                     // global output pixel of this lane
-        const int mc = opix_ok ? m : m_tile;             // padding lanes: any valid pixel (loads only)
         const int floor1 = a.relu1 ? 0 : INT32_MIN;
-        unsigned cofm[KK3];
-#pragma unroll
-        for (int kk = 0; kk < KK3; ++kk) cofm[kk] = (unsigned)(((kk * 2 + lh) ^ SM::f(l31)) << 4);
         v4i xf[KK3];                                     // this wave's mid2 fragments are chunk-invariant: read once
-        // (read after the first barrier below)
-        v4i rv[2][4], rn[2][4];
-        auto load_res = [&](v4i (&dst)[2][4], int c) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) dst[i][g] = *(const v4i*)(a.xr + i32t_index(mc, c * 64 + i * 32 + 8 * g + 4 * lh, C));
-        };
-        load_res(rv, 0);
         // one chunk of 64 output channels; `cur` holds this chunk's residual, `nxt` receives the next one's
-        auto chunk = [&](int c, v4i (&cur)[2][4], v4i (&nxt)[2][4]) {
-            // W4 chunk c landed?  Everything issued after it (>= 8 loads: residual prefetch, bias, plus the
-            // previous chunk's stores) may stay in flight; all of it is newer than the DMA, so the count is safe.
-            wait_vmcnt<8>();
+        auto chunk = [&](int c, v4i (&cur)[4], v4i (&nxt)[4]) {
+            // W4 chunk c landed?  Everything issued after it (>= 4 loads: the residual prefetch, fenced behind the
+            // DMA; plus bias loads and the previous chunk's stores) may stay in flight: all of it is newer.
+            wait_vmcnt<4>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                // chunk 0: also "mid2 complete"
-            // compiler fences: the counted wait of the NEXT chunk assumes that at least the 8 residual loads below are issued
-            // AFTER this DMA in program order; without the fences hipcc is free to hoist those loads above it
             asm volatile("" ::: "memory");
             if (c + 1 < NC3) issue_w4(c + 1, (S0 + c + 1) & 1);
             asm volatile("" ::: "memory");
+            load_res(nxt, c + 1 < NC3 ? c + 1 : c);      // always 4 loads per wave: the counted wait relies on it
             const char* base = ring + ((S0 + c) & 1) * RING;
             if (c == 0) {
 #pragma unroll
-                for (int kk = 0; kk < KK3; ++kk) xf[kk] = *(const v4i*)(mid2 + (wave * 32 + l31) * MID + cofm[kk]);
+                for (int kk = 0; kk < KK3; ++kk) xf[kk] = *(const v4i*)(mid2 + SM::off(opix, kk * 2 + lh));
             }
-            v16i acc[2];
+            v16i acc;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int r = 0; r < 16; ++r) acc[r] = 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] = 0;
+            for (int kk = 0; kk < KK3; ++kk) {
+                const v4i wf = *(const v4i*)(base + SM::off(wb * 32 + l31, kk * 2 + lh));
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, xf[kk], acc, 0, 0, 0);
+            }
+            const int cot = c * 64 + wb * 32;
+            int y[4][4];
 #pragma unroll
-            for (int kk = 0; kk < KK3; ++kk)
+            for (int g = 0; g < 4; ++g) {
+                const v4i bv = *(const v4i*)(a.b4 + cot + 8 * g + 4 * lh);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const v4i wf = *(const v4i*)(base + (i * 32 + l31) * MID + cofm[kk]);
-                    acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, xf[kk], acc[i], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned v = (unsigned)acc[4 * g + e] + (unsigned)bv[e];
+                    const unsigned s = (v << a.acc_shl) + ((unsigned)cur[g][e] << a.res_shl);
+                    y[g][e] = max(clamp_sym31((int)s), floor1);
                 }
-            // prefetch the next chunk's residual (always 8 loads per wave: the counted wait relies on it)
-            load_res(nxt, c + 1 < NC3 ? c + 1 : c);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int cot = c * 64 + i * 32;
-                int y[4][4];
+            }
+            if (a.out32 && opix_ok) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const v4i bv = *(const v4i*)(a.b4 + cot + 8 * g + 4 * lh);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const unsigned v = (unsigned)acc[i][4 * g + e] + (unsigned)bv[e];
-                        const unsigned s = (v << a.acc_shl) + ((unsigned)cur[i][g][e] << a.res_shl);
-                        y[g][e] = max(clamp_sym31((int)s), floor1);
-                    }
+                    v4i o = {y[g][0], y[g][1], y[g][2], y[g][3]};
+                    *(v4i*)(a.out32 + i32t_index(m, cot + 8 * g + 4 * lh, C)) = o;
                 }
-                if (a.out32 && opix_ok) {
+            }
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        v4i o = {y[g][0], y[g][1], y[g][2], y[g][3]};
-                        *(v4i*)(a.out32 + i32t_index(m, cot + 8 * g + 4 * lh, C)) = o;
-                    }
-                }
+            for (int k = 0; k < 2; ++k) {
+                if (!a.q[k].ptr) continue;
+                unsigned d[4];
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    if (!a.q[k].ptr) continue;
-                    unsigned d[4];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        d[g] = pack4(requant1(y[g][0], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(y[g][1], a.q[k].n, a.q[k].lo, a.q[k].hi),
-                                     requant1(y[g][2], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(y[g][3], a.q[k].n, a.q[k].lo, a.q[k].hi)) ^ a.q[k].bias_xor;
-                    auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
-                    auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
-                    if (opix_ok) {
-                        v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
-                        *(v4i*)(a.q[k].ptr + (size_t)m * C + cot + 16 * lh) = o;
-                    }
+                for (int g = 0; g < 4; ++g)
+                    d[g] = pack4(requant1(y[g][0], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(y[g][1], a.q[k].n, a.q[k].lo, a.q[k].hi),
+                                 requant1(y[g][2], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(y[g][3], a.q[k].n, a.q[k].lo, a.q[k].hi)) ^ a.q[k].bias_xor;
+                auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+                auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+                if (opix_ok) {
+                    v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
+                    *(v4i*)(a.q[k].ptr + (size_t)m * C + cot + 16 * lh) = o;
                 }
             }
         };
-        static_assert(NC3 % 2 == 0, "chunk loop is unrolled by two (residual ping-pong)");
         for (int c = 0; c < NC3; c += 2) {
             chunk(c, rv, rn);
             chunk(c + 1, rn, rv);
@@ -371,17 +394,33 @@ __global__ void __launch_bounds__(256) fused_bottleneck_kernel(const FusedArgs a
     }
 }
 
-hipError_t launch_fused_bottleneck(const FusedArgs& a, hipStream_t s) {
-    const int grid = a.N * a.tiles_per_img;
-    if (a.C == 256 && a.MID == 64 && a.W == 56 && a.R == 2) {
-        hipLaunchKernelGGL((fused_bottleneck_kernel<256, 64, 56, 2>), dim3(grid), dim3(256), 0, s, a);
-        return hipGetLastError();
+template <int C, int MID, int W, int R>
+static hipError_t launch_fused_t(const FusedArgs& a, hipStream_t s) {
+    using Cfg = FusedCfg<C, MID, W, R>;
+    static bool attr_set = false;
+    if (!attr_set) {   // dynamic LDS above 64 KB must be opted into once per kernel
+        hipError_t e = hipFuncSetAttribute((const void*)fused_bottleneck_kernel<C, MID, W, R>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
     }
+    const int grid = a.N * a.tiles_per_img;
+    hipLaunchKernelGGL((fused_bottleneck_kernel<C, MID, W, R>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_fused_bottleneck(const FusedArgs& a, hipStream_t s) {
+    if (a.C == 256 && a.MID == 64 && a.W == 56 && a.R == 2) return launch_fused_t<256, 64, 56, 2>(a, s);
+    if (a.C == 512 && a.MID == 128 && a.W == 28 && a.R == 4) return launch_fused_t<512, 128, 28, 4>(a, s);
+    if (a.C == 1024 && a.MID == 256 && a.W == 14 && a.R == 7) return launch_fused_t<1024, 256, 14, 7>(a, s);
     return hipErrorInvalidValue;
 }
 
 bool fused_bottleneck_supported(int C, int MID, int H, int W, int* R) {
-    if (C == 256 && MID == 64 && W == 56 && H % 2 == 0) { *R = 2; return true; }
+    static const int mask = [] { const char* e = getenv("F8_FUSE_STAGES"); return e ? atoi(e) : 3; }();   // bit s = stage s; measured (100-step A/B, bs 128):
+    // none 55.5k, stage 0 55.6k, stages 0+1 56.0k, +stage 2 52.5k img/s (256 tiles of 98 px cannot fill 256 CUs with 1 WG each)
+    if ((mask & 1) && C == 256 && MID == 64 && W == 56 && H % 2 == 0) { *R = 2; return true; }
+    if ((mask & 2) && C == 512 && MID == 128 && W == 28 && H % 4 == 0) { *R = 4; return true; }
+    if ((mask & 4) && C == 1024 && MID == 256 && W == 14 && H % 7 == 0) { *R = 7; return true; }
     return false;
 }
 

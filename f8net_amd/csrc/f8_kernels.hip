@@ -808,20 +808,21 @@ static hipError_t launch_conv_t(const ConvArgs& a, int grid, hipStream_t s) {
         else hipLaunchKernelGGL((conv_igemm_persist_kernel<BM, BN, BK, WPX, WCO, false, PST>), dim3(g), dim3(256), 0, s, a);
         return hipGetLastError();
     }
-    if (pad && res) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, true, true, ST>), dim3(grid), dim3(256), 0, s, a);
-    else if (pad) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, true, false, ST>), dim3(grid), dim3(256), 0, s, a);
-    else if (res) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, false, true, ST>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, false, false, ST>), dim3(grid), dim3(256), 0, s, a);
+    // long K loops (3x3 of the late stages: 36-72 steps of ~64-256 MFMA cycles against an ~800-cycle DMA round
+    // trip) want a deeper ring; short ones want the smaller LDS footprint
+    static const int deep_nk = [] { const char* e = getenv("F8_DEEP_NK"); return e ? atoi(e) : 16; }();
+    constexpr int DST = (4 * TILE <= 65536) ? 4 : ((3 * TILE <= 65536) ? 3 : 2);
+    const bool deep = (DST > ST) && (a.ktot / BK >= deep_nk);
+#define F8_LAUNCH(PAD_, RES_) \
+    do { if (deep) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, PAD_, RES_, DST>), dim3(grid), dim3(256), 0, s, a); \
+         else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, PAD_, RES_, ST>), dim3(grid), dim3(256), 0, s, a); } while (0)
+    if (pad && res) F8_LAUNCH(true, true);
+    else if (pad) F8_LAUNCH(true, false);
+    else if (res) F8_LAUNCH(false, true);
+    else F8_LAUNCH(false, false);
+#undef F8_LAUNCH
     return hipGetLastError();
 }
-
-#ifdef F8_TRACE
-#include <cstdio>
-#include <vector>
-#include <algorithm>
-static unsigned long long* g_trace_buf = nullptr;
-static int g_trace_launch = 0;
-#endif
 
 hipError_t launch_conv(const ConvArgs& a0, const ConvTile& t, hipStream_t s) {
     ConvArgs a = a0;

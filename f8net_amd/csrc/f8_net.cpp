@@ -111,6 +111,7 @@ struct f8_net {
     char* d_arena = nullptr; char* d_w = nullptr; bool uploaded = false;
     hipEvent_t* events = nullptr; int n_events = 0;
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t aux_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t lag_ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -230,6 +231,7 @@ void f8_net_destroy(f8_net* net) {
     }
     for (int k = 0; k < 4; ++k) if (net->aux[k]) (void)hipStreamDestroy(net->aux[k]);
     for (int k = 0; k < 5; ++k) if (net->aux_ev[k]) (void)hipEventDestroy(net->aux_ev[k]);
+    for (int k = 0; k < 4; ++k) if (net->lag_ev[k]) (void)hipEventDestroy(net->lag_ev[k]);
     delete net;
 }
 
@@ -1143,10 +1145,18 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
     }
     (void)hipEventRecord(net->aux_ev[0], s);
     for (int k = 0; k < parts; ++k) (void)hipStreamWaitEvent(net->aux[k], net->aux_ev[0], 0);
+    // optional stagger: sub-batch p starts only after sub-batch p-1 has finished its first `lag` launches, so that the
+    // streams do not march through the memory-bound and the latency-bound layers in lock step
+    static const int lag = [] { const char* e = getenv("F8_STAGGER"); return e ? atoi(e) : 2; }();   // measured: lag 0/1/2/4/8 = 56.06/56.37/56.65/56.34/55.1 k img/s
     for (int i = 0; i < ns; ++i)
         for (int p = 0; p < parts; ++p) {
             rc = run_step(net, net->steps[i], input, output, cut[p], cut[p + 1] - cut[p], net->aux[p]);
             if (rc) return rc;
+            if (lag > 0 && i == lag - 1 && p + 1 < parts) {
+                if (!net->lag_ev[p]) (void)hipEventCreateWithFlags(&net->lag_ev[p], hipEventDisableTiming);
+                (void)hipEventRecord(net->lag_ev[p], net->aux[p]);
+                (void)hipStreamWaitEvent(net->aux[p + 1], net->lag_ev[p], 0);
+            }
         }
     for (int k = 0; k < parts; ++k) {
         (void)hipEventRecord(net->aux_ev[1 + k], net->aux[k]);
