@@ -106,6 +106,7 @@ struct f8_net {
     std::vector<Step> steps;
     std::vector<uint8_t> wblob;
     size_t arena_bytes = 0;
+    size_t arena_stride = 0;           // device arena = kMaxParts copies (one per concurrent sub-batch)
     size_t stem_zero_off = 0, stem_zero_bytes = 0; int stem_zero_val = 0;   // halo = biased zero
     // device
     char* d_arena = nullptr; char* d_w = nullptr; bool uploaded = false;
@@ -908,24 +909,28 @@ int f8_net_upload(f8_net* net) {
     if (!net || !net->finalized) return fail(F8_ERR_STATE, "f8_net_upload: not finalized");
     if (net->uploaded) return F8_OK;
     hipError_t e;
-    if ((e = hipMalloc((void**)&net->d_arena, std::max<size_t>(net->arena_bytes, 256))) != hipSuccess) return hip_fail(e, "hipMalloc(arena)");
+    static const int parts_cap = [] { const char* e = getenv("F8_SPLIT"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+    net->arena_stride = round_up_z(std::max<size_t>(net->arena_bytes, 256), 4096);
+    if ((e = hipMalloc((void**)&net->d_arena, net->arena_stride * parts_cap)) != hipSuccess) return hip_fail(e, "hipMalloc(arena)");
     if ((e = hipMalloc((void**)&net->d_w, std::max<size_t>(net->wblob.size(), 256))) != hipSuccess) return hip_fail(e, "hipMalloc(weights)");
     if (!net->wblob.empty() && (e = hipMemcpy(net->d_w, net->wblob.data(), net->wblob.size(), hipMemcpyHostToDevice)) != hipSuccess)
         return hip_fail(e, "hipMemcpy(weights)");
-    if (net->stem_zero_bytes && (e = hipMemset(net->d_arena + net->stem_zero_off, net->stem_zero_val, net->stem_zero_bytes)) != hipSuccess)
-        return hip_fail(e, "hipMemset(stem halo)");
+    for (int p = 0; p < parts_cap; ++p)
+        if (net->stem_zero_bytes && (e = hipMemset(net->d_arena + p * net->arena_stride + net->stem_zero_off, net->stem_zero_val, net->stem_zero_bytes)) != hipSuccess)
+            return hip_fail(e, "hipMemset(stem halo)");
     if ((e = hipDeviceSynchronize()) != hipSuccess) return hip_fail(e, "upload sync");
     net->uploaded = true;
     return F8_OK;
 }
 
-// Runs one launch for images [n0, n0 + N) of the batch (sub-batches are independent: every form is laid
-// out image-major, so a sub-batch is a pointer offset; I32T forms need n0 * H * W % 32 == 0, which the
-// caller guarantees).
-static int run_step(f8_net* net, const Step& st, const int32_t* input, void* output, int n0, int N, hipStream_t s) {
+// Runs one launch for images [n0, n0 + N) of the batch.  Every sub-batch works in its OWN copy of the arena
+// (index `part`): the arena packs tensors by lifetime assuming the steps of one batch run in order, so two
+// sub-batches that are at different steps at the same time must not share it (a later, larger tensor of the
+// sub-batch that is ahead would overlap an earlier tensor the other one is still reading).
+static int run_step(f8_net* net, const Step& st, const int32_t* input, void* output, int n0, int N, int part, hipStream_t s) {
     auto& T = net->tensors;
-    char* A = net->d_arena;
-    auto fp = [&](const Form& F) -> char* { return A + F.off + (size_t)n0 * F.bytes_per_img; };
+    char* A = net->d_arena + (size_t)part * net->arena_stride;
+    auto fp = [&](const Form& F) -> char* { return A + F.off; };
     const Node& nd = net->nodes[st.node];
     auto fill_out = [&](int32_t** out32, QuantOut q[2]) {
         *out32 = nullptr; q[0].ptr = q[1].ptr = nullptr; q[0].n = q[1].n = 0; q[0].lo = q[1].lo = 0; q[0].hi = q[1].hi = 0;
@@ -1060,10 +1065,8 @@ static int split_batch(const f8_net* net, int N, int cut[5]) {
     static const int want = [] { const char* e = getenv("F8_SPLIT"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
     cut[0] = 0; cut[1] = N;
     if (want < 2 || N < 2) return 1;
-    int gran = 1;
-    for (auto& t : net->tensors)
-        for (auto& F : t.forms)
-            if (F.kind == FORM_I32 && ((size_t)t.H * t.W) % 32 != 0) gran = 32;
+    const int gran = 1;
+    (void)net;
     int parts = want;
     while (parts > 1 && (N / parts) / gran * gran == 0) --parts;
     if (parts < 2) return 1;
@@ -1096,7 +1099,7 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
             hipEvent_t* ev = net->events + p * (ns + 1);
             (void)hipEventRecord(ev[0], s);
             for (int i = 0; i < ns; ++i) {
-                rc = run_step(net, net->steps[i], input, output, cut[p], cut[p + 1] - cut[p], s);
+                rc = run_step(net, net->steps[i], input, output, cut[p], cut[p + 1] - cut[p], p, s);
                 if (rc) return rc;
                 (void)hipEventRecord(ev[i + 1], s);
             }
@@ -1115,7 +1118,7 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
     }
     if (parts == 1) {
         for (int i = 0; i < ns; ++i) {
-            rc = run_step(net, net->steps[i], input, output, 0, N, s);
+            rc = run_step(net, net->steps[i], input, output, 0, N, 0, s);
             if (rc) return rc;
         }
         return F8_OK;
@@ -1126,7 +1129,7 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
     if (!use_streams) {
         for (int p = 0; p < parts; ++p)
             for (int i = 0; i < ns; ++i) {
-                rc = run_step(net, net->steps[i], input, output, cut[p], cut[p + 1] - cut[p], s);
+                rc = run_step(net, net->steps[i], input, output, cut[p], cut[p + 1] - cut[p], p, s);
                 if (rc) return rc;
             }
         return F8_OK;
@@ -1150,7 +1153,7 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
     static const int lag = [] { const char* e = getenv("F8_STAGGER"); return e ? atoi(e) : 2; }();   // measured: lag 0/1/2/4/8 = 56.06/56.37/56.65/56.34/55.1 k img/s
     for (int i = 0; i < ns; ++i)
         for (int p = 0; p < parts; ++p) {
-            rc = run_step(net, net->steps[i], input, output, cut[p], cut[p + 1] - cut[p], net->aux[p]);
+            rc = run_step(net, net->steps[i], input, output, cut[p], cut[p + 1] - cut[p], p, net->aux[p]);
             if (rc) return rc;
             if (lag > 0 && i == lag - 1 && p + 1 < parts) {
                 if (!net->lag_ev[p]) (void)hipEventCreateWithFlags(&net->lag_ev[p], hipEventDisableTiming);

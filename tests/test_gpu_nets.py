@@ -92,6 +92,10 @@ def test_full_size_batch_properties(dev):
     net = build_net(spec, params, max_batch=n, hw=224)
     xt = torch.from_numpy(x).to(dev)
     full = net.run(xt).cpu().numpy()
+    # the batch runs as concurrent sub-batches on internal streams: repeated runs must be identical
+    # (this caught an arena-sharing race between sub-batches during development)
+    for _ in range(4):
+        np.testing.assert_array_equal(net.run(xt).cpu().numpy(), full)
     parts = np.concatenate([net.run(xt[i:i + 32].contiguous()).cpu().numpy() for i in range(0, n, 32)])
     np.testing.assert_array_equal(full, parts)
     perm = np.array(synth.rand_uniform_int(1, 'perm', (n,), 0, 10**9)).argsort()
