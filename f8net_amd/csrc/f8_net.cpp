@@ -720,8 +720,11 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 else {
                     const int wpx = (nd.tile.bm == 128 && nd.tile.bn <= 64) ? 4 : 2, wco = 4 / wpx;
                     // keep in sync with launch_conv_t (f8_kernels.hip)
-                    snprintf(buf, sizeof buf, "f8::conv_igemm_kernel<%d, %d, %d, %d, %d, %s, %s, 2>", nd.tile.bm, nd.tile.bn, nd.tile.bk, wpx, wco,
-                             (d.pad > 0 && !nd.stem) ? "true" : "false", st.res_t >= 0 ? "true" : "false");
+                    const int tile_b = (nd.tile.bm + nd.tile.bn) * nd.tile.bk;
+                    const int dst = (4 * tile_b <= 65536) ? 4 : ((3 * tile_b <= 65536) ? 3 : 2);
+                    const int stages = (dst > 2 && nd.ktot / nd.tile.bk >= 16) ? dst : 2;     // ring depth rule of launch_conv_t
+                    snprintf(buf, sizeof buf, "f8::conv_igemm_kernel<%d, %d, %d, %d, %d, %s, %s, %d>", nd.tile.bm, nd.tile.bn, nd.tile.bk, wpx, wco,
+                             (d.pad > 0 && !nd.stem) ? "true" : "false", st.res_t >= 0 ? "true" : "false", stages);
                 }
                 st.kernel = buf;
                 break;
