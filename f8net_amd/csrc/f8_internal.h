@@ -48,6 +48,7 @@ struct ConvArgs {
 struct DwArgs {
     const int8_t* x; const int8_t* w;      // w: [9][Cs] tap-major
     const int32_t* bias;                   // [Cs]
+    const int8_t* w4; const int32_t* bias4; // dot4 kernel: [Cs/4][9] tap-transposed dwords, bias + 128*sum(w) for unsigned inputs
     int32_t N, H, W, P, Q, Cs, stride, pad;
     int32_t in_signed;
     int32_t relu0;

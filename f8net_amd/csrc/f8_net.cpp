@@ -447,16 +447,38 @@ static void pack_conv_weights(f8_net* net, Node& nd, const Tensor& src, const Te
 }
 
 static void pack_dw_weights(f8_net* net, Node& nd, const Tensor& src) {
+    // Two images of the depthwise weights:
+    //  (1) [9][Cs] tap-major + plain bias            — scalar kernel (int32 outputs, fallback)
+    //  (2) [Cs/4][9] dwords for the dot4 kernel: per 4-channel quad, dword e (0..3) = taps 0..3 of channel e,
+    //      dword 4+e = taps 4..7 of channel e, dword 8 = tap 8 of the 4 channels; bias + 128 * sum(w) when the
+    //      input is unsigned (stored biased; out-of-image taps are replaced by the biased zero in the kernel).
     const f8_conv_desc& d = nd.cd;
     nd.coutP = src.Cs; nd.ck = 0; nd.ktot = 0;
     nd.w_off = round_up_z(net->wblob.size(), 256);
     nd.b_off = round_up_z(nd.w_off + (size_t)9 * src.Cs, 256);
-    net->wblob.resize(nd.b_off + (size_t)src.Cs * 4, 0);
+    nd.rc_off = round_up_z(nd.b_off + (size_t)src.Cs * 4, 256);            // dot4 weights
+    nd.cc_off = round_up_z(nd.rc_off + (size_t)(src.Cs / 4) * 9 * 4, 256);  // dot4 bias
+    net->wblob.resize(nd.cc_off + (size_t)src.Cs * 4, 0);
     int8_t* wp = (int8_t*)net->wblob.data() + nd.w_off;
     int32_t* bp = (int32_t*)(net->wblob.data() + nd.b_off);
+    int8_t* w4 = (int8_t*)net->wblob.data() + nd.rc_off;
+    int32_t* b4 = (int32_t*)(net->wblob.data() + nd.cc_off);
     for (int c = 0; c < d.cout; ++c) {
-        for (int t = 0; t < 9; ++t) wp[(size_t)t * src.Cs + c] = nd.w[(size_t)c * 9 + t];
+        long long sum = 0;
+        for (int t = 0; t < 9; ++t) {
+            const int8_t v = nd.w[(size_t)c * 9 + t];
+            wp[(size_t)t * src.Cs + c] = v;
+            sum += v;
+            int8_t* quad = w4 + (size_t)(c / 4) * 36;
+            const int e = c % 4;
+            if (t < 4) quad[e * 4 + t] = v;
+            else if (t < 8) quad[16 + e * 4 + (t - 4)] = v;
+            else quad[32 + e] = v;
+        }
         bp[c] = nd.bias[c];
+        uint32_t b = (uint32_t)nd.bias[c];
+        if (!d.input_signed) b += (uint32_t)(128ll * sum);
+        b4[c] = (int32_t)b;
     }
 }
 
@@ -716,7 +738,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 else snprintf(buf, sizeof buf, "conv%dx%ds%d_t%dx%dx%d%s%s:%s", d.kernel, d.kernel, d.stride, nd.tile.bm, nd.tile.bn,
                               nd.tile.bk, nd.stem ? "_stem" : "", st.res_t >= 0 ? "_res" : "", tname(net, nd.out).c_str());
                 st.name = buf;
-                if (nd.depthwise) snprintf(buf, sizeof buf, "f8::dwconv3x3_kernel<%s>", d.input_signed ? "true" : "false");
+                if (nd.depthwise) snprintf(buf, sizeof buf, "f8::dwconv3x3_dot4_kernel<%d, 2>", d.stride);
                 else {
                     const int wpx = (nd.tile.bm == 128 && nd.tile.bn <= 64) ? 4 : 2, wco = 4 / wpx;
                     // keep in sync with launch_conv_t (f8_kernels.hip)
@@ -1014,6 +1036,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             const Tensor& oT = T[nd.out];
             DwArgs a{};
             a.x = (const int8_t*)fp(sF); a.w = (const int8_t*)(net->d_w + nd.w_off); a.bias = (const int32_t*)(net->d_w + nd.b_off);
+            a.w4 = (const int8_t*)(net->d_w + nd.rc_off); a.bias4 = (const int32_t*)(net->d_w + nd.cc_off);
             a.N = N; a.H = sT.H; a.W = sT.W; a.P = oT.H; a.Q = oT.W; a.Cs = sT.Cs; a.stride = nd.cd.stride; a.pad = nd.cd.pad;
             a.in_signed = nd.cd.input_signed; a.relu0 = st.relu0;
             fill_out(&a.out32, a.q);
