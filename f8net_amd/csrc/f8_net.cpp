@@ -549,7 +549,6 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         const int other = (ad.a == c.out) ? ad.b : ad.a;
         if (other != a0.a) continue;                          // residual operand must be the block input
         const Tensor& x = T[a0.a];
-        if (ND[x.prod].kind == N_INPUT) continue;
         const int C = a0.cd.cin, MID = a0.cd.cout;
         if (c.cd.cout != C || b.cd.cin != MID || b.cd.cout != MID || c.cd.cin != MID) continue;
         int R = 0;

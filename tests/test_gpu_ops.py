@@ -146,3 +146,49 @@ def test_linear_pools(dev):
     m = np.maximum(synth.rand_normal_int(32, 'mp', (2, 64, 17, 18), 2e5), 0).astype(np.int32)
     got = ops.F8MaxPool2d(3, 2, 1)(_t(m, dev)).cpu().numpy()
     np.testing.assert_array_equal(got, oracle.maxpool(m))
+
+
+# (C, MID, H, W, N): shapes the fused bottleneck kernel is instantiated for, at small batch
+FUSED_SHAPES = [(256, 64, 56, 56, 2), (512, 128, 28, 28, 3), (256, 64, 4, 56, 1)]
+
+
+@pytest.mark.parametrize('shape', FUSED_SHAPES, ids=lambda g: 'x'.join(map(str, g)))
+@pytest.mark.parametrize('variant', ['res_shifts_left', 'acc_shifts_left_signed_mid'])
+def test_fused_bottleneck_block_matches_oracle(dev, shape, variant):
+    """One bottleneck identity block as a net of its own: the planner maps it onto
+    fused_bottleneck_kernel; result (int32 block output) must equal IntBlock.forward's (oracle)."""
+    from f8net_amd import topology
+    from f8net_amd.net import F8Net
+    C, MID, H, W, N = shape
+    b = topology.BlockSpec('blk', [topology.ConvSpec('blk.body.0', C, MID, 1, 1, 0, relu=True),
+                                   topology.ConvSpec('blk.body.2', MID, MID, 3, 1, 1, relu=True),
+                                   topology.ConvSpec('blk.body.4', MID, C, 1, 1, 0)], None, residual=True, post_relu=True)
+    if variant == 'res_shifts_left':
+        fls, x_fl = {'blk.body.0': (4, 7), 'blk.body.2': (3, 6), 'blk.body.4': (5, 7)}, 9          # out fl 12 > x fl 9
+    else:
+        fls, x_fl = {'blk.body.0': (2, 5), 'blk.body.2': (4, 7), 'blk.body.4': (1, 6)}, 11         # out fl 7 < x fl 11
+        b.body[1].signed_in = True        # exercise the plain (unbiased) LDS patch and its zero border
+    params = {}
+    for c in b.body:
+        in_fl, w_fl = fls[c.key]
+        params[c.key + '.weight'] = np.clip(synth.rand_normal_int(5, c.key + 'w' + variant, (c.cout, c.cin, c.k, c.k), 30.0), -127, 127).astype(np.int32)
+        params[c.key + '.bias'] = synth.rand_normal_int(6, c.key + 'b', (c.cout,), 2.0 ** (in_fl + w_fl)).astype(np.int32)
+        params[c.key + '.weight_fraclen'] = np.array(w_fl, np.int32)
+        params[c.key + '.input_fraclen'] = np.array([in_fl], np.int32)
+    x = synth.rand_normal_int(7, 'blkx' + variant, (N, C, H, W), 3.0e3 if variant == 'res_shifts_left' else 4.0e5).astype(np.int32)
+    x.reshape(-1)[:3] = [2**31 - 1, -2**31, 2**30]       # wrap / clamp corners of the residual join
+    net = F8Net()
+    t = net.input(C, H, W, x_fl)
+    r = t
+    for c in b.body:
+        r = net.conv(r, params[c.key + '.weight'], params[c.key + '.bias'], stride=1, pad=c.pad, groups=1,
+                     weight_fl=fls[c.key][1], input_fl=fls[c.key][0], input_signed=c.signed_in, quant_input=True, relu=c.relu)
+    r = net.add(r, t, relu=True)
+    net.output(r, as_float=False)
+    net.finalize(N)
+    if W in (56, 28) and H % (2 if W == 56 else 4) == 0:
+        assert 'fused_bottleneck' in net.describe(), net.describe()
+    got = net.run(_t(x, dev)).cpu().numpy().reshape(N, C, H, W)
+    want, want_fl = oracle.block_forward(b, params, x, x_fl)
+    assert net.output_fraclen == want_fl
+    np.testing.assert_array_equal(got, want)
