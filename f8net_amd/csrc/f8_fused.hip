@@ -27,6 +27,7 @@
 // chunk (see f8_kernels.hip).  LDS is dynamic (up to ~120 KB for MID = 256).
 #include "f8_device.h"
 #include <cstdlib>
+#include <cstdio>
 
 namespace f8 {
 
@@ -56,7 +57,8 @@ struct FusedCfg {
 };
 
 template <int C, int MID, int W, int R>
-__global__ void __launch_bounds__(512) fused_bottleneck_kernel(const FusedArgs a) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MID <= 128 ? 4 : 2)))
+fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so that two workgroups share a CU (LDS allows it)
     using Cfg = FusedCfg<C, MID, W, R>;
     constexpr int PW = Cfg::PW;
     constexpr int P1_PX = Cfg::P1_PX, NP1 = Cfg::NP1, OUT_PX = Cfg::OUT_PX, NPO = Cfg::NPO, CM = Cfg::CM;
@@ -105,6 +107,12 @@ __global__ void __launch_bounds__(512) fused_bottleneck_kernel(const FusedArgs a
     const __amdgpu_buffer_rsrc_t rw2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2, 0, a.w2_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw4 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w4, 0, a.w4_bytes, 0x00020000);
 
+#ifdef F8_TRACE
+    unsigned long long tt[8]; tt[0] = __builtin_readcyclecounter();
+#define F8_TT(i) tt[i] = __builtin_readcyclecounter()
+#else
+#define F8_TT(i)
+#endif
     // ---- patch <- biased zero everywhere (border and out-of-image rows keep it)
     {
         const unsigned z = a.xor1;
@@ -183,6 +191,13 @@ __global__ void __launch_bounds__(512) fused_bottleneck_kernel(const FusedArgs a
         unsigned cof[2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) cof[kk] = (unsigned)(((kk * 2 + lh) ^ S64::f(l31)) << 4);
+        // biases are fetched BEFORE any DMA / residual load of the phase is issued: VMEM returns in order, so a
+        // bias load issued behind them would make the epilogue wait for all of them (measured: 7-9k cycles)
+        v4i bq0[CMW][4];
+#pragma unroll
+        for (int i = 0; i < CMW; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bq0[i][g] = *(const v4i*)(a.b0 + (wb * CMW + i) * 32 + 8 * g + 4 * lh);
 
         issue_p1(0, 0);
         for (int ks = 0; ks < NK1; ++ks) {
@@ -210,6 +225,7 @@ __global__ void __launch_bounds__(512) fused_bottleneck_kernel(const FusedArgs a
                 }
             }
         }
+        F8_TT(1);
         // first W2 stage can already travel: its slot was last read two steps ago
         issue_w2(0, NK1 & 1);
 
@@ -230,7 +246,7 @@ __global__ void __launch_bounds__(512) fused_bottleneck_kernel(const FusedArgs a
                 unsigned d[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const v4i bv = *(const v4i*)(a.b0 + cot + 8 * g + 4 * lh);
+                    const v4i bv = bq0[i][g];
                     int y[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) y[e] = requant1(max((int)((unsigned)acc[j][i][4 * g + e] + (unsigned)bv[e]), floor0), a.n1, a.lo1, a.hi1);
@@ -246,6 +262,7 @@ __global__ void __launch_bounds__(512) fused_bottleneck_kernel(const FusedArgs a
         }
     }
 
+    F8_TT(2);
     // ---- output pixel of this lane (px tile wa) and the residual stream of its (px tile, co tile wb)
     const int opix = wa * 32 + l31;
     const bool opix_ok = opix < rows_out * W;
@@ -274,6 +291,11 @@ __global__ void __launch_bounds__(512) fused_bottleneck_kernel(const FusedArgs a
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) cof[kk] = (unsigned)(((kk * 2 + lh) ^ S64::f(l31)) << 4);
 
+        v4i bq2[CMW][4];
+#pragma unroll
+        for (int i = 0; i < CMW; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bq2[i][g] = *(const v4i*)(a.b2 + (wb * CMW + i) * 32 + 8 * g + 4 * lh);
         constexpr int S0 = NK1 & 1;                      // ring slot of W2 step 0
         constexpr int CH = MID / 64;                     // 64-byte channel chunks per tap
         int tr = 0, ts = 0, tc = 0;
@@ -295,6 +317,7 @@ __global__ void __launch_bounds__(512) fused_bottleneck_kernel(const FusedArgs a
             }
             if (++tc == CH) { tc = 0; if (++ts == 3) { ts = 0; ++tr; } }
         }
+        F8_TT(3);
         asm volatile("" ::: "memory");
         issue_w4(0, (S0 + NK2) & 1);
         asm volatile("" ::: "memory");   // the loads below must stay behind this DMA (counted wait in P3)
@@ -307,7 +330,7 @@ __global__ void __launch_bounds__(512) fused_bottleneck_kernel(const FusedArgs a
             unsigned d[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const v4i bv = *(const v4i*)(a.b2 + cot + 8 * g + 4 * lh);
+                const v4i bv = bq2[i][g];
                 int y[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = requant1(max((int)((unsigned)acc[i][4 * g + e] + (unsigned)bv[e]), floor0), a.n2, a.lo2, a.hi2);
@@ -320,6 +343,7 @@ __global__ void __launch_bounds__(512) fused_bottleneck_kernel(const FusedArgs a
         }
     }
 
+    F8_TT(4);
     // =========================================================================================
     // P3: y = clamp((W4 . mid2 + b4) << sa + (x << sr)) [ReLU]  ->  y32 (I32T) / int8 copies
     //     wave (wa, wb): px tile wa, co tile wb of each 64-channel chunk
@@ -327,14 +351,31 @@ __global__ void __launch_bounds__(512) fused_bottleneck_kernel(const FusedArgs a
     {
         constexpr int S0 = (NK1 + NK2) & 1;
         const int floor1 = a.relu1 ? 0 : INT32_MIN;
+        const int n_store = (a.out32 ? 4 : 0) + (a.q[0].ptr ? 1 : 0) + (a.q[1].ptr ? 1 : 0);   // store instructions per wave per chunk
+        static_assert((NPO - 1) * 32 < OUT_PX, "every pixel tile has live lanes (store count in the counted wait)");
         v4i xf[KK3];                                     // this wave's mid2 fragments are chunk-invariant: read once
         // one chunk of 64 output channels; `cur` holds this chunk's residual, `nxt` receives the next one's
         auto chunk = [&](int c, v4i (&cur)[4], v4i (&nxt)[4]) {
-            // W4 chunk c landed?  Everything issued after it (>= 4 loads: the residual prefetch, fenced behind the
-            // DMA; plus bias loads and the previous chunk's stores) may stay in flight: all of it is newer.
-            wait_vmcnt<4>();
+            // W4 chunk c landed?  VMEM retires in order, so exactly the operations issued AFTER that DMA may stay in
+            // flight: the 4 residual-prefetch loads (fenced behind it) and, from chunk 1 on, the previous chunk's
+            // stores (4 for the int32 form + 1 per int8 form; every wave has live lanes, so all of them issue).
+            // A smaller count would be safe but would drain the residual prefetch on every chunk (measured: P3
+            // 30k -> cycles per tile); a larger one would race.
+            if (c == 0) wait_vmcnt<4>();
+            else switch (n_store) {
+                case 1: wait_vmcnt<5>(); break;
+                case 2: wait_vmcnt<6>(); break;
+                case 4: wait_vmcnt<8>(); break;
+                case 5: wait_vmcnt<9>(); break;
+                case 6: wait_vmcnt<10>(); break;
+                default: wait_vmcnt<4>(); break;
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                // chunk 0: also "mid2 complete"
+            const int cot = c * 64 + wb * 32;
+            v4i bq4[4];                                  // this chunk's bias: requested before the DMA / prefetch below
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bq4[g] = *(const v4i*)(a.b4 + cot + 8 * g + 4 * lh);
             asm volatile("" ::: "memory");
             if (c + 1 < NC3) issue_w4(c + 1, (S0 + c + 1) & 1);
             asm volatile("" ::: "memory");
@@ -352,11 +393,10 @@ __global__ void __launch_bounds__(512) fused_bottleneck_kernel(const FusedArgs a
                 const v4i wf = *(const v4i*)(base + SM::off(wb * 32 + l31, kk * 2 + lh));
                 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, xf[kk], acc, 0, 0, 0);
             }
-            const int cot = c * 64 + wb * 32;
             int y[4][4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const v4i bv = *(const v4i*)(a.b4 + cot + 8 * g + 4 * lh);
+                const v4i bv = bq4[g];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const unsigned v = (unsigned)acc[4 * g + e] + (unsigned)bv[e];
@@ -392,6 +432,14 @@ __global__ void __launch_bounds__(512) fused_bottleneck_kernel(const FusedArgs a
             chunk(c + 1, rn, rv);
         }
     }
+#ifdef F8_TRACE
+    if (a.trace && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tt[5] = __builtin_readcyclecounter();
+        unsigned long long* tp = (unsigned long long*)a.trace + (size_t)blockIdx.x * 8;
+        for (int i = 0; i < 6; ++i) tp[i] = tt[i];
+    }
+#endif
 }
 
 template <int C, int MID, int W, int R>
@@ -404,8 +452,28 @@ static hipError_t launch_fused_t(const FusedArgs& a, hipStream_t s) {
         attr_set = true;
     }
     const int grid = a.N * a.tiles_per_img;
+#ifdef F8_TRACE
+    static unsigned long long* tbuf = nullptr; static int count = 0;
+    static const int want = [] { const char* e = getenv("F8_TRACE_FUSED"); return e ? atoi(e) : -1; }();
+    FusedArgs b = a;
+    const bool tracing = (count++ == want);
+    if (tracing) { if (!tbuf) (void)hipMalloc((void**)&tbuf, (size_t)1 << 22); (void)hipMemsetAsync(tbuf, 0, (size_t)grid * 64, s); b.trace = tbuf; }
+    hipLaunchKernelGGL((fused_bottleneck_kernel<C, MID, W, R>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, b);
+    if (tracing) {
+        (void)hipStreamSynchronize(s);
+        unsigned long long* h = new unsigned long long[(size_t)grid * 8];
+        (void)hipMemcpy(h, tbuf, (size_t)grid * 64, hipMemcpyDeviceToHost);
+        double ph[5] = {0, 0, 0, 0, 0}; int n = 0;
+        for (int i = 0; i < grid; ++i) { unsigned long long* p = h + (size_t)i * 8; if (!p[5]) continue; ++n; for (int k = 0; k < 5; ++k) ph[k] += (double)(p[k + 1] - p[k]); }
+        fprintf(stderr, "[trace fused<%d,%d,%d,%d>] grid %d: avg cycles per WG: P1 loop %.0f | P1 epi %.0f | P2 loop %.0f | P2 epi %.0f | P3 %.0f\n", C, MID, W, R, grid,
+                ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n);
+        delete[] h;
+    }
+    return hipGetLastError();
+#else
     hipLaunchKernelGGL((fused_bottleneck_kernel<C, MID, W, R>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, a);
     return hipGetLastError();
+#endif
 }
 
 hipError_t launch_fused_bottleneck(const FusedArgs& a, hipStream_t s) {

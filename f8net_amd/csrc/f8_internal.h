@@ -41,6 +41,12 @@ struct ConvArgs {
     int32_t relu1;                         // ReLU after the residual add
     int32_t* out32;                        // NHWC int32 (stride coutP) or nullptr
     QuantOut q[2];
+    // dual GEMM (x2 != nullptr): a second 1x1 / pad 0 conv over the same output pixels whose result (+ bias2) is
+    // the residual operand of the join; K steps of (x, w) run first, then those of (x2, w2)
+    const int8_t* x2; uint32_t x2_bytes;
+    const int8_t* w2; uint32_t w2_bytes;   // [coutP][ktot2]
+    const int32_t* bias2;                  // [coutP]
+    int32_t sN2, sP2, sQ2, ktot2;          // input byte strides of x2 (per image / output row / output col), its K
     void* trace;                           // tuning builds (F8_TRACE) only; nullptr otherwise
 };
 
@@ -101,6 +107,7 @@ struct FusedArgs {
     int32_t relu_a, relu_b;                // ReLU after body.0 / body.2
     int32_t acc_shl, res_shl, relu1;       // residual join
     int32_t* out32; QuantOut q[2];
+    void* trace;                           // tuning builds (F8_TRACE) only
 };
 
 struct ConvTile { int bm, bn, bk; };

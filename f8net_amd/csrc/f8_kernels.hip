@@ -15,6 +15,11 @@
 // is exact under wrap-around.
 #include "f8_device.h"
 #include <cstdlib>
+#ifdef F8_TRACE
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+#endif
 
 namespace f8 {
 
@@ -94,9 +99,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, v16i (&acc)[TCO
     }
 }
 
-template <int BM, int BN, int BK, int WPX, int WCO, bool HAS_PAD, bool HAS_RES, int STAGES>
+// DUAL: a second 1x1 conv (x2, w2, bias2; its own strides, no padding) is accumulated after the first in the
+// same DMA ring and takes the place of the residual operand:  out = join(acc + bias, acc2 + bias2).  This is the
+// downsample block's `body.4 + shortcut` pair: the int32 tensor between them never exists in HBM.
+template <int BM, int BN, int BK, int WPX, int WCO, bool HAS_PAD, bool HAS_RES, int STAGES, bool DUAL = false>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     static_assert(WPX * WCO == 4, "4 waves");
+    static_assert(!DUAL || (HAS_RES && !HAS_PAD), "dual GEMM: the second product is the residual operand; 1x1 convs only");
     static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
     constexpr int CPR = BK / 16;                  // chunks per row
     constexpr int RPB = 256 / BK;                 // rows per 256-byte bank row
@@ -140,7 +149,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     unsigned long long t_start = __builtin_readcyclecounter(), t_pro = 0, t_first = 0, t_loop = 0;
 #endif
     v4i rv[HAS_RES ? TCO : 1][HAS_RES ? TPX : 1][4];
-    if (HAS_RES) {
+    if (HAS_RES && !DUAL) {
 #pragma unroll
         for (int i = 0; i < TCO; ++i)
 #pragma unroll
@@ -185,6 +194,31 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
         wbase[j] = (idx < WCH) ? (unsigned)((co0 + row) * a.ktot + chunk * 16) : kOOB;
     }
 
+    // second operand pair (DUAL): same tile, its own image strides
+    const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? a.x2 : a.x), 0, DUAL ? a.x2_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw2 = __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? a.w2 : a.w), 0, DUAL ? a.w2_bytes : 0u, 0x00020000);
+    unsigned xbase2[DUAL ? XL : 1], wbase2[DUAL ? WL : 1];
+    if (DUAL) {
+#pragma unroll
+        for (int i = 0; i < XL; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / CPR, chunk = (idx % CPR) ^ ((row / RPB) % CPR);
+            const int m = m0 + row;
+            xbase2[i] = kOOB;
+            if (idx < XCH && m < a.M) {
+                const int n = (int)fast_div((unsigned)m, a.mPQ, a.s1PQ, a.s2PQ), rem = m - n * a.PQ;
+                const int p = (int)fast_div((unsigned)rem, a.mQ, a.s1Q, a.s2Q), q = rem - p * a.Q;
+                xbase2[i] = (unsigned)(n * a.sN2 + p * a.sP2 + q * a.sQ2 + chunk * 16);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WL; ++j) {
+            const int idx = tid + j * 256;
+            const int row = idx / CPR, chunk = (idx % CPR) ^ ((row / RPB) % CPR);
+            wbase2[j] = (idx < WCH) ? (unsigned)((co0 + row) * a.ktot2 + chunk * 16) : kOOB;
+        }
+    }
+
     // ---- per-lane fragment addresses
     const int fl = (l31 / RPB) % CPR;
     unsigned coff[KK];
@@ -201,7 +235,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
 
-    const int nk = a.ktot / BK;
+    const int nk1 = a.ktot / BK;
+    const int nk = nk1 + (DUAL ? a.ktot2 / BK : 0);
     // K-step state of the NEXT stage to issue (wave-uniform): tap row/col, channel offset in the tap
     int tr = 0, ts = 0, c0 = 0, kiss = 0;
 
@@ -210,6 +245,25 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     // it, and the counted waits below use the per-wave instruction count).
     auto issue_stage = [&](int slot) {
         char* base = lds + slot * TILE;
+        if (DUAL && kiss >= nk1) {               // wave-uniform: stages of the second product
+            const unsigned koff2 = (unsigned)((kiss - nk1) * BK);
+#pragma unroll
+            for (int i = 0; i < XL; ++i) {
+                const unsigned off = xbase2[i] + koff2;
+                if ((i * 256 + wave * 64) < XCH)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx2, (__attribute__((address_space(3))) void*)(base + i * 4096 + wave * 1024),
+                                                             16, off, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < WL; ++j) {
+                const unsigned woff = wbase2[j] + koff2;
+                if ((j * 256 + wave * 64) < WCH)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw2, (__attribute__((address_space(3))) void*)(base + XBYTES + j * 4096 + wave * 1024),
+                                                             16, woff, 0, 0, 0);
+            }
+            ++kiss;
+            return;
+        }
         const unsigned koffx = (unsigned)(tr * a.tapH + ts * a.tapW + c0);
 #pragma unroll
         for (int i = 0; i < XL; ++i) {
@@ -268,7 +322,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     t_pro = __builtin_readcyclecounter();
 #endif
 
-    for (int ks = 0; ks < nk; ++ks) {
+    auto k_step = [&](int ks, v16i (&ac)[TCO][TPX]) {
         // stages issued so far: min(nk, ks + STAGES - 1); stage ks must have landed
         const int issued = (ks + STAGES - 1 < nk) ? ks + STAGES - 1 : nk;
         wait_ahead(issued - 1 - ks);
@@ -292,10 +346,35 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < TPX; ++j)
 #ifndef F8_ABL_NO_MFMA
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    ac[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xf[j], ac[i][j], 0, 0, 0);
 #else
-                    acc[i][j][0] += wf[i].x ^ xf[j].x;
+                    ac[i][j][0] += wf[i].x ^ xf[j].x;
 #endif
+        }
+    };
+    for (int ks = 0; ks < nk1; ++ks) k_step(ks, acc);
+    if constexpr (DUAL) {
+        v16i acc2[TCO][TPX];
+#pragma unroll
+        for (int i = 0; i < TCO; ++i)
+#pragma unroll
+            for (int j = 0; j < TPX; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0;
+        for (int ks = nk1; ks < nk; ++ks) k_step(ks, acc2);
+        // the second product (+ its bias) is the residual operand; fragment order == I32T order
+#pragma unroll
+        for (int i = 0; i < TCO; ++i) {
+            const int cot = co0 + wco * (BN / WCO) + i * 32;
+            if (cot >= a.coutP) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const v4i bv = *(const v4i*)(a.bias2 + cot + 8 * g + 4 * lh);
+#pragma unroll
+                for (int j = 0; j < TPX; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rv[i][j][g][e] = (int)((unsigned)acc2[i][j][4 * g + e] + (unsigned)bv[e]);
+            }
         }
     }
 #ifdef F8_ABL_NO_EPI
@@ -909,7 +988,15 @@ static hipError_t launch_conv_t(const ConvArgs& a, int grid, hipStream_t s) {
     // trip) want a deeper ring; short ones want the smaller LDS footprint
     static const int deep_nk = [] { const char* e = getenv("F8_DEEP_NK"); return e ? atoi(e) : 16; }();
     constexpr int DST = (4 * TILE <= 65536) ? 4 : ((3 * TILE <= 65536) ? 3 : 2);
-    const bool deep = (DST > ST) && (a.ktot / BK >= deep_nk);
+    const bool deep = (DST > ST) && ((a.ktot + a.ktot2) / BK >= deep_nk);
+    if (a.x2) {   // dual GEMM (downsample join): 1x1 / no padding, 64-wide cout tiles only
+        if constexpr (BN == 64 && BK == 64) {
+            if (pad || res) return hipErrorInvalidValue;
+            if (deep) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, false, true, DST, true>), dim3(grid), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, false, true, ST, true>), dim3(grid), dim3(256), 0, s, a);
+            return hipGetLastError();
+        } else return hipErrorInvalidValue;
+    }
 #define F8_LAUNCH(PAD_, RES_) \
     do { if (deep) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, PAD_, RES_, DST>), dim3(grid), dim3(256), 0, s, a); \
          else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, PAD_, RES_, ST>), dim3(grid), dim3(256), 0, s, a); } while (0)
@@ -920,6 +1007,11 @@ static hipError_t launch_conv_t(const ConvArgs& a, int grid, hipStream_t s) {
 #undef F8_LAUNCH
     return hipGetLastError();
 }
+
+#ifdef F8_TRACE
+static int g_trace_launch = 0;
+static void* g_trace_buf = nullptr;
+#endif
 
 hipError_t launch_conv(const ConvArgs& a0, const ConvTile& t, hipStream_t s) {
     ConvArgs a = a0;

@@ -77,6 +77,8 @@ struct Node {
     bool stem = false, depthwise = false;
     int absorbed_by = -1;              // conv swallowed by a fused bottleneck launch (node id of its last conv)
     int fb_a = -1, fb_b = -1, fb_R = 0;  // last conv of a fused bottleneck: its first two convs, rows per tile
+    int dual = -1;                     // 1x1 conv hosting a join whose other operand is ANOTHER 1x1 conv (node id): one dual-GEMM launch
+    int dual_host = -1;                // ... and that other conv: the node that carries it
     bool no_classes = false;           // pack a single bias class (the consumer kernel pads with real zeros itself)
     size_t w_off = 0, b_off = 0; int coutP = 0, ck = 0, ktot = 0;
     size_t rc_off = 0, cc_off = 0; int ncc = 0;      // border-class tables (0 = single class)
@@ -88,6 +90,7 @@ struct Step {
     int kind; int node;
     int src_t = -1, src_f = -1;        // main input tensor / form
     int res_t = -1, res_f = -1;        // residual (conv) or second operand (add)
+    int src2_t = -1, src2_f = -1;      // dual GEMM: input of the second conv
     OutSel out;
     int acc_shl = 0, res_shl = 0, relu0 = 0, relu1 = 0;
     bool dense = false;
@@ -557,6 +560,23 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         c.fb_a = ta.prod; c.fb_b = tb.prod; c.fb_R = R;
     }
 
+    // ---- 1c. downsample join: the add's two operands are both 1x1 / pad 0 convs (body.4 and the shortcut) and the
+    //          earlier one feeds nothing else  ->  one dual-GEMM launch, its int32 result never touches HBM
+    static const int fuse_dual = [] { const char* e = getenv("F8_FUSE_DUAL"); return e ? atoi(e) : 1; }();
+    for (int i = 0; fuse_dual && i < nn; ++i) {
+        Node& h = ND[i];
+        if (h.kind != N_CONV || h.fused_add < 0 || h.fb_a >= 0 || h.cd.groups != 1 || h.cd.kernel != 1 || h.cd.pad != 0) continue;
+        if (h.cd.cin % 64 != 0 || round_up(h.cd.cout, 32) <= 32) continue;          // kernel instances: BK = 64, BN = 64
+        const Node& ad = ND[h.fused_add];
+        const int other = (ad.a == h.out) ? ad.b : ad.a;
+        if (T[other].consumers.size() != 1 || other == net->out_t) continue;
+        Node& g = ND[T[other].prod];
+        if (g.kind != N_CONV || g.fused_add >= 0 || g.absorbed_by >= 0 || g.fb_a >= 0 || g.cd.groups != 1 || g.cd.kernel != 1 || g.cd.pad != 0 ||
+            g.cd.relu || g.cd.cin % 64 != 0 || g.cd.cout != h.cd.cout) continue;
+        if (T[g.out].H != T[h.out].H || T[g.out].W != T[h.out].W) continue;
+        h.dual = T[other].prod; g.dual_host = i;
+    }
+
     // ---- 2. which forms does each tensor need?  (reverse order: consumers before producers)
     {
         Tensor& O = T[net->out_t];
@@ -596,7 +616,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 } else {
                     add_form(s, FORM_I8, n, nd.cd.input_signed ? 1 : 0);
                 }
-                if (nd.fused_add >= 0) {
+                if (nd.fused_add >= 0 && nd.dual < 0) {
                     const Node& ad = ND[nd.fused_add];
                     const int other = (ad.a == nd.out) ? ad.b : ad.a;
                     add_form(T[other], FORM_I32, 0, 0);
@@ -643,7 +663,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
     for (int i = 0; i < nn; ++i) {
         Node& nd = ND[i];
         if (nd.kind == N_ADD && nd.fused_into >= 0) continue;
-        if (nd.kind == N_CONV && nd.absorbed_by >= 0) continue;
+        if (nd.kind == N_CONV && (nd.absorbed_by >= 0 || nd.dual_host >= 0)) continue;
         Step st; st.node = i;
         std::vector<int> extra;
         int out_t = nd.out;
@@ -709,11 +729,20 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     const int M1 = T[nd.out].H * T[nd.out].W;
                     if (!pick_conv_tile(M1 * max_batch, nd.coutP, nd.ck, nd.fused_add >= 0, &nd.tile))
                         return fail(F8_ERR_UNSUPPORTED, "finalize: no conv kernel instance for ck=%d coutP=%d", nd.ck, nd.coutP);
+                    if (nd.dual >= 0) { nd.tile.bn = 64; nd.tile.bk = 64; }       // the dual-GEMM instances
                 }
                 if (nd.fused_add >= 0) {
                     const Node& ad = ND[nd.fused_add];
                     const int other = (ad.a == nd.out) ? ad.b : ad.a;
-                    st.res_t = other; st.res_f = find_form(T[other], FORM_I32, 0, 0);
+                    if (nd.dual >= 0) {
+                        Node& g = ND[nd.dual];
+                        Tensor& s2 = T[g.a];
+                        int n2 = 0; consumer_format(s2, g.cd, &n2, "finalize");
+                        st.src2_t = g.a; st.src2_f = find_form(s2, FORM_I8, n2, g.cd.input_signed ? 1 : 0);
+                        pack_conv_weights(net, g, s2, T[g.out]);
+                    } else {
+                        st.res_t = other; st.res_f = find_form(T[other], FORM_I32, 0, 0);
+                    }
                     const int dfl = T[nd.out].fl - T[other].fl;     // >0: residual shifts left
                     st.acc_shl = dfl < 0 ? -dfl : 0; st.res_shl = dfl > 0 ? dfl : 0;
                     st.relu1 = ad.relu;
@@ -727,15 +756,22 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 st.ops_per_img = 2.0 * opix * d.cout * (d.cin / d.groups) * d.kernel * d.kernel;
                 double b = (double)s.H * s.W * (nd.stem ? 4 : s.Cs);            // input once
                 if (st.res_t >= 0) b += opix * o.Cs * 4;
+                if (nd.dual >= 0) {
+                    const Node& g = ND[nd.dual];
+                    b += (double)T[g.a].H * T[g.a].W * T[g.a].Cs;
+                    st.ops_per_img += 2.0 * opix * g.cd.cout * g.cd.cin;
+                }
                 if (st.dense) b += (double)d.cout * 4;
                 if (st.out.f32 >= 0) b += opix * o.Cs * 4;
                 for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += opix * o.Cs;
                 st.bytes_per_img = b;
                 st.bytes_const = nd.depthwise ? (double)s.Cs * 13 : (double)nd.coutP * (nd.ktot + 4);
+                if (nd.dual >= 0) st.bytes_const += (double)ND[nd.dual].coutP * (ND[nd.dual].ktot + 4);
                 char buf[160];
                 if (nd.depthwise) snprintf(buf, sizeof buf, "dwconv3x3s%d:%s", d.stride, tname(net, nd.out).c_str());
                 else snprintf(buf, sizeof buf, "conv%dx%ds%d_t%dx%dx%d%s%s:%s", d.kernel, d.kernel, d.stride, nd.tile.bm, nd.tile.bn,
-                              nd.tile.bk, nd.stem ? "_stem" : "", st.res_t >= 0 ? "_res" : "", tname(net, nd.out).c_str());
+                              nd.tile.bk, nd.stem ? "_stem" : "", st.res_t >= 0 ? "_res" : (nd.dual >= 0 ? "_dual" : ""),
+                              (nd.dual >= 0 ? tname(net, ND[nd.dual].out) + "+" + tname(net, nd.out) : tname(net, nd.out)).c_str());
                 st.name = buf;
                 if (nd.depthwise) snprintf(buf, sizeof buf, "f8::dwconv3x3_dot4_kernel<%d, 2>", d.stride);
                 else {
@@ -743,9 +779,11 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     // keep in sync with launch_conv_t (f8_kernels.hip)
                     const int tile_b = (nd.tile.bm + nd.tile.bn) * nd.tile.bk;
                     const int dst = (4 * tile_b <= 65536) ? 4 : ((3 * tile_b <= 65536) ? 3 : 2);
-                    const int stages = (dst > 2 && nd.ktot / nd.tile.bk >= 16) ? dst : 2;     // ring depth rule of launch_conv_t
-                    snprintf(buf, sizeof buf, "f8::conv_igemm_kernel<%d, %d, %d, %d, %d, %s, %s, %d>", nd.tile.bm, nd.tile.bn, nd.tile.bk, wpx, wco,
-                             (d.pad > 0 && !nd.stem) ? "true" : "false", st.res_t >= 0 ? "true" : "false", stages);
+                    const int ksteps = (nd.ktot + (nd.dual >= 0 ? ND[nd.dual].ktot : 0)) / nd.tile.bk;
+                    const int stages = (dst > 2 && ksteps >= 16) ? dst : 2;     // ring depth rule of launch_conv_t
+                    snprintf(buf, sizeof buf, "f8::conv_igemm_kernel<%d, %d, %d, %d, %d, %s, %s, %d, %s>", nd.tile.bm, nd.tile.bn, nd.tile.bk, wpx, wco,
+                             (d.pad > 0 && !nd.stem) ? "true" : "false", (st.res_t >= 0 || nd.dual >= 0) ? "true" : "false", stages,
+                             nd.dual >= 0 ? "true" : "false");
                 }
                 st.kernel = buf;
                 break;
@@ -803,6 +841,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         Step& st = net->steps[si];
         touch(st.src_t, st.src_f, (int)si);
         touch(st.res_t, st.res_f, (int)si);
+        touch(st.src2_t, st.src2_f, (int)si);
         if (st.out.t >= 0 && !st.dense) {
             touch(st.out.t, st.out.f32, (int)si);
             touch(st.out.t, st.out.f8[0], (int)si);
@@ -1001,6 +1040,15 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             }
             a.relu0 = st.relu0;
             if (st.res_t >= 0) { a.res = (const int32_t*)fp(T[st.res_t].forms[st.res_f]); a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1; }
+            if (nd.dual >= 0) {
+                const Node& g = net->nodes[nd.dual];
+                const Tensor& s2 = T[st.src2_t]; const Form& F2 = s2.forms[st.src2_f];
+                a.x2 = (const int8_t*)fp(F2); a.x2_bytes = (uint32_t)(F2.bytes_per_img * N);
+                a.w2 = (const int8_t*)(net->d_w + g.w_off); a.w2_bytes = (uint32_t)((size_t)g.coutP * g.ktot);
+                a.bias2 = (const int32_t*)(net->d_w + g.b_off);
+                a.sN2 = s2.H * s2.W * s2.Cs; a.sP2 = g.cd.stride * s2.W * s2.Cs; a.sQ2 = g.cd.stride * s2.Cs; a.ktot2 = g.ktot;
+                a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1;
+            }
             fill_out(&a.out32, a.q);
             e = launch_conv(a, nd.tile, s);
             break;

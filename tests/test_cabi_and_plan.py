@@ -79,9 +79,9 @@ def test_run_without_gpu_fails_loudly():
     assert rc < 0 and b'hip' in _lib.lib().f8_last_error().lower()
 
 
-@pytest.mark.parametrize('arch,launches,fused', [('resnet18', 25, 0), ('resnet50', 48, 5), ('mobilenet_v1', 31, 0),
-                                                  ('mobilenet_v2', 56, 0)])
-def test_plan_fuses_requant_relu_residual(arch, launches, fused):
+@pytest.mark.parametrize('arch,launches,fused,dual', [('resnet18', 25, 0, 0), ('resnet50', 44, 5, 4), ('mobilenet_v1', 31, 0, 0),
+                                                       ('mobilenet_v2', 56, 0, 0)])
+def test_plan_fuses_requant_relu_residual(arch, launches, fused, dual):
     spec = topology.get(arch)
     net = build_net(spec, synth.make_params(spec, 1), max_batch=8, hw=224)
     plan = net.describe()
@@ -90,8 +90,10 @@ def test_plan_fuses_requant_relu_residual(arch, launches, fused):
     assert 'add:' not in plan and 'requant:' not in plan
     # bottleneck identity blocks of stages 0-1 run as ONE launch each (1x1 -> 3x3 -> 1x1 + residual)
     assert plan.count('fused_bottleneck') == fused
+    # bottleneck downsample blocks: body.4 and the shortcut conv are ONE dual-GEMM launch (no int32 tensor between them)
+    assert plan.count('_dual:') == dual
     n_res_blocks = sum(1 for b in spec.blocks if b.residual)
-    assert plan.count('_res:') + fused == n_res_blocks
+    assert plan.count('_res:') + plan.count('_dual:') + fused == n_res_blocks
     assert net.weight_bytes > 0 and net.arena_bytes > 0
 
 
@@ -101,8 +103,12 @@ def test_plan_keeps_int32_only_where_semantics_need_it():
     lines = net.describe().splitlines()
     body0 = [l for l in lines if '.body.0 ' in l or '.body.2 ' in l]
     assert body0 and all('i32=0' in l for l in body0)          # inside a block: int8 only
-    res = [l for l in lines if '_res:' in l or 'fused_bottleneck' in l]
+    res = [l for l in lines if '_res:' in l or '_dual:' in l or 'fused_bottleneck' in l]
     assert len(res) == 16
+    # the int32 residual stream exists only where an identity block follows (a downsample block's convs read int8)
+    assert sum('i32=0' in l for l in res) == 3
+    # downsample blocks: no int32 tensor between body.4 and the shortcut conv (one dual-GEMM launch)
+    assert not any('.body.4 ' in l and '_res' not in l for l in lines)
     # the stem emits int8 straight into an int8 max-pool (requant commutes with max)
     assert any('maxpool_i8' in l for l in lines)
     # algorithmic bytes are reported per launch and sum to less than the structural model
