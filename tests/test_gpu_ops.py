@@ -192,3 +192,53 @@ def test_fused_bottleneck_block_matches_oracle(dev, shape, variant):
     want, want_fl = oracle.block_forward(b, params, x, x_fl)
     assert net.output_fraclen == want_fl
     np.testing.assert_array_equal(got, want)
+
+
+DUAL_SHAPES = [(64, 64, 256, 1, 24, 24, 3), (256, 128, 512, 2, 28, 28, 2), (128, 64, 96, 2, 15, 15, 2)]   # Cin, MID, Cout, stride, H, W, N
+
+
+@pytest.mark.parametrize('shape', DUAL_SHAPES, ids=lambda g: 'x'.join(map(str, g)))
+@pytest.mark.parametrize('variant', ['body_shifts_left', 'shortcut_shifts_left'])
+def test_downsample_block_dual_gemm_matches_oracle(dev, shape, variant):
+    """A bottleneck downsample block (fix_resnet.py:26-77 with a shortcut conv): body.4 and shortcut.0 are planned as
+    ONE dual-GEMM launch; the int32 block output must equal the oracle's IntBlock.forward, wrap and clamp included."""
+    from f8net_amd import topology
+    from f8net_amd.net import F8Net
+    Cin, MID, Cout, stride, H, W, N = shape
+    body = [topology.ConvSpec('blk.body.0', Cin, MID, 1, 1, 0, relu=True),
+            topology.ConvSpec('blk.body.2', MID, MID, 3, stride, 1, relu=True),
+            topology.ConvSpec('blk.body.4', MID, Cout, 1, 1, 0)]
+    sc = topology.ConvSpec('blk.shortcut.0', Cin, Cout, 1, stride, 0)
+    b = topology.BlockSpec('blk', body, sc, residual=True, post_relu=True)
+    if variant == 'body_shifts_left':
+        fls = {'blk.body.0': (4, 7), 'blk.body.2': (3, 6), 'blk.body.4': (3, 5), 'blk.shortcut.0': (5, 7)}     # 8 vs 12
+    else:
+        fls = {'blk.body.0': (4, 7), 'blk.body.2': (3, 6), 'blk.body.4': (6, 7), 'blk.shortcut.0': (4, 6)}     # 13 vs 10
+    x_fl = 9
+    params = {}
+    for c in body + [sc]:
+        in_fl, w_fl = fls[c.key]
+        params[c.key + '.weight'] = np.clip(synth.rand_normal_int(15, c.key + 'w' + variant, (c.cout, c.cin, c.k, c.k), 50.0), -127, 127).astype(np.int32)
+        params[c.key + '.bias'] = synth.rand_normal_int(16, c.key + 'b', (c.cout,), 2.0 ** 27).astype(np.int32)   # joins wrap / clamp
+        params[c.key + '.weight_fraclen'] = np.array(w_fl, np.int32)
+        params[c.key + '.input_fraclen'] = np.array([in_fl], np.int32)
+    x = synth.rand_normal_int(17, 'dsx' + variant, (N, Cin, H, W), 2.0e3).astype(np.int32)
+    net = F8Net()
+    t = net.input(Cin, H, W, x_fl)
+    r = t
+    for c in body:
+        r = net.conv(r, params[c.key + '.weight'], params[c.key + '.bias'], stride=c.stride, pad=c.pad, groups=1,
+                     weight_fl=fls[c.key][1], input_fl=fls[c.key][0], input_signed=c.signed_in, quant_input=True, relu=c.relu)
+    s = net.conv(t, params[sc.key + '.weight'], params[sc.key + '.bias'], stride=stride, pad=0, groups=1,
+                 weight_fl=fls[sc.key][1], input_fl=fls[sc.key][0], input_signed=sc.signed_in, quant_input=True, relu=False)
+    r = net.add(r, s, relu=True)
+    net.output(r, as_float=False)
+    net.finalize(N)
+    plan = net.describe()
+    assert ('_dual:' in plan) == (Cin % 64 == 0 and MID % 64 == 0 and Cout > 32), plan
+    P, Q = (H - 1) // stride + 1, (W - 1) // stride + 1
+    got = net.run(_t(x, dev)).cpu().numpy().reshape(N, Cout, P, Q)
+    want, want_fl = oracle.block_forward(b, params, x, x_fl)
+    assert net.output_fraclen == want_fl
+    np.testing.assert_array_equal(got, want)
+    assert (np.abs(want.astype(np.int64)) > 2**30).any()       # the join ran at full int32 width (wrap-around arithmetic)
