@@ -88,6 +88,18 @@ __device__ __forceinline__ int clamp_sym31(int v) {   // clamp_(max=2^31-1, min=
 // i.e. x - 128 as int8) and the zero padding (biased 0 == real 128) is repaired by a per-border-class
 // bias: bias[class][cout] = b + 128 * sum over the class's in-image taps of w  (host: pack_conv_weights).
 // ---------------------------------------------------------------------------------------------
+// XOR swizzle of an LDS image made of ROWB-byte rows (ROWB a power of two >= 64... or any multiple of 256):
+// 16-byte chunk c of row r is stored at chunk c ^ f(r), so that the 16 lanes of a ds_read_b128 service group
+// (consecutive rows, same logical chunk) cover all 64 banks.
+template <int ROWB> struct Swz {                       // LDS bank rows are 256 bytes
+    static constexpr int CPR = ROWB / 16;
+    static __device__ __forceinline__ int f(int row) {
+        if (ROWB >= 256) return row % 16;               // a row spans whole bank rows: spread rows over the 16 slots
+        return (row / (256 / ROWB)) % CPR;
+    }
+    static __device__ __forceinline__ unsigned off(int row, int chunk) { return (unsigned)(row * ROWB + ((chunk ^ f(row)) << 4)); }
+};
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
 }  // namespace f8

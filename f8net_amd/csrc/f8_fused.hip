@@ -31,15 +31,6 @@
 
 namespace f8 {
 
-template <int ROWB> struct Swz {                       // rows of ROWB bytes; LDS bank rows are 256 bytes
-    static constexpr int CPR = ROWB / 16;
-    static __device__ __forceinline__ int f(int row) {
-        if (ROWB >= 256) return row % 16;               // a row spans whole bank rows: spread rows over the 16 slots
-        return (row / (256 / ROWB)) % CPR;
-    }
-    static __device__ __forceinline__ unsigned off(int row, int chunk) { return (unsigned)(row * ROWB + ((chunk ^ f(row)) << 4)); }
-};
-
 template <int C, int MID, int W, int R>
 struct FusedCfg {
     static constexpr int PW = W + 2, PR = R + 2;

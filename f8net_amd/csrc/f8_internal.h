@@ -119,6 +119,9 @@ int  conv_grid(const ConvTile& t, int M, int coutP);
 hipError_t launch_conv(const ConvArgs& a, const ConvTile& t, hipStream_t s);
 hipError_t launch_fused_bottleneck(const FusedArgs& a, hipStream_t s);
 bool fused_bottleneck_supported(int C, int MID, int H, int W, int* R);
+// 3x3 / stride 1 / pad 1 with the input patch resident in LDS (f8_conv3x3.hip); config = false: no instance
+bool conv3x3_patch_config(int cin, int H, int W, int coutP, int* R, int* IMGS, int* BN);
+hipError_t launch_conv3x3_patch(const ConvArgs& a, int cin, hipStream_t s);
 hipError_t launch_dwconv(const DwArgs& a, hipStream_t s);
 hipError_t launch_maxpool(const PoolArgs& a, hipStream_t s);
 hipError_t launch_avgpool(const AvgArgs& a, hipStream_t s);

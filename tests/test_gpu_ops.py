@@ -89,6 +89,13 @@ CONV_GEOMS = [
     (2, 144, 9, 9, 144, 3, 2, 1, 144, False),  # depthwise stride 2, C=144
     (2, 24, 8, 8, 24, 3, 1, 1, 24, True),      # depthwise signed input
     (130, 64, 4, 4, 64, 1, 1, 0, 1, False),    # many images, tiny maps
+    # shapes served by the LDS-patch 3x3 kernel (f8_conv3x3.hip)
+    (3, 64, 56, 56, 64, 3, 1, 1, 1, False),    # 2 rows per tile
+    (2, 128, 28, 28, 128, 3, 1, 1, 1, True),   # 4 rows per tile, signed input (single bias class)
+    (3, 256, 14, 14, 256, 3, 1, 1, 1, False),  # half an image per tile
+    (2, 256, 14, 14, 96, 3, 1, 1, 1, False),   # cout 96: partial 128-wide cout tile
+    (5, 512, 7, 7, 512, 3, 1, 1, 1, False),    # two images per tile, odd image count
+    (2, 64, 28, 56, 192, 3, 1, 1, 1, False),   # H != W
 ]
 
 
