@@ -33,7 +33,10 @@ struct PatchCfg {
     static constexpr int PATCH_BYTES = PL * 8192;               // whole wave pieces (tail slots are written as zeros)
     static constexpr int W_BYTES = BN * KB;                     // one weight stage: KB bytes of K for BN couts
     static constexpr int NS = 3;                                // weight ring depth (tools/ubench_ldsdma: 3 == 4 > 8)
-    static constexpr int LDS_BYTES = PATCH_BYTES + NS * W_BYTES;
+    // K-split exchange buffer (reuses the patch / ring space): every wave parks the partial sums of the tiles it
+    // does not finish itself: 8 waves x (4 - 4/KS) tiles x 4 KB, KS = 8 / (BN / 32)
+    static constexpr int RED_BYTES = 8 * (4 - 4 / (8 / (2 * (BN / 64)))) * 4096;
+    static constexpr int LDS_BYTES = PATCH_BYTES + NS * W_BYTES > RED_BYTES ? PATCH_BYTES + NS * W_BYTES : RED_BYTES;
     static constexpr int NK = 9 * CIN / KB;
     static_assert((9 * CIN) % KB == 0 && (KB == 64 || KB == 128 || KB == 256), "stage width");
     static constexpr int CMW = BN / 64;                         // cout tiles per wave
@@ -48,9 +51,15 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(const ConvArgs a) {
     using Cfg = PatchCfg<CIN, W, R, IMGS, BN, KB>;
     constexpr int PW = Cfg::PW, IMG_PX = Cfg::IMG_PX, OUT_PX = Cfg::OUT_PX, CPR = Cfg::CPR;
     constexpr int PSLOTS = Cfg::PSLOTS, PL = Cfg::PL, PATCH_BYTES = Cfg::PATCH_BYTES, W_BYTES = Cfg::W_BYTES;
-    constexpr int NS = Cfg::NS, NK = Cfg::NK, CMW = Cfg::CMW;
+    constexpr int NS = Cfg::NS, NK = Cfg::NK;
     constexpr int WS = BN * KB / 16;                            // 16-byte slots of a weight stage
     constexpr int WL = (WS + 511) / 512, WCPR = KB / 16;
+    // Wave roles.  The workgroup tile is 4 pixel tiles x NCO cout tiles of 32x32.  A wave accumulates a 2x2 BLOCK
+    // of them (two x fragments + two w fragments from LDS feed four MFMAs: LDS read bandwidth, 128 B/clk per CU,
+    // is what bounds one-tile-per-wave schemes), and the KS waves that share a block split the K slices of every
+    // stage between them; their partial sums meet in LDS after the loop (integer adds: order-free, exact).
+    constexpr int NCO = BN / 32, NB = 2 * (NCO / 2), KS = 8 / NB, NSL = KB / 32, NF = 4 / KS;
+    static_assert(NCO == 2 || NCO == 4, "cout tiles");
     using SK = Swz<KB>;
     using SC = Swz<CIN>;
 
@@ -61,8 +70,12 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(const ConvArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;
-    const int wa = wave >> 1, wb = wave & 1;                    // pixel tile (0..3), cout group (0..1)
+    const int blk = wave % NB, ks = wave / NB;                  // 2x2 block, K-split index
+    const int bp = blk & 1, bc = blk >> 1;                      // pixel-tile pair, cout-tile pair
     const int l31 = lane & 31, lh = lane >> 5;
+    // tiles this wave finishes in the epilogue: pixel tile fpx, cout tiles fco .. fco + NF - 1
+    const int fpx = 2 * bp + (ks & 1);
+    const int fco = 2 * bc + (KS == 4 ? (ks >> 1) : 0);
 
     // ---- tile: XCD-aware order, cout tile fastest (the workgroups sharing a patch sit on one XCD's L2)
     const int tilesN = (a.coutP + BN - 1) / BN;
@@ -89,49 +102,29 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(const ConvArgs a) {
 #else
 #define F8_TT(i)
 #endif
-    // ---- this lane's output pixel
-    const int opix = wa * 32 + l31;
+    // patch pixel of tap (0,0) for output pixel `op` of the tile (padding lanes: a valid pixel, result unused)
+    auto patch_px = [&](int op, int* row, int* col) {
+        const int oc = op < OUT_PX ? op : OUT_PX - 1;
+        const int oimg = oc / (R * W), orem = oc - oimg * (R * W);
+        const int orow = orem / W, ocol = orem - orow * W;
+        *row = orow; *col = ocol;
+        return oimg * IMG_PX + orow * PW + ocol;
+    };
+    int dr, dc;
+    const int bpxA = patch_px((2 * bp) * 32 + l31, &dr, &dc);   // main loop: pixel tiles 2bp, 2bp + 1
+    const int bpxB = patch_px((2 * bp + 1) * 32 + l31, &dr, &dc);
+    // epilogue pixel of this lane
+    const int opix = fpx * 32 + l31;
     const bool opix_ok = opix < live_px;
     const int m = m_tile + opix;
-    const int oc = opix < OUT_PX ? opix : OUT_PX - 1;           // padding lanes compute on a valid patch pixel
-    const int oimg = oc / (R * W), orem = oc - oimg * (R * W);
-    const int orow = orem / W, ocol = orem - orow * W;
-    const int bpx = oimg * IMG_PX + orow * PW + ocol;           // patch pixel of tap (0,0)
+    int orow, ocol;
+    (void)patch_px(opix, &orow, &ocol);
 
-    // ---- oldest VMEM first: residual operand, then the class biases (in-order return: nothing the epilogue
-    //      needs may queue behind the DMA stream)
-    v4i rv[HAS_RES ? CMW : 1][4];
-    if (HAS_RES) {
-        const int mc = opix_ok ? m : m_tile;
-#pragma unroll
-        for (int i = 0; i < CMW; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = co0 + (wb * CMW + i) * 32 + 8 * g + 4 * lh;
-                v4i z = {0, 0, 0, 0};
-                rv[i][g] = (c < a.coutP) ? *(const v4i*)(a.res + i32t_index(mc, c, a.coutP)) : z;
-            }
-    }
-    v4i bq[CMW][4];
-    {
-        const int32_t* bias = a.bias;
-        if (a.ncc > 0) {
-            const int p = p0 + orow;                             // IMGS > 1: p0 == 0
-            bias += (size_t)((int)a.rowcls[p] * a.ncc + (int)a.colcls[ocol]) * (size_t)a.coutP;
-        }
-#pragma unroll
-        for (int i = 0; i < CMW; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = co0 + (wb * CMW + i) * 32 + 8 * g + 4 * lh;
-                v4i z = {0, 0, 0, 0};
-                bq[i][g] = (c < a.coutP) ? *(const v4i*)(bias + c) : z;
-            }
-    }
-    asm volatile("" ::: "memory");
+    // border class of this lane's pixel: two dependent byte loads, requested first and consumed after the DMA issue
+    int cls_r = 0, cls_c = 0;
+    if (a.ncc > 0) { cls_r = a.rowcls[p0 + orow]; cls_c = a.colcls[ocol]; }   // IMGS > 1: p0 == 0
 
     // ---- patch: every 16-byte slot once
-    int my_pl = 0;
 #pragma unroll
     for (int i = 0; i < PL; ++i) {
         const int s = tid + i * 512;
@@ -141,12 +134,9 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(const ConvArgs a) {
         const int h = p0 - 1 + pr, w = pc - 1, n = n0 + img;
         const bool ok = s < PSLOTS && h >= 0 && h < a.H && w >= 0 && w < W && n < NIMG;
         const unsigned off = ok ? (unsigned)(((n * a.H + h) * W + w) * CIN + ((phys ^ SC::f(ppx)) << 4)) : kOOB;
-        if ((i * 512 + wave * 64) < PSLOTS) {                   // wave-uniform
+        if ((i * 512 + wave * 64) < PSLOTS)                     // wave-uniform
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(patch + i * 8192 + wave * 1024), 16, off, 0, 0, 0);
-            ++my_pl;
-        }
     }
-    (void)my_pl;
 
     // ---- weight ring: stage j = bytes [j*KB, j*KB + KB) of BN cout rows (K is tap-major, then channel)
     unsigned wbs[WL];
@@ -168,61 +158,185 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(const ConvArgs a) {
         }
     };
 #pragma unroll
-    for (int st = 0; st < NS - 1; ++st)
+    for (int st = 0; st < NS; ++st)
         if (st < NK) issue_w(st, st);
+    asm volatile("" ::: "memory");
+
+    // ---- residual operand and class biases: behind the prologue DMA in the (in-order) VMEM queue, which only
+    //      makes the first counted waits conservative; they are consumed after the K loop
+    v4i rv[HAS_RES ? NF : 1][4];
+    if (HAS_RES) {
+        const int mc = opix_ok ? m : m_tile;
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = co0 + (fco + i) * 32 + 8 * g + 4 * lh;
+                v4i z = {0, 0, 0, 0};
+                rv[i][g] = (c < a.coutP) ? *(const v4i*)(a.res + i32t_index(mc, c, a.coutP)) : z;
+            }
+    }
+    v4i bq[NF][4];
+    {
+        const int32_t* bias = a.bias;
+        bias += (size_t)(cls_r * a.ncc + cls_c) * (size_t)a.coutP;      // ncc == 0: single class
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = co0 + (fco + i) * 32 + 8 * g + 4 * lh;
+                v4i z = {0, 0, 0, 0};
+                bq[i][g] = (c < a.coutP) ? *(const v4i*)(bias + c) : z;
+            }
+    }
 
     F8_TT(1);
-    v16i acc[CMW];
+    v16i acc[2][2];                                             // [cout tile of the pair][pixel tile of the pair]
 #pragma unroll
-    for (int i = 0; i < CMW; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0;
-    constexpr int CH = CIN / 64;                                // 64-byte channel chunks per tap
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+    constexpr int CH = CIN / 64;                                // 64-byte channel pieces per tap
     constexpr int SUB = KB / 64;                                // 64-byte K pieces per stage
-    int tr = 0, ts = 0, tc = 0;
-    for (int j = 0; j < NK; ++j) {
-        // stage j (and, at j == 0, the patch issued before it) landed; up to NS-2 later stages stay in flight
-        const int ahead = (NK - 1 - j) < (NS - 2) ? (NK - 1 - j) : (NS - 2);
+    constexpr int NQ = (NSL / KS) > 0 ? (NSL / KS) : 1;         // K slices of a stage this wave owns
+    const int wf_sw = SK::f(l31);                               // == f(row) for both rows (row = 32k + l31, 32 % 16 == 0)
+    struct Frag { v4i xa, xb, w0, w1; };
+    // The fragments of stage j+1 are fetched from LDS WHILE the MFMAs of stage j run (register double buffer):
+    // with one barrier per stage, read-then-multiply inside a stage would serialise the LDS latency, the LDS
+    // transfer (1 KB per MFMA) and the matrix pipe on every step.
+    auto read_frags = [&](int j, Frag (&f)[NQ]) {
+        const char* base = ring + (j % NS) * W_BYTES;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = ks + i * KS;                          // this wave's 32-byte K slice of the stage
+            if (q < NSL) {                                      // wave-uniform (only the CIN = 64 shape has idle waves)
+                const int u = q >> 1, kk = q & 1;
+                const int piece = j * SUB + u;                  // 64-byte K piece: tap = piece / CH, channel piece = piece % CH
+                const int tap = piece / CH, tc = piece - tap * CH;
+                const int tr = (tap * 11) >> 5, ts = tap - tr * 3;        // tap / 3 for tap < 9
+                const int xch = tc * 4 + kk * 2 + lh;
+                f[i].xa = *(const v4i*)(patch + SC::off(bpxA + tr * PW + ts, xch));
+                f[i].xb = *(const v4i*)(patch + SC::off(bpxB + tr * PW + ts, xch));
+                const unsigned wch = (unsigned)(((u * 4 + kk * 2 + lh) ^ wf_sw) << 4);
+                f[i].w0 = *(const v4i*)(base + ((2 * bc) * 32 + l31) * KB + wch);
+                f[i].w1 = *(const v4i*)(base + ((2 * bc + 1) * 32 + l31) * KB + wch);
+            }
+        }
+    };
+    auto stage = [&](int j, Frag (&cur)[NQ], Frag (&nxt)[NQ]) {
+        // stage j+1 landed (its fragments are read below); up to NS-2 later stages stay in flight
+        const int rem = NK - 2 - j;                             // stages after j+1
+        const int ahead = rem < 0 ? 0 : (rem < (NS - 2) ? rem : (NS - 2));
         const int nfl = ahead * ldw;
         if (nfl == 0) wait_vmcnt<0>();
         else if (nfl == 1) wait_vmcnt<1>();
         else wait_vmcnt<2>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // `cur` is in registers; every wave is done with slot j % NS
+        __builtin_amdgcn_s_barrier();
+        if (j + NS < NK) issue_w(j + NS, j % NS);
+        if (j + 1 < NK) read_frags(j + 1, nxt);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            if (ks + i * KS < NSL) {
+                acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur[i].w0, cur[i].xa, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur[i].w0, cur[i].xb, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur[i].w1, cur[i].xa, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur[i].w1, cur[i].xb, acc[1][1], 0, 0, 0);
+            }
+        }
+    };
+    Frag fa[NQ], fb[NQ];
+    // prologue: patch + stage 0 landed everywhere, then this wave's stage-0 fragments
+    {
+        const int inflight = ((NK < NS ? NK : NS) - 1) * ldw;
+        if (inflight == 0) wait_vmcnt<0>();
+        else if (inflight == 1) wait_vmcnt<1>();
+        else if (inflight == 2) wait_vmcnt<2>();
+        else if (inflight == 3) wait_vmcnt<3>();
+        else wait_vmcnt<4>();
         __builtin_amdgcn_s_barrier();
 #ifdef F8_TRACE
-        if (j == 0) tt[2] = __builtin_readcyclecounter();
+        tt[2] = __builtin_readcyclecounter();
 #endif
-        if (j + NS - 1 < NK) issue_w(j + NS - 1, (j + NS - 1) % NS);
-        const char* base = ring + (j % NS) * W_BYTES;
+        read_frags(0, fa);
+    }
+    for (int j = 0; j < NK; j += 2) {
+        stage(j, fa, fb);
+        if (j + 1 < NK) stage(j + 1, fb, fa);
+    }
+    F8_TT(3);
+
+    // ---- K-split exchange through LDS (patch / ring are dead now): a wave keeps the partial sums of the NF tiles it
+    //      finishes in registers, parks the other 4 - NF tiles of its block at park[wave][slot], and adds its
+    //      partners' parked partials of its own tiles.  Block tile index = 2 * (cout of pair) + (pixel of pair).
+    v4i* const park = (v4i*)lds;
+    constexpr int NPARK = 4 - NF;
+    auto park_at = [&](int w, int slot, int g) { return park + ((w * NPARK + slot) * 4 + g) * 64 + lane; };
+    // tiles finished by K-split member k of a block: KS == 2: pixel k, couts 0 and 1; KS == 4: pixel k & 1, cout k >> 1
+    auto owner = [&](int i, int j) { return KS == 2 ? j : (2 * i + j); };     // i = cout of pair, j = pixel of pair
+    // parking slot of tile (i, j) in a non-owner's area: rank of the tile among those that wave does not own
+    auto slot_of = [&](int k, int i, int j) {
+        int sl = 0;
+        for (int ii = 0; ii < 2; ++ii)
+            for (int jj = 0; jj < 2; ++jj) {
+                if (ii == i && jj == j) return sl;
+                if (owner(ii, jj) != k) ++sl;
+            }
+        return sl;
+    };
+    __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int u = 0; u < SUB; ++u) {
-            const int ppx = bpx + tr * PW + ts;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const v4i xf = *(const v4i*)(patch + SC::off(ppx, tc * 4 + kk * 2 + lh));
+        for (int j = 0; j < 2; ++j) {
 #pragma unroll
-                for (int i = 0; i < CMW; ++i) {
-                    const v4i wf = *(const v4i*)(base + SK::off((wb * CMW + i) * 32 + l31, u * 4 + kk * 2 + lh));
-                    acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, xf, acc[i], 0, 0, 0);
+            for (int k = 0; k < KS; ++k) {
+                if (k == ks && owner(i, j) != k) {              // wave-uniform
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        v4i v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                        *park_at(wave, slot_of(k, i, j), g) = v;
+                    }
                 }
             }
-            if (++tc == CH) { tc = 0; if (++ts == 3) { ts = 0; ++tr; } }
         }
-    }
-
-    F8_TT(3);
-    // ---- epilogue
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    v4i fin[NF][4];                                             // finished accumulators of this wave's tiles
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                if (k == ks && owner(i, j) == k) {              // wave-uniform: one of my tiles
+                    const int f = KS == 2 ? i : 0;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        v4i v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+#pragma unroll
+                        for (int o = 0; o < KS; ++o)
+                            if (o != k) v += *park_at(blk + o * NB, slot_of(o, i, j), g);
+                        fin[f][g] = v;
+                    }
+                }
+            }
+        }
+    // ---- epilogue on this wave's NF tiles
     const int floor0 = a.relu0 ? 0 : INT32_MIN, floor1 = a.relu1 ? 0 : INT32_MIN;
 #pragma unroll
-    for (int i = 0; i < CMW; ++i) {
-        const int cot = co0 + (wb * CMW + i) * 32;
+    for (int i = 0; i < NF; ++i) {
+        const int cot = co0 + (fco + i) * 32;
         if (cot >= a.coutP) continue;                           // wave-uniform
         int y[4][4];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                int v = max((int)((unsigned)acc[i][4 * g + e] + (unsigned)bq[i][g][e]), floor0);
+                int v = max((int)((unsigned)fin[i][g][e] + (unsigned)bq[i][g][e]), floor0);
                 if (HAS_RES) {
                     const unsigned s = ((unsigned)v << a.acc_shl) + ((unsigned)rv[i][g][e] << a.res_shl);
                     v = max(clamp_sym31((int)s), floor1);
@@ -306,7 +420,6 @@ static hipError_t launch_patch_t(const ConvArgs& a, hipStream_t s) {
 bool conv3x3_patch_config(int cin, int H, int W, int coutP, int* R, int* IMGS, int* BN) {
     static const int on = [] { const char* e = getenv("F8_PATCH3X3"); return e ? atoi(e) : 1; }();
     if (!on || coutP < 64) return false;
-    if (cin == 64 && W == 56 && H % 2 == 0) { *R = 2; *IMGS = 1; *BN = 64; return true; }
     if (cin == 128 && W == 28 && H % 4 == 0) { *R = 4; *IMGS = 1; *BN = 128; return true; }
     if (cin == 256 && W == 14 && H % 7 == 0) { *R = 7; *IMGS = 1; *BN = 128; return true; }
     if (cin == 512 && W == 7 && H == 7) { *R = 7; *IMGS = 2; *BN = 64; return true; }
@@ -314,7 +427,6 @@ bool conv3x3_patch_config(int cin, int H, int W, int coutP, int* R, int* IMGS, i
 }
 
 hipError_t launch_conv3x3_patch(const ConvArgs& a, int cin, hipStream_t s) {
-    if (cin == 64 && a.W == 56) return launch_patch_t<64, 56, 2, 1, 64, 64>(a, s);
     if (cin == 128 && a.W == 28) return launch_patch_t<128, 28, 4, 1, 128, 128>(a, s);
     if (cin == 256 && a.W == 14) return launch_patch_t<256, 14, 7, 1, 128, 128>(a, s);
     if (cin == 512 && a.W == 7) return launch_patch_t<512, 7, 7, 2, 64, 256>(a, s);

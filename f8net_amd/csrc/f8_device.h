@@ -94,8 +94,8 @@ __device__ __forceinline__ int clamp_sym31(int v) {   // clamp_(max=2^31-1, min=
 template <int ROWB> struct Swz {                       // LDS bank rows are 256 bytes
     static constexpr int CPR = ROWB / 16;
     static __device__ __forceinline__ int f(int row) {
-        if (ROWB >= 256) return row % 16;               // a row spans whole bank rows: spread rows over the 16 slots
-        return (row / (256 / ROWB)) % CPR;
+        if constexpr (ROWB >= 256) return row % 16;     // a row spans whole bank rows: spread rows over the 16 slots
+        else return (row / (256 / ROWB)) % CPR;
     }
     static __device__ __forceinline__ unsigned off(int row, int chunk) { return (unsigned)(row * ROWB + ((chunk ^ f(row)) << 4)); }
 };
