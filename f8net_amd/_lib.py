@@ -39,6 +39,8 @@ SYMBOLS = [
     ('f8_version', _i, []),
     ('f8_device_count', _i, []),
     ('f8_requant_i32', _i, [_vp, _vp, _sz, _i, _i, _i, _vp]),
+    ('f8_quantize_input_f32', _i, [_vp, _vp, _sz, _i, _i, _i, _vp]),
+    ('f8_topk_correct_f32', _i, [_vp, _vp, _i, _i, ctypes.POINTER(_i), _i, _vp, _vp]),
     ('f8_relu_i32', _i, [_vp, _sz, _vp]),
     ('f8_add_align_i32', _i, [_vp, _vp, _sz, _i, _i, ctypes.POINTER(_i), _vp]),
     ('f8_net_create', _vp, []),
@@ -60,6 +62,7 @@ SYMBOLS = [
     ('f8_net_upload', _i, [_vp]),
     ('f8_net_num_parts', _i, [_vp, _i]),
     ('f8_net_run', _i, [_vp, _vp, _vp, _i, _vp]),
+    ('f8_net_run_f32', _i, [_vp, _vp, _i, _vp, _i, _vp]),
     ('f8_net_run_profiled', _i, [_vp, _vp, _vp, _i, _vp, ctypes.POINTER(ctypes.c_float), _i]),
     ('f8_net_launch_info', _i, [_vp, _i, _i, ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_double),
                                 ctypes.POINTER(ctypes.c_double)]),

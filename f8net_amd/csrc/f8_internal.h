@@ -84,6 +84,7 @@ struct AddArgs {                           // standalone align-add (when it cann
 
 struct InArgs {                            // network input: int32 NCHW -> NHWC forms
     const int32_t* x; int32_t N, C, H, W;
+    const float* xf; float scale; int32_t qlo, qhi;   // fp32 images quantised on the fly (x unused): rint(xf * scale) clamped
     uint32_t xor8;                         // 0x80808080 when the int8 consumer format is unsigned (biased storage)
     int8_t* out8;  int32_t Cs8;            // NHWC int8 (Cs8-channel rows), or
     int8_t* stem;  int32_t Hp, Wp, pad;    // zero-haloed NHWC4 for the stem conv
@@ -128,6 +129,8 @@ hipError_t launch_avgpool(const AvgArgs& a, hipStream_t s);
 hipError_t launch_add(const AddArgs& a, hipStream_t s);
 hipError_t launch_input(const InArgs& a, hipStream_t s);
 hipError_t launch_output(const OutArgs& a, hipStream_t s);
+hipError_t launch_quantize_input(const float* x, int32_t* y, size_t n, float scale, int lo, int hi, hipStream_t s);
+hipError_t launch_topk_correct(const float* logits, const int64_t* target, int N, int C, const int* ks_dev, int nk, float* correct, hipStream_t s);
 hipError_t launch_requant_i32(const int32_t* src, int32_t* dst, size_t n, int sh, int lo, int hi, hipStream_t s);
 hipError_t launch_relu_i32(int32_t* x, size_t n, hipStream_t s);
 hipError_t launch_add_align_i32(int32_t* res, const int32_t* x, size_t n, int res_shl, int x_shl, hipStream_t s);

@@ -855,6 +855,39 @@ __global__ void __launch_bounds__(256) add_kernel(const AddArgs a) {
 
 // Network input: int32 NCHW -> zero-haloed NHWC4 int8 (stem) / NHWC int8 / NHWC int32.
 // One thread per (n, h, w); C planes are read coalesced along w.
+// Input quantisation of forward_loss (fix_train.py:683-692) on one fp32 value: rint(x * scale) (round half to even,
+// one IEEE multiply: 255 or 2^fl), clamped to [lo, hi] (normalize: +-127 or [0,255], fix_quant_ops.py:64-87;
+// the u8 path has no clamp in the reference: lo / hi = int32 range there).
+__device__ __forceinline__ int quant_in(float x, float scale, int lo, int hi) {
+    const float r = rintf(__fmul_rn(x, scale));
+    return (int)fminf(fmaxf(r, (float)lo), (float)hi);
+}
+
+__global__ void __launch_bounds__(256) quantize_input_kernel(const float* x, int32_t* y, size_t n, float scale, int lo, int hi) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = quant_in(x[i], scale, lo, hi);
+}
+
+// ImageNet scoring of forward_loss (fix_train.py:697-704): correct[k][n] = 1 if target n is among the k largest logits.
+// Rank of the target = #{logit > logit[target]} + #{logit == logit[target], index < target} (ties by lower index, the
+// order a stable descending sort gives); one wave per image.
+__global__ void __launch_bounds__(256) topk_correct_kernel(const float* logits, const int64_t* target, int N, int C, const int* ks, int nk, float* correct) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int t = (int)target[n];
+    const float* row = logits + (size_t)n * C;
+    const bool valid = t >= 0 && t < C;
+    const float lt = valid ? row[t] : 0.f;
+    int rank = 0;
+    for (int c = lane; c < C; c += 64) {
+        const float v = row[c];
+        rank += (v > lt || (v == lt && c < t)) ? 1 : 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) rank += __shfl_down(rank, off, 64);
+    if (lane == 0)
+        for (int k = 0; k < nk; ++k) correct[(size_t)k * N + n] = (valid && rank < ks[k]) ? 1.f : 0.f;
+}
+
 __global__ void __launch_bounds__(256) input_kernel(const InArgs a) {
     const size_t total = (size_t)a.N * a.H * a.W;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -863,22 +896,24 @@ __global__ void __launch_bounds__(256) input_kernel(const InArgs a) {
         size_t t = idx / a.W;
         const int h = (int)(t % a.H);
         const int n = (int)(t / a.H);
-        const int32_t* xp = a.x + ((size_t)n * a.C * a.H + h) * a.W + w;
+        const size_t pix0 = ((size_t)n * a.C * a.H + h) * a.W + w;
         const size_t plane = (size_t)a.H * a.W;
+        // fp32 images are quantised on the fly (f8_net_run_f32): the int32 tensor of the reference never exists
+        auto ld = [&](int c) { return a.xf ? quant_in(a.xf[pix0 + c * plane], a.scale, a.qlo, a.qhi) : a.x[pix0 + c * plane]; };
         if (a.stem) {
             int v[4] = {0, 0, 0, 0};
-            for (int c = 0; c < a.C; ++c) v[c] = xp[c * plane];
+            for (int c = 0; c < a.C; ++c) v[c] = ld(c);
             *(unsigned*)(a.stem + ((((size_t)n * a.Hp + h + a.pad) * a.Wp) + w + a.pad) * 4) = pack4(v[0], v[1], v[2], v[3]) ^ a.xor8;
         }
         if (a.out8) {
             int8_t* o = a.out8 + (((size_t)n * a.H + h) * a.W + w) * a.Cs8;
             const int8_t bx = (int8_t)(a.xor8 & 0xff);
-            for (int c = 0; c < a.C; ++c) o[c] = (int8_t)(xp[c * plane]) ^ bx;
+            for (int c = 0; c < a.C; ++c) o[c] = (int8_t)(ld(c)) ^ bx;
             for (int c = a.C; c < a.Cs8; ++c) o[c] = bx;
         }
         if (a.out32) {
             const int m = (n * a.H + h) * a.W + w;
-            for (int c = 0; c < a.Cs32; ++c) a.out32[i32t_index(m, c, a.Cs32)] = c < a.C ? xp[c * plane] : 0;
+            for (int c = 0; c < a.Cs32; ++c) a.out32[i32t_index(m, c, a.Cs32)] = c < a.C ? ld(c) : 0;
         }
     }
 }
@@ -1093,6 +1128,14 @@ hipError_t launch_add(const AddArgs& a, hipStream_t s) {
 }
 hipError_t launch_input(const InArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(input_kernel, dim3(grid_for((size_t)a.N * a.H * a.W)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_quantize_input(const float* x, int32_t* y, size_t n, float scale, int lo, int hi, hipStream_t s) {
+    hipLaunchKernelGGL(quantize_input_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, n, scale, lo, hi);
+    return hipGetLastError();
+}
+hipError_t launch_topk_correct(const float* logits, const int64_t* target, int N, int C, const int* ks_dev, int nk, float* correct, hipStream_t s) {
+    hipLaunchKernelGGL(topk_correct_kernel, dim3((N + 3) / 4), dim3(256), 0, s, logits, target, N, C, ks_dev, nk, correct);
     return hipGetLastError();
 }
 hipError_t launch_output(const OutArgs& a, hipStream_t s) {

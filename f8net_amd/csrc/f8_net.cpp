@@ -117,6 +117,9 @@ struct f8_net {
     hipEvent_t* events = nullptr; int n_events = 0;
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t aux_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t lag_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    const float* in_f32 = nullptr; float in_scale = 0.f; int in_lo = 0, in_hi = 0;   // set by f8_net_run_f32 for the duration of the call
+    // hipGraph of one whole run (both sub-batch streams), replayed while (input, output, N, stream) stay the same
+    hipGraphExec_t g_exec = nullptr; const void* g_in = nullptr; void* g_out = nullptr; int g_N = 0; hipStream_t g_stream = nullptr; int g_warm = 0;
 };
 
 namespace {
@@ -207,6 +210,28 @@ int f8_requant_i32(const int32_t* src, int32_t* dst, size_t n, int src_fl, int d
     hipError_t e = launch_requant_i32(src, dst, n, sh, is_signed ? -127 : 0, is_signed ? 127 : 255, (hipStream_t)stream);
     return e == hipSuccess ? F8_OK : hip_fail(e, "f8_requant_i32");
 }
+int f8_quantize_input_f32(const float* src, int32_t* dst, size_t n, int normalize, int fl, int is_signed, void* stream) {
+    if (normalize && (fl < 0 || fl > (is_signed ? 7 : 8)))
+        return fail(F8_ERR_INVALID, "f8_quantize_input_f32: fl %d outside [0,%d] (fix_quant_ops.py:66-71)", fl, is_signed ? 7 : 8);
+    if (n == 0) return F8_OK;
+    if (!src || !dst) return fail(F8_ERR_INVALID, "f8_quantize_input_f32: null pointer");
+    hipError_t e = normalize ? launch_quantize_input(src, dst, n, (float)(1 << fl), is_signed ? -127 : 0, is_signed ? 127 : 255, (hipStream_t)stream)
+                             : launch_quantize_input(src, dst, n, 255.f, INT32_MIN, INT32_MAX, (hipStream_t)stream);
+    return e == hipSuccess ? F8_OK : hip_fail(e, "f8_quantize_input_f32");
+}
+int f8_topk_correct_f32(const float* logits, const int64_t* target, int N, int classes, const int* ks, int nk, float* correct, void* stream) {
+    if (N < 0 || classes < 1 || nk < 1 || nk > 8 || !ks) return fail(F8_ERR_INVALID, "f8_topk_correct_f32: bad arguments");
+    for (int k = 0; k < nk; ++k) if (ks[k] < 1 || ks[k] > classes) return fail(F8_ERR_INVALID, "f8_topk_correct_f32: k=%d outside [1,%d]", ks[k], classes);
+    if (N == 0) return F8_OK;
+    if (!logits || !target || !correct) return fail(F8_ERR_INVALID, "f8_topk_correct_f32: null pointer");
+    // the k list is tiny and call-specific: it travels through a per-thread device scratch (8 ints)
+    static thread_local int* ks_dev = nullptr;
+    hipError_t e = hipSuccess;
+    if (!ks_dev && (e = hipMalloc((void**)&ks_dev, 8 * sizeof(int))) != hipSuccess) return hip_fail(e, "f8_topk_correct_f32: hipMalloc");
+    if ((e = hipMemcpyAsync(ks_dev, ks, nk * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream)) != hipSuccess) return hip_fail(e, "f8_topk_correct_f32: copy");
+    e = launch_topk_correct(logits, target, N, classes, ks_dev, nk, correct, (hipStream_t)stream);
+    return e == hipSuccess ? F8_OK : hip_fail(e, "f8_topk_correct_f32");
+}
 int f8_relu_i32(int32_t* x, size_t n, void* stream) {
     if (n == 0) return F8_OK;
     if (!x) return fail(F8_ERR_INVALID, "f8_relu_i32: null pointer");
@@ -237,6 +262,7 @@ void f8_net_destroy(f8_net* net) {
     for (int k = 0; k < 4; ++k) if (net->aux[k]) (void)hipStreamDestroy(net->aux[k]);
     for (int k = 0; k < 5; ++k) if (net->aux_ev[k]) (void)hipEventDestroy(net->aux_ev[k]);
     for (int k = 0; k < 4; ++k) if (net->lag_ev[k]) (void)hipEventDestroy(net->lag_ev[k]);
+    if (net->g_exec) (void)hipGraphExecDestroy(net->g_exec);
     delete net;
 }
 
@@ -1014,6 +1040,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
         case S_INPUT: {
             const Tensor& o = T[st.out.t];
             InArgs a{}; a.x = input + (size_t)n0 * o.C * o.H * o.W; a.N = N; a.C = o.C; a.H = o.H; a.W = o.W;
+            if (net->in_f32) { a.xf = net->in_f32 + (size_t)n0 * o.C * o.H * o.W; a.scale = net->in_scale; a.qlo = net->in_lo; a.qhi = net->in_hi; }
             for (auto& F : o.forms) {
                 if (F.kind == FORM_I8) { if (F.n == 0) { a.out8 = (int8_t*)fp(F); a.Cs8 = o.Cs; if (!F.sgn) a.xor8 = 0x80808080u; } }
                 else if (F.kind == FORM_I32) { a.out32 = (int32_t*)fp(F); a.Cs32 = o.Cs; }
@@ -1226,6 +1253,34 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
             if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
         }
     }
+    // F8_GRAPH=1: the second call with the same (input, output, N, stream) captures the launches below into a hipGraph
+    // (the aux streams join the capture through the fork event); later calls replay it with one hipGraphLaunch.
+    // The legacy null stream cannot be captured: the graph then lives on an internal stream fenced by events.
+    static const int use_graph = [] { const char* e = getenv("F8_GRAPH"); return e ? atoi(e) : 0; }();
+    bool capturing = false;
+    hipStream_t user_s = s;
+    auto graph_replay = [&]() -> int {
+        hipStream_t gs = user_s ? user_s : net->aux[3];
+        if (gs != user_s) { (void)hipEventRecord(net->aux_ev[0], user_s); (void)hipStreamWaitEvent(gs, net->aux_ev[0], 0); }
+        hipError_t e = hipGraphLaunch(net->g_exec, gs);
+        if (e != hipSuccess) return hip_fail(e, "hipGraphLaunch");
+        if (gs != user_s) { (void)hipEventRecord(net->aux_ev[4], gs); (void)hipStreamWaitEvent(user_s, net->aux_ev[4], 0); }
+        return F8_OK;
+    };
+    if (use_graph && parts <= 3 && !net->in_f32) {
+        const bool same = net->g_in == input && net->g_out == output && net->g_N == N && net->g_stream == user_s;
+        if (same && net->g_exec) return graph_replay();
+        if (!same) {
+            if (net->g_exec) { (void)hipGraphExecDestroy(net->g_exec); net->g_exec = nullptr; }
+            net->g_in = input; net->g_out = output; net->g_N = N; net->g_stream = user_s; net->g_warm = 0;
+        }
+        if (net->g_warm++ >= 1) {      // first call with a new key runs eagerly (one-time kernel attribute calls happen there)
+            s = user_s ? user_s : net->aux[3];
+            hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
+            if (e != hipSuccess) return hip_fail(e, "hipStreamBeginCapture");
+            capturing = true;
+        }
+    }
     (void)hipEventRecord(net->aux_ev[0], s);
     for (int k = 0; k < parts; ++k) (void)hipStreamWaitEvent(net->aux[k], net->aux_ev[0], 0);
     // optional stagger: sub-batch p starts only after sub-batch p-1 has finished its first `lag` launches, so that the
@@ -1234,7 +1289,10 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
     for (int i = 0; i < ns; ++i)
         for (int p = 0; p < parts; ++p) {
             rc = run_step(net, net->steps[i], input, output, cut[p], cut[p + 1] - cut[p], p, net->aux[p]);
-            if (rc) return rc;
+            if (rc) {
+                if (capturing) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(s, &g); if (g) (void)hipGraphDestroy(g); }
+                return rc;
+            }
             if (lag > 0 && i == lag - 1 && p + 1 < parts) {
                 if (!net->lag_ev[p]) (void)hipEventCreateWithFlags(&net->lag_ev[p], hipEventDisableTiming);
                 (void)hipEventRecord(net->lag_ev[p], net->aux[p]);
@@ -1244,6 +1302,15 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
     for (int k = 0; k < parts; ++k) {
         (void)hipEventRecord(net->aux_ev[1 + k], net->aux[k]);
         (void)hipStreamWaitEvent(s, net->aux_ev[1 + k], 0);
+    }
+    if (capturing) {
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamEndCapture(s, &g);
+        if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
+        e = hipGraphInstantiate(&net->g_exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) { net->g_exec = nullptr; return hip_fail(e, "hipGraphInstantiate"); }
+        return graph_replay();
     }
     return F8_OK;
 }
@@ -1256,6 +1323,32 @@ int f8_net_num_parts(const f8_net* net, int N) {
 
 int f8_net_run(f8_net* net, const int32_t* input, void* output, int N, void* stream) {
     return run_common(net, input, output, N, stream, nullptr, 0);
+}
+int f8_net_run_f32(f8_net* net, const float* images, int normalize, void* output, int N, void* stream) {
+    if (!net || !net->finalized) return fail(F8_ERR_STATE, "f8_net_run_f32: not finalized");
+    if (!images) return fail(F8_ERR_INVALID, "f8_net_run_f32: null pointer");
+    // the consumer format of the network input: fraclen of the input tensor, signedness of the conv(s) reading it
+    const Tensor& in = net->tensors[net->nodes[0].out];
+    int sgn = -1;
+    for (int c : in.consumers) {
+        const Node& nd = net->nodes[c];
+        if (nd.kind != N_CONV && nd.kind != N_LINEAR) return fail(F8_ERR_UNSUPPORTED, "f8_net_run_f32: the input must feed convolutions");
+        if (sgn >= 0 && sgn != (nd.cd.input_signed ? 1 : 0)) return fail(F8_ERR_UNSUPPORTED, "f8_net_run_f32: consumers disagree on signedness");
+        sgn = nd.cd.input_signed ? 1 : 0;
+    }
+    if (sgn < 0) return fail(F8_ERR_UNSUPPORTED, "f8_net_run_f32: the input has no consumer");
+    if (normalize) {
+        if (in.fl < 0 || in.fl > (sgn ? 7 : 8)) return fail(F8_ERR_INVALID, "f8_net_run_f32: input fraclen %d outside [0,%d]", in.fl, sgn ? 7 : 8);
+        net->in_scale = (float)(1 << in.fl); net->in_lo = sgn ? -127 : 0; net->in_hi = sgn ? 127 : 255;
+    } else {
+        if (in.fl != 8 || sgn) return fail(F8_ERR_INVALID, "f8_net_run_f32: normalize == 0 needs an unsigned input at fraclen 8 (fix_train.py:689-692), net has fl %d %s",
+                                           in.fl, sgn ? "signed" : "unsigned");
+        net->in_scale = 255.f; net->in_lo = 0; net->in_hi = 255;      // images are in [0,1] (asserted >= 0 by the reference); 8-bit storage
+    }
+    net->in_f32 = images;
+    const int rc = run_common(net, (const int32_t*)images, output, N, stream, nullptr, 0);
+    net->in_f32 = nullptr;
+    return rc;
 }
 int f8_net_run_profiled(f8_net* net, const int32_t* input, void* output, int N, void* stream, float* ms, int cap) {
     if (!ms) return fail(F8_ERR_INVALID, "f8_net_run_profiled: null ms");

@@ -113,6 +113,12 @@ class IntModel(nn.Module):
         assert x.shape[2] == x.shape[3], 'square inputs'
         return self.plan(int(x.shape[2]), int(x.shape[0])).run(x.contiguous())
 
+    def forward_f32(self, images, normalize=False):
+        """forward_loss's input quantisation (fix_train.py:683-692) fused into the input kernel: `images` is the
+        float32 batch the data loader yields; no int32 copy of it is ever written."""
+        assert images.shape[2] == images.shape[3], 'square inputs'
+        return self.plan(int(images.shape[2]), int(images.shape[0])).run_f32(images.contiguous(), normalize)
+
     def _load_from_state_dict(self, *a, **k):
         super()._load_from_state_dict(*a, **k)
         self._plans = {}

@@ -162,6 +162,28 @@ class F8Net:
             check(self._L.f8_net_run(self._h, x.data_ptr(), out.data_ptr(), N, ctypes.c_void_p(stream)))
         return out
 
+    def run_f32(self, images, normalize, out=None):
+        """images: float32 CUDA tensor [N,C,H,W] as forward_loss receives them (fix_train.py:676-692); the input
+        quantisation runs inside the input kernel.  normalize: FLAGS.normalize of the reference."""
+        import torch
+        if not images.is_cuda:
+            raise ValueError('F8Net.run_f32: input must be a CUDA/HIP tensor (there is no CPU path)')
+        if images.dtype != torch.float32 or not images.is_contiguous():
+            raise ValueError('F8Net.run_f32: input must be contiguous float32 NCHW')
+        if tuple(images.shape[1:]) != tuple(self.in_shape):
+            raise ValueError(f'F8Net.run_f32: input shape {tuple(images.shape)} != [N,{self.in_shape}]')
+        N = images.shape[0]
+        if not (1 <= N <= self.max_batch):
+            raise ValueError(f'F8Net.run_f32: batch {N} outside [1,{self.max_batch}]')
+        if out is None:
+            out = torch.empty((N, self.out_elems), dtype=torch.float32 if self.out_float else torch.int32,
+                              device=images.device)
+        stream = torch.cuda.current_stream(images.device).cuda_stream
+        with torch.cuda.device(images.device):
+            check(self._L.f8_net_run_f32(self._h, images.data_ptr(), int(bool(normalize)), out.data_ptr(), N,
+                                         ctypes.c_void_p(stream)))
+        return out
+
     def run_profiled(self, x, out=None):
         """Like run(); also returns per-launch milliseconds (HIP events on the launch stream)."""
         import torch

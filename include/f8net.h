@@ -56,6 +56,18 @@ int f8_device_count(void);
 int f8_requant_i32(const int32_t* src_dev, int32_t* dst_dev, size_t n,
                    int src_fl, int dst_fl, int is_signed, void* stream);
 
+/* Input quantisation of forward_loss as a stand-alone op — fix_train.py:683-692:
+ *   normalize == 0: dst = round_half_even(255 * src)  (fl, is_signed ignored; output fraclen 8; no clamp, as in the reference)
+ *   normalize != 0: dst = clamp(round_half_even(src * 2^fl), [-127,127] if is_signed else [0,255])
+ * F8_ERR_INVALID where fix_quant asserts (fl outside [0, 8 - signed], fix_quant_ops.py:66-71). */
+int f8_quantize_input_f32(const float* src_dev, int32_t* dst_dev, size_t n, int normalize, int fl, int is_signed, void* stream);
+
+/* Scoring of forward_loss — fix_train.py:697-704: correct_dev[k][n] = 1.0f if target n is among the ks[k] largest
+ * logits of image n, else 0 (the rows the reference concatenates behind the loss).  Equal logits rank by lower class
+ * index.  logits_dev: float32 [N, classes]; target_dev: int64 [N]; ks: host array of nk <= 8 values. */
+int f8_topk_correct_f32(const float* logits_dev, const int64_t* target_dev, int N, int classes,
+                        const int* ks, int nk, float* correct_dev, void* stream);
+
 /* nn.ReLU on int32 — models/fix_resnet.py:39,77.  In place. */
 int f8_relu_i32(int32_t* x_dev, size_t n, void* stream);
 
@@ -156,6 +168,14 @@ int f8_net_upload(f8_net* net);
 /* Runs the net on `N` images (1 <= N <= max_batch).  input_dev: int32 NCHW [N,C,H,W];
  * output_dev: float32 or int32 [N, output_elems].  Asynchronous on `stream`. */
 int f8_net_run(f8_net* net, const int32_t* input_dev, void* output_dev, int N, void* stream);
+
+/* Same net, fed with the fp32 images forward_loss receives (fix_train.py:676-692): the input quantisation
+ *   normalize == 0:  x_int = round_half_even(255 * x), fraclen 8        (fix_train.py:689-692; requires an unsigned head at fraclen 8)
+ *   normalize != 0:  x_int = clamp(round_half_even(x * 2^fl), +-127 or [0,255]), fl = the head's input fraclen
+ *                    (fix_train.py:683-687 through fix_quant, models/fix_quant_ops.py:64-87)
+ * is applied inside the input kernel, so the int32 NCHW tensor of the reference never exists in HBM.
+ * images_dev: float32 NCHW [N,C,H,W].  F8_ERR_INVALID if normalize == 0 and the net's input fraclen is not 8. */
+int f8_net_run_f32(f8_net* net, const float* images_dev, int normalize, void* output_dev, int N, void* stream);
 
 /* f8_net_run cuts a batch of N into this many independent sub-batches (1..4) that it runs on
  * internal streams forked from / joined to `stream` (no host synchronisation); every planned launch

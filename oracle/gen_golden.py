@@ -286,6 +286,22 @@ def child_ops():
     fl = torch.tensor([5], dtype=torch.int32)
     q = (fix_quant(torch.from_numpy(xn.copy()), 8, fl * 1.0, 1, True)[0] * (2 ** fl)).int()
     out['inq/xn'], out['inq/s8_fl5'] = xn, q.numpy()
+    # --- scoring (fix_train.py:697-704; fix_train.py itself cannot be imported here — torchvision / pytorchcv are absent —
+    #     so its five tensor statements are executed as written, on torch, with FLAGS.topk = [1, 5])
+    logits = synth.rand_normal_int(61, 'logits', (12, 40), 3.0e4).astype(np.float32)      # integer-valued, like int_op_only logits
+    target = synth.rand_uniform_int(62, 'target', (12,), 0, 39).astype(np.int64)
+    am = np.argsort(-logits, axis=1, kind='stable')
+    target[0], target[1], target[2] = am[0, 0], am[1, 4], am[2, 5]              # top-1 hit, top-5 edge hit, just outside top-5
+    output, tgt = torch.from_numpy(logits), torch.from_numpy(target)
+    topk = [1, 5]
+    _, pred = output.topk(max(topk))
+    pred = pred.t()
+    correct = pred.eq(tgt.view(1, -1).expand_as(pred))
+    correct_k = []
+    for k in topk:
+        correct_k.append(correct[:k].float().sum(0))
+    out['topk/logits'], out['topk/target'] = logits, target
+    out['topk/correct'] = torch.stack(correct_k, 0).numpy()
     np.savez_compressed(os.path.join(GOLD, 'ops.npz'), **out)
     print(f'[gen_golden] ops: wrote ops.npz ({len(out)} arrays)')
 

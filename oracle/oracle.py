@@ -226,6 +226,17 @@ def quantize_input_u8(img01):
     return np.rint(255.0 * np.asarray(img01, dtype=np.float32)).astype(np.int32), 8
 
 
+def topk_correct(logits, target, topk=(1, 5)):
+    """fix_train.py:697-704: rows of per-sample flags `target in top-k`.  Equal logits rank by lower class index (what a
+    stable descending sort gives; torch.topk leaves the order of ties unspecified, tie-free inputs agree exactly)."""
+    logits = np.asarray(logits, dtype=np.float32)
+    target = np.asarray(target).reshape(-1)
+    lt = logits[np.arange(logits.shape[0]), target][:, None]
+    idx = np.arange(logits.shape[1])[None, :]
+    rank = ((logits > lt) | ((logits == lt) & (idx < target[:, None]))).sum(1)
+    return np.stack([(rank < k).astype(np.float32) for k in topk], 0)
+
+
 def quantize_input_normalized(x, head_in_fl: int):
     """fix_train.py:683-687 via fix_quant (fix_quant_ops.py:64-87): round(x*2^fl) clamp +-127, fl."""
     v = np.rint(np.asarray(x, dtype=np.float32) * np.float32(2.0 ** head_in_fl))

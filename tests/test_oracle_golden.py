@@ -98,3 +98,10 @@ def test_whole_net_vs_reference(arch, golden_dir):
         for name, want in zip(names, sums):
             np.testing.assert_array_equal(caps[name], want, err_msg=f'{arch} {tag} layer {name}')
         np.testing.assert_array_equal(logits, g[f'{tag}/logits'])
+
+
+def test_topk_scoring_matches_reference(ops):
+    """fix_train.py:697-704 executed by torch (gen_golden.py) vs the oracle's rank formulation."""
+    got = oracle.topk_correct(ops['topk/logits'], ops['topk/target'], (1, 5))
+    np.testing.assert_array_equal(got, ops['topk/correct'])
+    assert got[0].sum() >= 1 and got[1].sum() > got[0].sum()      # hits at k = 1 and more at k = 5
