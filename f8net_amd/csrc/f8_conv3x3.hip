@@ -13,6 +13,7 @@
 // Arithmetic is that of conv_igemm_kernel: wrapping int32 accumulate, class bias, ReLU, optional residual join,
 // int32 (I32T) and / or requantised int8 outputs (reference: models/fix_quant_ops.py:99-112, fix_resnet.py:40-54).
 #include "f8_device.h"
+#include "f8_block.h"
 #include <cstdlib>
 #ifdef F8_TRACE
 #include <cstdio>
@@ -269,103 +270,10 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(const ConvArgs a) {
     }
     F8_TT(3);
 
-    // ---- K-split exchange through LDS (patch / ring are dead now): a wave keeps the partial sums of the NF tiles it
-    //      finishes in registers, parks the other 4 - NF tiles of its block at park[wave][slot], and adds its
-    //      partners' parked partials of its own tiles.  Block tile index = 2 * (cout of pair) + (pixel of pair).
-    v4i* const park = (v4i*)lds;
-    constexpr int NPARK = 4 - NF;
-    auto park_at = [&](int w, int slot, int g) { return park + ((w * NPARK + slot) * 4 + g) * 64 + lane; };
-    // tiles finished by K-split member k of a block: KS == 2: pixel k, couts 0 and 1; KS == 4: pixel k & 1, cout k >> 1
-    auto owner = [&](int i, int j) { return KS == 2 ? j : (2 * i + j); };     // i = cout of pair, j = pixel of pair
-    // parking slot of tile (i, j) in a non-owner's area: rank of the tile among those that wave does not own
-    auto slot_of = [&](int k, int i, int j) {
-        int sl = 0;
-        for (int ii = 0; ii < 2; ++ii)
-            for (int jj = 0; jj < 2; ++jj) {
-                if (ii == i && jj == j) return sl;
-                if (owner(ii, jj) != k) ++sl;
-            }
-        return sl;
-    };
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int k = 0; k < KS; ++k) {
-                if (k == ks && owner(i, j) != k) {              // wave-uniform
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        v4i v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                        *park_at(wave, slot_of(k, i, j), g) = v;
-                    }
-                }
-            }
-        }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    v4i fin[NF][4];                                             // finished accumulators of this wave's tiles
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int k = 0; k < KS; ++k) {
-                if (k == ks && owner(i, j) == k) {              // wave-uniform: one of my tiles
-                    const int f = KS == 2 ? i : 0;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        v4i v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-#pragma unroll
-                        for (int o = 0; o < KS; ++o)
-                            if (o != k) v += *park_at(blk + o * NB, slot_of(o, i, j), g);
-                        fin[f][g] = v;
-                    }
-                }
-            }
-        }
-    // ---- epilogue on this wave's NF tiles
-    const int floor0 = a.relu0 ? 0 : INT32_MIN, floor1 = a.relu1 ? 0 : INT32_MIN;
-#pragma unroll
-    for (int i = 0; i < NF; ++i) {
-        const int cot = co0 + (fco + i) * 32;
-        if (cot >= a.coutP) continue;                           // wave-uniform
-        int y[4][4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                int v = max((int)((unsigned)fin[i][g][e] + (unsigned)bq[i][g][e]), floor0);
-                if (HAS_RES) {
-                    const unsigned s = ((unsigned)v << a.acc_shl) + ((unsigned)rv[i][g][e] << a.res_shl);
-                    v = max(clamp_sym31((int)s), floor1);
-                }
-                y[g][e] = v;
-            }
-        if (a.out32 && opix_ok) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                v4i o = {y[g][0], y[g][1], y[g][2], y[g][3]};
-                *(v4i*)(a.out32 + i32t_index(m, cot + 8 * g + 4 * lh, a.coutP)) = o;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (!a.q[k].ptr) continue;                          // wave-uniform
-            unsigned d[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                d[g] = pack4(requant1(y[g][0], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(y[g][1], a.q[k].n, a.q[k].lo, a.q[k].hi),
-                             requant1(y[g][2], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(y[g][3], a.q[k].n, a.q[k].lo, a.q[k].hi)) ^ a.q[k].bias_xor;
-            auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
-            auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
-            if (opix_ok) {
-                v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
-                *(v4i*)(a.q[k].ptr + (size_t)m * a.coutP + cot + 16 * lh) = o;
-            }
-        }
-    }
+    // ---- K-split exchange through LDS (patch / ring are dead now), then the fused epilogue on this wave's NF tiles
+    v4i fin[NF][4];
+    block_exchange<KS, NB, NF>(acc, (v4i*)lds, wave, blk, ks, lane, fin);
+    block_finish<NF, HAS_RES>(a, fin, bq, rv, co0 + fco * 32, m, opix_ok, lh);
 #ifdef F8_TRACE
     if (a.trace && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
