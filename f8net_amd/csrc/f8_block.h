@@ -47,25 +47,30 @@ __device__ __forceinline__ void block_exchange(v16i (&acc)[2][2], v4i* park, int
         }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // Own tiles: explicit wave-uniform switch with CONSTANT accumulator indices in every arm (a loop with a run-time
+    // "is this tile mine" test gets folded by the compiler into acc[ks >> 1][ks & 1], i.e. a dynamically indexed private
+    // array = the accumulators in scratch memory)
+    auto finish_tile = [&](v16i& t, int i, int j, int f) {      // i, j, f are literals at every call site
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int g = 0; g < 4; ++g) {
+            v4i v = {t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]};
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int k = 0; k < KS; ++k) {
-                if (k == ks && owner(i, j) == k) {              // wave-uniform: one of my tiles
-                    const int f = KS == 2 ? i : 0;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        v4i v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-#pragma unroll
-                        for (int o = 0; o < KS; ++o)
-                            if (o != k) v += *park_at(blk + o * NB, slot_of(o, i, j), g);
-                        fin[f][g] = v;
-                    }
-                }
-            }
+            for (int o = 0; o < KS; ++o)
+                if (o != ks) v += *park_at(blk + o * NB, slot_of(o, i, j), g);
+            fin[f][g] = v;
         }
+    };
+    if constexpr (KS == 2) {
+        if (ks == 0) { finish_tile(acc[0][0], 0, 0, 0); finish_tile(acc[1][0], 1, 0, 1); }
+        else { finish_tile(acc[0][1], 0, 1, 0); finish_tile(acc[1][1], 1, 1, 1); }
+    } else {
+        switch (ks) {
+            case 0: finish_tile(acc[0][0], 0, 0, 0); break;
+            case 1: finish_tile(acc[0][1], 0, 1, 0); break;
+            case 2: finish_tile(acc[1][0], 1, 0, 0); break;
+            default: finish_tile(acc[1][1], 1, 1, 0); break;
+        }
+    }
 }
 
 // Fused epilogue of NF finished 32x32 tiles (cout tiles cot0, cot0 + 32, ...; this lane's output pixel m):

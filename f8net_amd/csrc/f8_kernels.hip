@@ -245,25 +245,6 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     // it, and the counted waits below use the per-wave instruction count).
     auto issue_stage = [&](int slot) {
         char* base = lds + slot * TILE;
-        if (DUAL && kiss >= nk1) {               // wave-uniform: stages of the second product
-            const unsigned koff2 = (unsigned)((kiss - nk1) * BK);
-#pragma unroll
-            for (int i = 0; i < XL; ++i) {
-                const unsigned off = xbase2[i] + koff2;
-                if ((i * 256 + wave * 64) < XCH)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx2, (__attribute__((address_space(3))) void*)(base + i * 4096 + wave * 1024),
-                                                             16, off, 0, 0, 0);
-            }
-#pragma unroll
-            for (int j = 0; j < WL; ++j) {
-                const unsigned woff = wbase2[j] + koff2;
-                if ((j * 256 + wave * 64) < WCH)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw2, (__attribute__((address_space(3))) void*)(base + XBYTES + j * 4096 + wave * 1024),
-                                                             16, woff, 0, 0, 0);
-            }
-            ++kiss;
-            return;
-        }
         const unsigned koffx = (unsigned)(tr * a.tapH + ts * a.tapW + c0);
 #pragma unroll
         for (int i = 0; i < XL; ++i) {
@@ -288,6 +269,29 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
         if (c0 == a.CK) {
             c0 = 0; ++ts;
             if (ts == a.kw) { ts = 0; ++tr; }
+        }
+    };
+    // DUAL (two 1x1 convs: no tap state): STATELESS issue of global stage g.  The mutable captures of issue_stage end
+    // up in scratch memory once a second code path touches them, and a scratch load queues behind every DMA in flight
+    // (VMEM returns in order): the ring would drain on every K step.
+    auto issue_dual = [&](int slot, int g) {
+        char* base = lds + slot * TILE;
+        const bool second = g >= nk1;                            // wave-uniform
+        const unsigned koff = (unsigned)((second ? g - nk1 : g) * BK);
+        const __amdgpu_buffer_rsrc_t qx = second ? rx2 : rx, qw = second ? rw2 : rw;
+#pragma unroll
+        for (int i = 0; i < XL; ++i) {
+            const unsigned b = second ? xbase2[DUAL ? i : 0] : xbase[i];
+            const unsigned off = b == kOOB ? kOOB : b + koff;
+            if ((i * 256 + wave * 64) < XCH)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(qx, (__attribute__((address_space(3))) void*)(base + i * 4096 + wave * 1024), 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < WL; ++j) {
+            const unsigned b = second ? wbase2[DUAL ? j : 0] : wbase[j];
+            const unsigned woff = b == kOOB ? kOOB : b + koff;
+            if ((j * 256 + wave * 64) < WCH)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(qw, (__attribute__((address_space(3))) void*)(base + XBYTES + j * 4096 + wave * 1024), 16, woff, 0, 0, 0);
         }
     };
     // DMA instructions THIS wave issues per stage (compile-time per wave index is not available, so
@@ -317,7 +321,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     // prologue: STAGES-1 tiles in flight
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
-        if (s < nk) issue_stage(s);
+        if (s < nk) { if constexpr (DUAL) issue_dual(s, s); else issue_stage(s); }
 #ifdef F8_TRACE
     t_pro = __builtin_readcyclecounter();
 #endif
@@ -331,7 +335,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
         if (ks == 0) t_first = __builtin_readcyclecounter();
 #endif
 #ifndef F8_ABL_NO_DMA
-        if (ks + STAGES - 1 < nk) issue_stage((ks + STAGES - 1) % STAGES);
+        if (ks + STAGES - 1 < nk) { if constexpr (DUAL) issue_dual((ks + STAGES - 1) % STAGES, ks + STAGES - 1); else issue_stage((ks + STAGES - 1) % STAGES); }
 #endif
         const char* base = lds + (ks % STAGES) * TILE;
 #pragma unroll
