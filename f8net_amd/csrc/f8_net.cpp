@@ -706,7 +706,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     if (o.forms[f].kind == FORM_I8 && o.forms[f].n != 0) extra.push_back((int)f);
                 if (!extra.empty()) add_form(o, FORM_I32, 0, 0);
                 st.out.t = nd.out;
-                st.name = "input"; st.kernel = "f8::input_kernel";
+                st.name = "input"; st.kernel = "f8::input_kernel";     // refined below once the forms are known
                 double b = (double)o.C * o.H * o.W * 4;
                 for (auto& F : o.forms) b += (double)o.H * o.W * (F.kind == FORM_I32 ? o.Cs * 4 : (F.kind == FORM_STEM ? 4 : o.Cs));
                 st.bytes_per_img = b;
@@ -854,7 +854,8 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 st.src_f = i8 ? find_form(s, FORM_I8, o.forms[0].n, o.forms[0].sgn) : find_form(s, FORM_I32, 0, 0);
                 if (o.forms.empty()) add_form(o, FORM_I32, 0, 0);
                 select_outputs(net, nd.out, &st.out, &extra);
-                st.name = std::string(i8 ? "maxpool_i8:" : "maxpool_i32:") + tname(net, nd.out); st.kernel = "f8::maxpool_kernel";
+                st.name = std::string(i8 ? "maxpool_i8:" : "maxpool_i32:") + tname(net, nd.out);
+                st.kernel = (i8 && (s.Cs & 15) == 0 && nd.ppad < nd.pk) ? "f8::maxpool_i8x16_kernel" : "f8::maxpool_kernel";   // keep in sync with launch_maxpool
                 const double ei = (double)s.H * s.W * s.Cs, eo = (double)o.H * o.W * o.Cs;
                 st.bytes_per_img = ei * (i8 ? 1 : 4) + (st.out.f32 >= 0 ? eo * 4 : 0) + (st.out.f8[0] >= 0 ? eo : 0) + (st.out.f8[1] >= 0 ? eo : 0);
                 break;
@@ -881,6 +882,13 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         net->steps.push_back(st);
     }
 
+    for (auto& st : net->steps)
+        if (st.kind == S_INPUT) {      // keep in sync with launch_input
+            const Tensor& o = T[st.out.t];
+            bool only_stem = !o.forms.empty();
+            for (auto& F : o.forms) only_stem = only_stem && F.kind == FORM_STEM;
+            if (only_stem && (o.W & 3) == 0 && o.C <= 4) st.kernel = "f8::input_stem4_kernel";
+        }
     // ---- 4. lifetimes and arena layout (first-fit over a free list; in-place residual update)
     for (size_t si = 0; si < net->steps.size(); ++si) {
         Step& st = net->steps[si];
