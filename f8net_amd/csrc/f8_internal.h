@@ -116,6 +116,7 @@ struct ConvTile { int bm, bn, bk; };
 // Tile choice for a conv; returns false if no kernel instance fits (ck % bk).
 bool pick_conv_tile(int M, int coutP, int ck, bool has_res, ConvTile* t);
 int  conv_grid(const ConvTile& t, int M, int coutP);
+int  conv_deep_nk();
 
 hipError_t launch_conv(const ConvArgs& a, const ConvTile& t, hipStream_t s);
 hipError_t launch_fused_bottleneck(const FusedArgs& a, hipStream_t s);

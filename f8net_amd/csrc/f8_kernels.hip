@@ -1061,6 +1061,14 @@ bool pick_conv_tile(int M, int coutP, int ck, bool has_res, ConvTile* t) {
     return true;
 }
 
+// K loops of at least this many steps get the deepest ring that fits 64 KB of static LDS (else 2 slots).
+// Measured (ResNet-50, bs 128, A/B/A/B): threshold 16 -> 64.0-64.5 k, 7 -> 64.7-64.9 k, 5 -> 65.2 k img/s; 7 takes in the
+// 7-step stem (80 -> 75 us) and the 9-step 3x3s without touching the 4-step residual-carrying 1x1s.
+int conv_deep_nk() {
+    static const int v = [] { const char* e = getenv("F8_DEEP_NK"); return e ? atoi(e) : 7; }();
+    return v;
+}
+
 int conv_grid(const ConvTile& t, int M, int coutP) {
     return ((M + t.bm - 1) / t.bm) * ((coutP + t.bn - 1) / t.bn);
 }
@@ -1104,7 +1112,7 @@ static hipError_t launch_conv_t(const ConvArgs& a, int grid, hipStream_t s) {
     }
     // long K loops (3x3 of the late stages: 36-72 steps of ~64-256 MFMA cycles against an ~800-cycle DMA round
     // trip) want a deeper ring; short ones want the smaller LDS footprint
-    static const int deep_nk = [] { const char* e = getenv("F8_DEEP_NK"); return e ? atoi(e) : 16; }();
+    const int deep_nk = conv_deep_nk();
     constexpr int DST = (4 * TILE <= 65536) ? 4 : ((3 * TILE <= 65536) ? 3 : 2);
     const bool deep = (DST > ST) && ((a.ktot + a.ktot2) / BK >= deep_nk);
     if (a.x2) {   // dual GEMM (downsample join): 1x1 / no padding, 64-wide cout tiles only

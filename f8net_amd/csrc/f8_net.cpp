@@ -825,7 +825,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     const int tile_b = (nd.tile.bm + nd.tile.bn) * nd.tile.bk;
                     const int dst = (4 * tile_b <= 65536) ? 4 : ((3 * tile_b <= 65536) ? 3 : 2);
                     const int ksteps = (nd.ktot + (nd.dual >= 0 ? ND[nd.dual].ktot : 0)) / nd.tile.bk;
-                    const int stages = (dst > 2 && ksteps >= 16) ? dst : 2;     // ring depth rule of launch_conv_t
+                    const int stages = (dst > 2 && ksteps >= conv_deep_nk()) ? dst : 2;     // ring depth rule of launch_conv_t
                     snprintf(buf, sizeof buf, "f8::conv_igemm_kernel<%d, %d, %d, %d, %d, %s, %s, %d, %s>", nd.tile.bm, nd.tile.bn, nd.tile.bk, wpx, wco,
                              (d.pad > 0 && !nd.stem) ? "true" : "false", (st.res_t >= 0 || nd.dual >= 0) ? "true" : "false", stages,
                              nd.dual >= 0 ? "true" : "false");
