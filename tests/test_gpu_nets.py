@@ -80,25 +80,31 @@ def test_state_dict_keys_match_reference_export():
         assert 'head.0.weight_fraclen' in m.state_dict() and 'classifier.0.input_fraclen' in m.state_dict()
 
 
-def test_full_size_batch_properties(dev):
-    """ResNet-50 at the benchmark batch: size-independent properties instead of a CPU forward —
-    (1) images are independent: a batch of 128 == the same images run as 4 x 32 and permuted;
-    (2) the first image reproduces the golden logits captured from the reference."""
+# the single-GPU configurations of BASELINE.json (configs[1..3]) plus the bench workload and MobileNet-V1
+FULL_SIZE = [('resnet50', 128), ('resnet50', 256), ('resnet18', 128), ('mobilenet_v2', 128), ('mobilenet_v1', 128)]
+
+
+@pytest.mark.parametrize('arch,n', FULL_SIZE, ids=lambda v: str(v))
+def test_full_size_batch_properties(dev, arch, n):
+    """Full-size batches: size-independent properties instead of a CPU forward of the whole batch —
+    (1) the batch runs as concurrent sub-batches on internal streams: repeated runs are identical
+        (this caught an arena-sharing race between sub-batches during development);
+    (2) images are independent: the batch == the same images run in chunks of 32, and permuted;
+    (3) the first two images equal the CPU oracle bit for bit."""
     from f8net_amd.net import build_net
-    spec = topology.get('resnet50', normalize=True)
-    params = synth.make_params(spec, seed=1234, fraclens=topology.R50_NVIDIA_FRACLENS)
-    n = 128
-    x, _ = synth.make_input(spec, params, n, 224, seed=11)
+    normalize = arch == 'resnet50'
+    spec = topology.get(arch, normalize=normalize)
+    params = synth.make_params(spec, seed=1234, fraclens=topology.R50_NVIDIA_FRACLENS if arch == 'resnet50' else None)
+    x, x_fl = synth.make_input(spec, params, n, 224, seed=11)
     net = build_net(spec, params, max_batch=n, hw=224)
     xt = torch.from_numpy(x).to(dev)
     full = net.run(xt).cpu().numpy()
-    # the batch runs as concurrent sub-batches on internal streams: repeated runs must be identical
-    # (this caught an arena-sharing race between sub-batches during development)
-    for _ in range(4):
+    for _ in range(3):
         np.testing.assert_array_equal(net.run(xt).cpu().numpy(), full)
     parts = np.concatenate([net.run(xt[i:i + 32].contiguous()).cpu().numpy() for i in range(0, n, 32)])
     np.testing.assert_array_equal(full, parts)
     perm = np.array(synth.rand_uniform_int(1, 'perm', (n,), 0, 10**9)).argsort()
     permuted = net.run(xt[torch.from_numpy(perm).to(dev)].contiguous()).cpu().numpy()
     np.testing.assert_array_equal(permuted, full[perm])
+    np.testing.assert_array_equal(full[:2], oracle.net_forward(spec, params, x[:2], x_fl))
     assert np.count_nonzero(full) > 0.9 * full.size
