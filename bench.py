@@ -31,8 +31,9 @@ sys.path.insert(0, ROOT)
 BS = 128
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 MFMA_I8_PEAK_TOPS = 5033.0     # 256 CU x 4 SIMD x 2048 op/clk x 2.4 GHz
-R50_OPS_PER_IMG = 8.178368512e9        # 2 * 4 089 184 256 MACs
-R50_STRUCT_BYTES_PER_IMG = 93444000.0  # structural byte model of SURVEY.md §8d
+# per image: integer ops (2 * MACs) and the structural byte model of SURVEY.md §8d
+OPS_PER_IMG = {'resnet50': 8.178368512e9, 'resnet18': 3.628146688e9, 'mobilenet_v2': 0.601548544e9, 'mobilenet_v1': 1.137480704e9}
+STRUCT_BYTES_PER_IMG = {'resnet50': 93444000.0, 'resnet18': 20830112.0, 'mobilenet_v2': 20602656.0, 'mobilenet_v1': 28911520.0}
 
 
 def cpu_baseline(spec, params, x_np, x_fl, ref_logits):
@@ -171,8 +172,8 @@ def main():
                          'alg_bytes_per_launch': round(d['bytes'] / d_launches, 0),
                          'kernel_share_of_step': round(d['ms'] / total_ms, 3)},
             'whole_net': {'sum_kernel_ms': round(total_ms, 4),
-                          'mfma_int8_frac_of_peak': round(value / world * R50_OPS_PER_IMG / 1e12 / MFMA_I8_PEAK_TOPS, 4),
-                          'hbm_frac_structural_bytes': round(value / world * R50_STRUCT_BYTES_PER_IMG / 1e9 / HBM_PEAK_GBS, 4),
+                          'mfma_int8_frac_of_peak': round(value / world * OPS_PER_IMG.get(args.arch, 0.0) / 1e12 / MFMA_I8_PEAK_TOPS, 4),
+                          'hbm_frac_structural_bytes': round(value / world * STRUCT_BYTES_PER_IMG.get(args.arch, 0.0) / 1e9 / HBM_PEAK_GBS, 4),
                           'alg_bytes_per_img': round(sum(r[3] for r in rows) / BS, 0)},
         }
         if world == 1 and not args.no_cpu_baseline and args.arch == 'resnet50':
