@@ -90,13 +90,16 @@ def main():
     net = build_net(spec, params, max_batch=BS, hw=224)
     net.upload()
     x = torch.from_numpy(x_np).to(dev)
-    logits = torch.empty((BS, spec.num_classes), dtype=torch.float32, device=dev)
-    sharded = f8dist.ShardedForward(lambda t: net.run(t, out=logits), spec.num_classes)
+    # the all-gather of step i overlaps the compute of step i+1 (double-buffered logits); fence() completes every
+    # outstanding collective before the clock stops
+    sharded = f8dist.PipelinedShardedForward(lambda t, out: net.run(t, out=out), spec.num_classes, BS, dev)
+    logits = sharded.local[0]
 
     def step():
         return sharded(x)
 
     def fence():
+        sharded.finish()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)

@@ -75,3 +75,37 @@ class ShardedForward:
 
     def __call__(self, x_local, n_total=None):
         return self.gather(self.forward_local(x_local), n_total)
+
+
+class PipelinedShardedForward(ShardedForward):
+    """Same exchange, off the critical path: the all-gather of batch i runs on RCCL's stream (`async_op=True`) while
+    batch i+1 is already computing.  `forward_local(x, out)` must write its logits into `out`: two (local, gathered)
+    buffer pairs alternate, and a pair is only reused after its collective has been waited for.  The tensor returned by
+    `__call__` is complete after `finish()` (or after the pair comes round again).  Equal shards only."""
+
+    def __init__(self, forward_local, num_classes: int, n_local: int, device, group=None):
+        super().__init__(forward_local, num_classes, group)
+        self.n_local = n_local
+        self.local = [torch.empty((n_local, num_classes), dtype=torch.float32, device=device) for _ in range(2)]
+        world = self.world
+        self.full = [torch.empty((n_local * world, num_classes), dtype=torch.float32, device=device) for _ in range(2)] \
+            if world > 1 else self.local
+        self.work = [None, None]
+        self.i = 0
+
+    def __call__(self, x_local, n_total=None):
+        k = self.i & 1
+        self.i += 1
+        if self.work[k] is not None:
+            self.work[k].wait()            # the pair's previous collective (two batches ago) is done before its buffers are rewritten
+            self.work[k] = None
+        self.forward_local(x_local, self.local[k])
+        if self.world > 1:
+            self.work[k] = dist.all_gather_into_tensor(self.full[k], self.local[k], group=self.group, async_op=True)
+        return self.full[k]
+
+    def finish(self):
+        for k in range(2):
+            if self.work[k] is not None:
+                self.work[k].wait()
+                self.work[k] = None
