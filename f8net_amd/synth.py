@@ -104,3 +104,37 @@ def make_input(spec: topology.NetSpec, params: dict, n: int, hw: int = 224, seed
         x = rand_uniform_int(seed, 'input', (n, 3, hw, hw), 0, 255)
         fl = 8
     return x.astype(np.int32), fl
+
+
+def make_float_state(spec: topology.NetSpec, seed: int = 77) -> dict:
+    """Synthetic FLOAT model state (the keys of a trained F8Net ResNet `state_dict()`: `….conv.weight`, `….bn.*`,
+    `….alpha`, `….input_fraclen`, `classifier.0.weight/bias`) for the exporter parity tests.  Every value is an integer
+    from the counter PRNG divided by a power of two, so the float32 arrays are bit-identical wherever they are rebuilt."""
+    from .export import float_key
+    sd = {}
+
+    def f(key, name, shape, sigma_q, shift, offset_q=0):
+        v = rand_normal_int(seed, f'{key}.{name}', shape, sigma_q) + offset_q
+        return (v.astype(np.float64) / float(1 << shift)).astype(np.float32)
+
+    def u(key, name, shape, lo_q, hi_q, shift):
+        v = rand_uniform_int(seed, f'{key}.{name}', shape, lo_q, hi_q)
+        return (v.astype(np.float64) / float(1 << shift)).astype(np.float32)
+
+    for c in spec.convs():
+        fk = float_key(c.key)
+        fan = c.k * c.k * c.cout
+        sig = (2.0 / fan) ** 0.5
+        sd[f'{fk}.conv.weight'] = f(c.key, 'w', (c.cout, c.cin // c.groups, c.k, c.k), sig * (1 << 16), 16)
+        sd[f'{fk}.bn.weight'] = u(c.key, 'bnw', (c.cout,), 512, 1536, 10)            # 0.5 .. 1.5
+        sd[f'{fk}.bn.bias'] = f(c.key, 'bnb', (c.cout,), 0.2 * 1024, 10)
+        sd[f'{fk}.bn.running_mean'] = f(c.key, 'bnm', (c.cout,), 0.3 * 1024, 10)
+        sd[f'{fk}.bn.running_var'] = u(c.key, 'bnv', (c.cout,), 256, 2048, 10)       # 0.25 .. 2.0
+        sd[f'{fk}.alpha'] = u(c.key, 'alpha', (), 3 * 256, 9 * 256, 8)               # 3 .. 9
+        sd[f'{fk}.input_fraclen'] = u(c.key, 'infl', (1,), 67, 109, 4)               # 4.19 .. 6.81 in steps of 1/16: exact .5 ties occur
+    k = spec.fc_key
+    sd[f'{k}.weight'] = f(k, 'w', (spec.num_classes, spec.fc_in), 0.05 * (1 << 16), 16)
+    sd[f'{k}.bias'] = f(k, 'b', (spec.num_classes,), 0.1 * 1024, 10)
+    sd[f'{k}.alpha'] = u(k, 'alpha', (), 3 * 256, 9 * 256, 8)
+    sd[f'{k}.input_fraclen'] = u(k, 'infl', (1,), 67, 109, 4)
+    return sd

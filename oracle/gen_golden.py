@@ -50,12 +50,20 @@ def checksum(a: np.ndarray):
 
 # --------------------------------------------------------------------------- child: one model
 
-def build_reference_int_model(arch):
+EXPORT_CASES = {
+    # name: (arch, yml) — the two export regimes the shipped int_op_only ymls use
+    'resnet18_metric': ('resnet18', 'apps/imagenet/resnet18/conventional/res18_fix_quant_test_int_op_only.yml'),
+    'resnet18_gridsearch': ('resnet18', 'apps/imagenet/resnet18/tiny_finetuning/res18_fix_quant_ptcv_pretrained_test_int_op_only_on_cpu.yml'),
+    'resnet50_gridsearch': ('resnet50', YMLS['resnet50']),
+}
+
+
+def build_reference_int_model(arch, yml=None, float_state=None):
     import torch
     import torch.nn as nn
     sys.dont_write_bytecode = True
     sys.path.insert(0, REF)
-    sys.argv = ['gen_golden', f'app:{os.path.join(REF, YMLS[arch])}', 'bs:1']
+    sys.argv = ['gen_golden', f'app:{os.path.join(REF, yml or YMLS[arch])}', 'bs:1']
     from myutils.config import FLAGS
     model_lib = importlib.import_module(FLAGS.model)
     from models.fix_quant_ops import ReLUClipFXQConvBN, ReLUClipFXQLinear
@@ -86,6 +94,14 @@ def build_reference_int_model(arch):
         if isinstance(m, ReLUClipFXQLinear):
             m.rescale_forward = getattr(FLAGS, 'rescale_forward', True)
     model.eval()
+    if float_state is not None:
+        # exporter parity: the float model's parameters / buffers are overwritten with our synthetic state
+        sd = model.state_dict()
+        want = {k for k in sd if not k.endswith('num_batches_tracked')}
+        assert want == set(float_state), sorted(want ^ set(float_state))[:8]
+        with torch.no_grad():
+            for k, v in float_state.items():
+                sd[k].copy_(torch.from_numpy(np.asarray(v)).reshape(sd[k].shape))
     # -- fix_train.py:930-934 with the requires_grad shim
     orig_conv, orig_lin = nn.Conv2d.__init__, nn.Linear.__init__
 
@@ -172,6 +188,37 @@ def child_model(arch):
     out['normalize'] = np.array(normalize)
     np.savez_compressed(os.path.join(GOLD, f'net_{arch}.npz'), **out)
     print(f'[gen_golden] {arch}: wrote net_{arch}.npz ({len(out)} arrays)')
+
+
+def child_export(case):
+    """Exporter parity (SURVEY.md §8f-1): the reference's own int_model() on a float model holding our synthetic state;
+    the fixture keeps checksums of the int32 weights, the biases and fraclens in full."""
+    import torch
+    sys.path.insert(0, REPO)
+    from f8net_amd import synth, topology
+    arch, yml = EXPORT_CASES[case]
+    spec0 = topology.get(arch)
+    fstate = synth.make_float_state(spec0, seed=77)
+    int_model, FLAGS = build_reference_int_model(arch, yml=yml, float_state=fstate)
+    sd = int_model.state_dict()
+    out = {'flags': np.array([int(bool(getattr(FLAGS, k, False))) for k in
+                              ('normalize', 'format_from_metric', 'format_grid_search', 'no_clipping', 'input_fraclen_sharing',
+                               'quant_avgpool', 'pool_fusing', 'rescale_forward', 'rescale_forward_conv')], dtype=np.int32)}
+    names, sums = [], []
+    for k in sorted(sd):
+        v = sd[k].numpy()
+        assert v.dtype == np.int32, (k, v.dtype)
+        if k.endswith('.weight'):
+            names.append(k)
+            sums.append(checksum(v))
+            out[f'head/{k}'] = v.reshape(-1)[:64].copy()
+        else:
+            out[f'full/{k}'] = v.copy()
+    out['weight_names'] = np.array(names)
+    out['weight_sums'] = np.stack(sums)
+    np.savez_compressed(os.path.join(GOLD, f'export_{case}.npz'), **out)
+    wfl = [int(sd[k]) for k in sorted(sd) if k.endswith('weight_fraclen')]
+    print(f'[gen_golden] export {case}: {len(names)} layers, weight fraclens {sorted(set(wfl))}, wrote export_{case}.npz')
 
 
 def child_ops():
@@ -313,11 +360,13 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     if args.child == 'ops':
         child_ops()
+    elif args.child and args.child.startswith('export:'):
+        child_export(args.child.split(':', 1)[1])
     elif args.child:
         child_model(args.child)
     else:
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
-        for c in ['ops'] + list(YMLS):
+        for c in ['ops'] + list(YMLS) + [f'export:{c}' for c in EXPORT_CASES]:
             subprocess.check_call([sys.executable, os.path.abspath(__file__), '--child', c], env=env)
 
 

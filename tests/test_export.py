@@ -1,0 +1,73 @@
+"""Float -> int exporter against the reference's own `Model.int_model()`:
+`oracle/gen_golden.py --child export:<case>` ran the reference export on a float model holding `synth.make_float_state`
+and stored checksums of the int32 weights plus biases / fraclens in full; here the same synthetic state goes through
+`f8net_amd.export.export_int_state`.  Bit-exact: every weight, bias and fraction length."""
+import os
+
+import numpy as np
+import pytest
+
+from f8net_amd import synth, topology
+
+torch = pytest.importorskip('torch')
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+FLAG_NAMES = ('normalize', 'format_from_metric', 'format_grid_search', 'no_clipping', 'input_fraclen_sharing',
+              'quant_avgpool', 'pool_fusing', 'rescale_forward', 'rescale_forward_conv')
+
+
+def checksum(a):
+    v = np.ascontiguousarray(a).reshape(-1).astype(np.int64)
+    with np.errstate(over='ignore'):
+        wgt = (np.arange(v.size, dtype=np.int64) % 65521) + 1
+        return np.array([v.sum(), (v * wgt).sum()], dtype=np.int64)
+
+
+@pytest.mark.parametrize('case,arch', [('resnet18_metric', 'resnet18'), ('resnet18_gridsearch', 'resnet18'),
+                                       ('resnet50_gridsearch', 'resnet50')])
+def test_export_matches_reference_int_model(case, arch):
+    from f8net_amd import export
+    g = np.load(os.path.join(GOLD, f'export_{case}.npz'))
+    flags = dict(zip(FLAG_NAMES, (bool(v) for v in g['flags'])))
+    cfg = export.ExportConfig(**flags)
+    spec = topology.get(arch, normalize=cfg.normalize)
+    got = export.export_int_state(spec, synth.make_float_state(topology.get(arch), seed=77), cfg)
+    assert sorted(got) == sorted([str(k) for k in g['weight_names']] + [k[5:] for k in g.files if k.startswith('full/')])
+    for k in g.files:
+        if k.startswith('full/'):
+            np.testing.assert_array_equal(got[k[5:]].numpy().reshape(g[k].shape), g[k], err_msg=k)
+        elif k.startswith('head/'):
+            np.testing.assert_array_equal(got[k[5:]].numpy().reshape(-1)[:64], g[k], err_msg=k)
+    for name, want in zip(g['weight_names'], g['weight_sums']):
+        w = got[str(name)].numpy()
+        assert w.dtype == np.int32 and np.abs(w).max() <= 127
+        np.testing.assert_array_equal(checksum(w), want, err_msg=str(name))
+
+
+def test_exported_state_loads_into_the_int_model_and_the_oracle_runs_it():
+    """The exporter's output is a drop-in for the reference export: same keys / shapes as IntModel.state_dict(), and the
+    CPU oracle runs a forward on it (non-degenerate logits)."""
+    from f8net_amd import export, int_model
+    from oracle import oracle
+    oracle.build()
+    spec = topology.get('resnet18', num_classes=1000)
+    cfg = export.ExportConfig()
+    sd = export.export_int_state(spec, synth.make_float_state(spec, seed=5), cfg)
+    m = int_model.IntModel(spec)
+    ref = m.state_dict()
+    assert set(ref) == set(sd)
+    m.load_state_dict({k: v.reshape(ref[k].shape) for k, v in sd.items()}, strict=True)
+    params = {k: v.numpy() for k, v in sd.items()}
+    x = synth.rand_uniform_int(3, 'img', (1, 3, 64, 64), 0, 255).astype(np.int32)
+    y = oracle.net_forward(spec, params, x, 8)
+    assert y.shape == (1, 1000) and np.count_nonzero(y) > 900
+
+
+def test_export_rejects_missing_keys_and_unsupported_nets():
+    from f8net_amd import export
+    spec = topology.get('resnet18')
+    st = synth.make_float_state(spec, seed=1)
+    del st['head.0.alpha']
+    with pytest.raises(KeyError):
+        export.export_int_state(spec, st, export.ExportConfig())
+    with pytest.raises(NotImplementedError):
+        export.export_int_state(topology.get('mobilenet_v2'), {}, export.ExportConfig())

@@ -128,3 +128,19 @@ def test_forward_loss_end_to_end(dev):
     want = oracle.topk_correct(logits, target, (1, 5))
     assert errors[1] == list(1.0 - want[0]) and errors[5] == list(1.0 - want[1])
     assert errors[1] == [0.0, 1.0, 1.0, 1.0, 1.0, 0.0] and errors[5] == [0.0, 0.0, 0.0, 1.0, 1.0, 0.0]
+
+
+def test_float_checkpoint_to_gpu_logits(dev, tmp_path):
+    """best_model.pt-shaped float checkpoint -> exporter -> IntModel on the GPU == the oracle on the exported integers."""
+    from f8net_amd import export
+    spec = topology.get('resnet18')
+    fstate = synth.make_float_state(spec, seed=9)
+    ck = tmp_path / 'best_model.pt'
+    torch.save({'model': {'module.' + k: torch.from_numpy(np.asarray(v)) for k, v in fstate.items()}}, ck)
+    cfg = export.ExportConfig()
+    model = export.int_model_from_float('resnet18', str(ck), cfg).to(dev)
+    params = {k: v.cpu().numpy() for k, v in model.state_dict().items()}
+    u = synth.rand_uniform_int(4, 'ck', (3, 3, 64, 64), 0, 255).astype(np.float32) / np.float32(255.0)
+    got = model.forward_f32(torch.from_numpy(u).to(dev), normalize=False)
+    x_ref, fl = oracle.quantize_input_u8(u)
+    np.testing.assert_array_equal(got.cpu().numpy(), oracle.net_forward(spec, params, x_ref, fl))
