@@ -1,4 +1,4 @@
-"""Float -> int exporter for the ResNets: what `Model.int_model()` of the reference does before the int_op_only path runs
+"""Float -> int exporter (ResNets, MobileNet-V1 / V2): what `Model.int_model()` of the reference does before the int_op_only path runs
 (SURVEY.md §8f-1).  Input: the `state_dict()` of a trained F8Net float model (`best_model.pt`, keys `head.0.conv.weight`,
 `stage_i_layer_j.body.k.bn.running_var`, `….alpha`, `….input_fraclen`, `classifier.0.weight`, …) plus the handful of
 yml flags that shape the export.  Output: the int32 parameter set of the exported IntModel under ITS keys
@@ -16,8 +16,9 @@ Restated from (not copied; same float32 operation ORDER, because rounding at .5 
       master / following wiring: BasicBlock :125-147,196-207  Bottleneck :227-254,302-311  Model :437-486,
       int_block :209-224,313-326, int_model :526-544
 
-This is one-time host-side float32 work (torch on the CPU): nothing here is on the timed path.  MobileNet exporters
-(fix_mobilenet_v1/v2.py) are not restated yet.
+  /root/reference/models/fix_mobilenet_v1.py :53-93,186-232,262-279   fix_mobilenet_v2.py :76-170,275-352,405-423
+
+This is one-time host-side float32 work (torch on the CPU): nothing here is on the timed path.
 """
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
@@ -225,14 +226,22 @@ class _Layer:
 
 
 def export_int_state(spec: topology.NetSpec, float_state: dict, cfg: ExportConfig) -> Dict[str, torch.Tensor]:
-    """`model.int_model().state_dict()` of the reference for a ResNet, from the float model's state_dict."""
-    if not spec.arch.startswith('resnet'):
-        raise NotImplementedError(f'export: {spec.arch} (only the ResNet exporter is restated so far)')
-    if not spec.head_maxpool:
-        raise NotImplementedError('export: ResNet head expected')
+    """`model.int_model().state_dict()` of the reference (ResNets, MobileNet-V1 / V2) from the float model's state_dict.
+
+    Wiring (who shares whose activation scale = `master`, whose scale divides my weights = `following`):
+      ResNet   fix_resnet.py:125-147,196-207,227-254,302-311,437-486     identity blocks chain their first conv to the stage's
+               master, a downsample block's first conv AND shortcut take the previous master and reset it
+      MBV2     fix_mobilenet_v2.py:76-134,162-170,311-352                same chaining through `residual_connection` blocks;
+               the tail conv takes the last master; signed (`double_side`) inputs as in the topology table
+      MBV1     fix_mobilenet_v1.py:53-80,204-230                         no masters
+    """
+    resnet, mbv2, mbv1 = spec.arch.startswith('resnet'), spec.arch == 'mobilenet_v2', spec.arch == 'mobilenet_v1'
+    if not (resnet or mbv2 or mbv1):
+        raise NotImplementedError(f'export: {spec.arch}')
     layers: Dict[str, _Layer] = {}
 
     def conv(c: topology.ConvSpec, **kw):
+        kw.setdefault('double_side', c.signed_in)
         L = _Layer(c.key, float_state, cfg, groups=c.groups, kernel=c.k, cout=c.cout, **kw)
         layers[c.key] = L
         return L
@@ -242,27 +251,40 @@ def export_int_state(spec: topology.NetSpec, float_state: dict, cfg: ExportConfi
     master = None
     for b in spec.blocks:
         body = [conv(c) for c in b.body]
-        body[0].master = master
         sc = None
-        if b.shortcut is not None:
-            sc = conv(b.shortcut)
-            sc.master = master
-            master = None
-        else:
-            master = body[0]
+        if resnet:
+            body[0].master = master
+            if b.shortcut is not None:
+                sc = conv(b.shortcut)
+                sc.master = master
+                master = None
+            else:
+                master = body[0]
+        elif mbv2:
+            body[0].master = master
+            master = body[0] if b.residual else None
         for L in prev_tail:
             L.following = body[0]
         for a, nxt in zip(body, body[1:]):
             a.following = nxt
         prev_tail = [body[-1]] + ([sc] if sc is not None else [])
+    last_conv = layers[spec.blocks[-1].body[-1].key]
+    if spec.tail is not None:
+        tail = conv(spec.tail)
+        tail.master = master
+        for L in prev_tail:
+            L.following = tail
+        prev_tail = [tail]
+        last_conv = tail
     fc = _Layer(spec.fc_key, float_state, cfg, linear=True)
     layers[spec.fc_key] = fc
     for L in prev_tail:
         L.following = fc
     if cfg.quant_avgpool:
-        # FXQAvgPool2d(7).scale = 2^round(log2(49)) / 49; int_model passes it to the LAST block's last conv (fix_resnet.py:536-539)
+        # FXQAvgPool2d(7).scale = 2^round(log2(49)) / 49 goes to the last conv before the pool
+        # (fix_resnet.py:536-539, fix_mobilenet_v1.py:271-275, fix_mobilenet_v2.py:419-420)
         shiftnum = torch.round(torch.log2(torch.tensor(7 ** 2))).int().item()
-        layers[spec.blocks[-1].body[-1].key].avgpool_scale = 2 ** shiftnum / (7 ** 2)
+        last_conv.avgpool_scale = 2 ** shiftnum / (7 ** 2)
     out: Dict[str, torch.Tensor] = {}
     with torch.no_grad():
         for key in spec.layer_keys():

@@ -55,6 +55,8 @@ EXPORT_CASES = {
     'resnet18_metric': ('resnet18', 'apps/imagenet/resnet18/conventional/res18_fix_quant_test_int_op_only.yml'),
     'resnet18_gridsearch': ('resnet18', 'apps/imagenet/resnet18/tiny_finetuning/res18_fix_quant_ptcv_pretrained_test_int_op_only_on_cpu.yml'),
     'resnet50_gridsearch': ('resnet50', YMLS['resnet50']),
+    'mobilenet_v1_metric': ('mobilenet_v1', YMLS['mobilenet_v1']),
+    'mobilenet_v2_metric': ('mobilenet_v2', YMLS['mobilenet_v2']),
 }
 
 

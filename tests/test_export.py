@@ -23,7 +23,8 @@ def checksum(a):
 
 
 @pytest.mark.parametrize('case,arch', [('resnet18_metric', 'resnet18'), ('resnet18_gridsearch', 'resnet18'),
-                                       ('resnet50_gridsearch', 'resnet50')])
+                                       ('resnet50_gridsearch', 'resnet50'), ('mobilenet_v1_metric', 'mobilenet_v1'),
+                                       ('mobilenet_v2_metric', 'mobilenet_v2')])
 def test_export_matches_reference_int_model(case, arch):
     from f8net_amd import export
     g = np.load(os.path.join(GOLD, f'export_{case}.npz'))
@@ -62,12 +63,12 @@ def test_exported_state_loads_into_the_int_model_and_the_oracle_runs_it():
     assert y.shape == (1, 1000) and np.count_nonzero(y) > 900
 
 
-def test_export_rejects_missing_keys_and_unsupported_nets():
+def test_export_rejects_missing_keys():
     from f8net_amd import export
     spec = topology.get('resnet18')
     st = synth.make_float_state(spec, seed=1)
     del st['head.0.alpha']
     with pytest.raises(KeyError):
         export.export_int_state(spec, st, export.ExportConfig())
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(KeyError):
         export.export_int_state(topology.get('mobilenet_v2'), {}, export.ExportConfig())
