@@ -92,7 +92,10 @@ def main():
     x = torch.from_numpy(x_np).to(dev)
     # the all-gather of step i overlaps the compute of step i+1 (double-buffered logits); fence() completes every
     # outstanding collective before the clock stops
-    sharded = f8dist.PipelinedShardedForward(lambda t, out: net.run(t, out=out), spec.num_classes, BS, dev)
+    # consecutive steps overlap inside the library as well (f8_net_set_pipelined: static input, double-buffered outputs)
+    pipelined = os.environ.get('F8_BENCH_PIPELINED', '1') != '0'
+    net.set_pipelined(pipelined)
+    sharded = f8dist.PipelinedShardedForward(lambda t, out: net.run(t, out=out), spec.num_classes, BS, dev, lagged=pipelined)
     logits = sharded.local[0]
 
     def step():
@@ -122,6 +125,7 @@ def main():
     if rank == 0:
         imgs = BS * world * args.steps
         value = imgs / dt
+        net.set_pipelined(False)
         # ---- roofline of the dominant kernel, measured live (HIP events on the launch stream)
         n_l = net.num_launches
         reps = 7

@@ -68,6 +68,7 @@ SYMBOLS = [
                                 ctypes.POINTER(ctypes.c_double)]),
     ('f8_net_launch_kernel', _i, [_vp, _i, ctypes.c_char_p, _sz]),
     ('f8_net_set_label', _i, [_vp, _i, ctypes.c_char_p]),
+    ('f8_net_set_pipelined', _i, [_vp, _i]),
 ]
 
 

@@ -119,6 +119,8 @@ struct f8_net {
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t aux_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t lag_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     const float* in_f32 = nullptr; float in_scale = 0.f; int in_lo = 0, in_hi = 0;   // set by f8_net_run_f32 for the duration of the call
+    // pipelined submission (f8_net_set_pipelined): fork dependency = the event recorded at the PREVIOUS run's entry
+    int pipelined = 0; hipEvent_t start_ev[2] = {nullptr, nullptr}; int start_idx = 0; bool have_prev_start = false; hipStream_t prev_stream = nullptr;
     // hipGraph of one whole run (both sub-batch streams), replayed while (input, output, N, stream) stay the same
     hipGraphExec_t g_exec = nullptr; const void* g_in = nullptr; void* g_out = nullptr; int g_N = 0; hipStream_t g_stream = nullptr; int g_warm = 0;
 };
@@ -264,6 +266,7 @@ void f8_net_destroy(f8_net* net) {
     for (int k = 0; k < 5; ++k) if (net->aux_ev[k]) (void)hipEventDestroy(net->aux_ev[k]);
     for (int k = 0; k < 4; ++k) if (net->lag_ev[k]) (void)hipEventDestroy(net->lag_ev[k]);
     if (net->g_exec) (void)hipGraphExecDestroy(net->g_exec);
+    for (int k = 0; k < 2; ++k) if (net->start_ev[k]) (void)hipEventDestroy(net->start_ev[k]);
     delete net;
 }
 
@@ -387,6 +390,13 @@ int f8_net_output(f8_net* net, int src, int as_float) {
     if (rc) return rc;
     if (net->out_t >= 0) return fail(F8_ERR_UNSUPPORTED, "f8_net_output: one output per net");
     net->out_t = src; net->out_float = as_float ? 1 : 0;
+    return F8_OK;
+}
+
+int f8_net_set_pipelined(f8_net* net, int on) {
+    if (!net) return fail(F8_ERR_INVALID, "f8_net_set_pipelined: null net");
+    net->pipelined = on ? 1 : 0;
+    net->have_prev_start = false;
     return F8_OK;
 }
 
@@ -1301,11 +1311,26 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
             capturing = true;
         }
     }
-    (void)hipEventRecord(net->aux_ev[0], s);
-    for (int k = 0; k < parts; ++k) (void)hipStreamWaitEvent(net->aux[k], net->aux_ev[0], 0);
+    if (net->pipelined && !capturing) {
+        // lagged fork: the sub-batch streams order themselves behind the previous run on the same arena copy by stream
+        // order; towards the caller they only wait for the state of `s` at the previous run's entry (header contract)
+        if (!net->start_ev[0])
+            for (int k = 0; k < 2; ++k) (void)hipEventCreateWithFlags(&net->start_ev[k], hipEventDisableTiming);
+        const int cur = net->start_idx;
+        (void)hipEventRecord(net->start_ev[cur], s);
+        hipEvent_t dep = (net->have_prev_start && net->prev_stream == s) ? net->start_ev[cur ^ 1] : net->start_ev[cur];
+        for (int k = 0; k < parts; ++k) (void)hipStreamWaitEvent(net->aux[k], dep, 0);
+        net->start_idx ^= 1; net->have_prev_start = true; net->prev_stream = s;
+    } else {
+        (void)hipEventRecord(net->aux_ev[0], s);
+        for (int k = 0; k < parts; ++k) (void)hipStreamWaitEvent(net->aux[k], net->aux_ev[0], 0);
+        net->have_prev_start = false;
+    }
     // optional stagger: sub-batch p starts only after sub-batch p-1 has finished its first `lag` launches, so that the
     // streams do not march through the memory-bound and the latency-bound layers in lock step
-    static const int lag = [] { const char* e = getenv("F8_STAGGER"); return e ? atoi(e) : 2; }();   // measured: lag 0/1/2/4/8 = 56.06/56.37/56.65/56.34/55.1 k img/s
+    static const int lag_env = [] { const char* e = getenv("F8_STAGGER"); return e ? atoi(e) : -1; }();
+    static const int lag_pipe = [] { const char* e = getenv("F8_STAGGER_PIPELINED"); return e ? atoi(e) : 2; }();
+    const int lag = lag_env >= 0 ? lag_env : (net->pipelined ? lag_pipe : 2);   // measured: lag 0/1/2/4/8 = 56.06/56.37/56.65/56.34/55.1 k img/s
     for (int i = 0; i < ns; ++i)
         for (int p = 0; p < parts; ++p) {
             rc = run_step(net, net->steps[i], input, output, cut[p], cut[p + 1] - cut[p], p, net->aux[p]);

@@ -83,9 +83,13 @@ class PipelinedShardedForward(ShardedForward):
     buffer pairs alternate, and a pair is only reused after its collective has been waited for.  The tensor returned by
     `__call__` is complete after `finish()` (or after the pair comes round again).  Equal shards only."""
 
-    def __init__(self, forward_local, num_classes: int, n_local: int, device, group=None):
+    def __init__(self, forward_local, num_classes: int, n_local: int, device, group=None, lagged=False):
         super().__init__(forward_local, num_classes, group)
         self.n_local = n_local
+        # lagged: the net runs with f8_net_set_pipelined(1), whose contract wants a buffer free ONE CALL before the run that
+        # writes it: the collective of the previous batch is then waited for at the top of this call (the wait lands on the
+        # caller's stream, which the net's sub-batch streams only follow with one call of lag: it stalls no compute)
+        self.lagged = lagged
         self.local = [torch.empty((n_local, num_classes), dtype=torch.float32, device=device) for _ in range(2)]
         world = self.world
         self.full = [torch.empty((n_local * world, num_classes), dtype=torch.float32, device=device) for _ in range(2)] \
@@ -96,9 +100,10 @@ class PipelinedShardedForward(ShardedForward):
     def __call__(self, x_local, n_total=None):
         k = self.i & 1
         self.i += 1
-        if self.work[k] is not None:
-            self.work[k].wait()            # the pair's previous collective (two batches ago) is done before its buffers are rewritten
-            self.work[k] = None
+        for j in ((k, k ^ 1) if self.lagged else (k,)):
+            if self.work[j] is not None:
+                self.work[j].wait()        # a pair's previous collective is done before its buffers are rewritten
+                self.work[j] = None
         self.forward_local(x_local, self.local[k])
         if self.world > 1:
             self.work[k] = dist.all_gather_into_tensor(self.full[k], self.local[k], group=self.group, async_op=True)

@@ -162,6 +162,11 @@ class F8Net:
             check(self._L.f8_net_run(self._h, x.data_ptr(), out.data_ptr(), N, ctypes.c_void_p(stream)))
         return out
 
+    def set_pipelined(self, on=True):
+        """Let consecutive runs overlap (f8_net_set_pipelined): the caller keeps inputs / outputs of consecutive runs in
+        buffers that were ready one call earlier (static input, double-buffered outputs)."""
+        check(self._L.f8_net_set_pipelined(self._h, int(bool(on))))
+
     def run_f32(self, images, normalize, out=None):
         """images: float32 CUDA tensor [N,C,H,W] as forward_loss receives them (fix_train.py:676-692); the input
         quantisation runs inside the input kernel.  normalize: FLAGS.normalize of the reference."""

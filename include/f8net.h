@@ -177,6 +177,15 @@ int f8_net_run(f8_net* net, const int32_t* input_dev, void* output_dev, int N, v
  * images_dev: float32 NCHW [N,C,H,W].  F8_ERR_INVALID if normalize == 0 and the net's input fraclen is not 8. */
 int f8_net_run_f32(f8_net* net, const float* images_dev, int normalize, void* output_dev, int N, void* stream);
 
+/* Pipelined submission (off by default).  By default a run starts after everything enqueued on `stream` before it,
+ * which includes the PREVIOUS run's join: consecutive runs execute back to back.  With pipelining on, the caller
+ * promises one call of slack on its buffers — the input of run i was complete, and the output buffer of run i free,
+ * by the time run i-1 was submitted (static or double-buffered buffers) — and the sub-batches of run i then start as
+ * soon as the sub-batches of run i-1 that use the same arena have finished: the tail of one run overlaps the head of
+ * the next (its memory-bound early stages with the previous run's compute-bound late stages).  Results still become
+ * visible in `stream` order (every run joins `stream`).  Same `stream` for consecutive pipelined runs. */
+int f8_net_set_pipelined(f8_net* net, int on);
+
 /* f8_net_run cuts a batch of N into this many independent sub-batches (1..4) that it runs on
  * internal streams forked from / joined to `stream` (no host synchronisation); every planned launch
  * is therefore issued this many times per run, each over N / parts images. */

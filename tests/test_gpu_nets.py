@@ -108,3 +108,27 @@ def test_full_size_batch_properties(dev, arch, n):
     np.testing.assert_array_equal(permuted, full[perm])
     np.testing.assert_array_equal(full[:2], oracle.net_forward(spec, params, x[:2], x_fl))
     assert np.count_nonzero(full) > 0.9 * full.size
+
+
+def test_pipelined_runs_overlap_safely(dev):
+    """f8_net_set_pipelined: consecutive runs may overlap when the caller double-buffers; every run's result still equals
+    the strictly ordered one (different inputs per run, two alternating output buffers, many runs in flight)."""
+    from f8net_amd.net import build_net
+    spec = topology.get('resnet50', normalize=True)
+    params = synth.make_params(spec, seed=1234, fraclens=topology.R50_NVIDIA_FRACLENS)
+    n = 64
+    net = build_net(spec, params, max_batch=n, hw=224)
+    xs = [torch.from_numpy(synth.make_input(spec, params, n, 224, seed=100 + i)[0]).to(dev) for i in range(3)]
+    want = [net.run(x).cpu().numpy() for x in xs]
+    assert not np.array_equal(want[0], want[1])
+    net.set_pipelined(True)
+    outs = [torch.empty((n, spec.num_classes), dtype=torch.float32, device=dev) for _ in range(2)]
+    hist = []
+    for rep in range(12):
+        o = outs[rep & 1]
+        net.run(xs[rep % 3], out=o)
+        hist.append(o.clone())        # consumer enqueued right after its run: the buffer is free one call before it is rewritten
+    torch.cuda.synchronize(dev)
+    net.set_pipelined(False)
+    for rep, y in enumerate(hist):
+        np.testing.assert_array_equal(y.cpu().numpy(), want[rep % 3])
