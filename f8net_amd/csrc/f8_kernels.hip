@@ -1115,8 +1115,8 @@ static hipError_t launch_conv_t(const ConvArgs& a, int grid, hipStream_t s) {
     const int deep_nk = conv_deep_nk();
     constexpr int DST = (4 * TILE <= 65536) ? 4 : ((3 * TILE <= 65536) ? 3 : 2);
     const bool deep = (DST > ST) && ((a.ktot + a.ktot2) / BK >= deep_nk);
-    if (a.x2) {   // dual GEMM (downsample join): 1x1 / no padding, 64-wide cout tiles only
-        if constexpr (BN == 64 && BK == 64) {
+    if (a.x2) {   // dual GEMM (downsample join): 1x1 / no padding; 64-wide cout tiles, or 128x128 for the wide late stages
+        if constexpr (BK == 64 && (BN == 64 || (BN == 128 && BM == 128))) {
             if (pad || res) return hipErrorInvalidValue;
             if (deep) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, false, true, DST, true>), dim3(grid), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WPX, WCO, false, true, ST, true>), dim3(grid), dim3(256), 0, s, a);

@@ -767,7 +767,11 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     const int M1 = T[nd.out].H * T[nd.out].W;
                     if (!pick_conv_tile(M1 * max_batch, nd.coutP, nd.ck, nd.fused_add >= 0, &nd.tile))
                         return fail(F8_ERR_UNSUPPORTED, "finalize: no conv kernel instance for ck=%d coutP=%d", nd.ck, nd.coutP);
-                    if (nd.dual >= 0) { nd.tile.bn = 64; nd.tile.bk = 64; }       // the dual-GEMM instances
+                    if (nd.dual >= 0) {       // the dual-GEMM instances: 128x64 / 64x64, or 128x128 where many cout tiles re-read X
+                        static const int wide = [] { const char* e = getenv("F8_DUAL_WIDE"); return e ? atoi(e) : 2048; }();   // measured: 7x7x2048 join 67 -> 52 us; 14x14x1024 and 28x28x512 are slower with the wide tile
+                        nd.tile.bk = 64;
+                        if (nd.coutP >= wide && nd.tile.bm == 128) nd.tile.bn = 128; else nd.tile.bn = 64;
+                    }
                     if (!nd.stem && nd.cd.groups == 1 && nd.cd.kernel == 1 && nd.cd.pad == 0 && nd.ck == nd.cd.cin) {
                         static const int split = [] { const char* e = getenv("F8_SPLIT"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
                         const int launch_px = M1 * std::max(1, max_batch / split);
