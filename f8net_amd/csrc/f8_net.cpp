@@ -546,6 +546,40 @@ static void select_outputs(f8_net* net, int t, OutSel* o, std::vector<int>* extr
         }
 }
 
+// Name (layer key + kernel variant) and device symbol (as rocprofv3 prints it) of a conv step; depends on the tile.
+static void label_conv_step(f8_net* net, Step& st, const Node& nd) {
+    auto& ND = net->nodes;
+    const f8_conv_desc& d = nd.cd;
+    const Tensor& s = net->tensors[nd.a];
+    char buf[160];
+    if (nd.depthwise) snprintf(buf, sizeof buf, "dwconv3x3s%d:%s", d.stride, tname(net, nd.out).c_str());
+    else snprintf(buf, sizeof buf, "conv%dx%ds%d_t%dx%dx%d%s%s:%s", d.kernel, d.kernel, d.stride, nd.tile.bm, nd.tile.bn,
+                  nd.tile.bk, nd.stem ? "_stem" : "", st.res_t >= 0 ? "_res" : (nd.dual >= 0 ? "_dual" : ""),
+                  (nd.dual >= 0 ? tname(net, ND[nd.dual].out) + "+" + tname(net, nd.out) : tname(net, nd.out)).c_str());
+    if (nd.c1_bn > 0) snprintf(buf, sizeof buf, "conv1x1s%d_blk128x%d%s:%s", d.stride, nd.c1_bn, st.res_t >= 0 ? "_res" : (nd.dual >= 0 ? "_dual" : ""),
+                               (nd.dual >= 0 ? tname(net, ND[nd.dual].out) + "+" + tname(net, nd.out) : tname(net, nd.out)).c_str());
+    if (nd.p3_R > 0) snprintf(buf, sizeof buf, "conv3x3s1_patch_R%dx%d_bn%d%s:%s", nd.p3_R, nd.p3_imgs, nd.p3_bn, st.res_t >= 0 ? "_res" : "",
+                              tname(net, nd.out).c_str());
+    st.name = buf;
+    if (nd.depthwise) snprintf(buf, sizeof buf, "f8::dwconv3x3_dot4_kernel<%d, 2>", d.stride);
+    else if (nd.c1_bn > 0) snprintf(buf, sizeof buf, "f8::conv1x1_block_kernel<%d, %s, %s>", nd.c1_bn, (st.res_t >= 0 || nd.dual >= 0) ? "true" : "false",
+                                    nd.dual >= 0 ? "true" : "false");
+    else if (nd.p3_R > 0) snprintf(buf, sizeof buf, "f8::conv3x3_patch_kernel<%d, %d, %d, %d, %d, %d, %s>", d.cin, s.W, nd.p3_R, nd.p3_imgs, nd.p3_bn,
+                                   d.cin == 64 ? 64 : (nd.p3_bn == 128 ? 128 : 256), st.res_t >= 0 ? "true" : "false");   // keep in sync with launch_conv3x3_patch
+    else {
+        const int wpx = (nd.tile.bm == 128 && nd.tile.bn <= 64) ? 4 : 2, wco = 4 / wpx;
+        // keep in sync with launch_conv_t (f8_kernels.hip)
+        const int tile_b = (nd.tile.bm + nd.tile.bn) * nd.tile.bk;
+        const int dst = (4 * tile_b <= 65536) ? 4 : ((3 * tile_b <= 65536) ? 3 : 2);
+        const int ksteps = (nd.ktot + (nd.dual >= 0 ? ND[nd.dual].ktot : 0)) / nd.tile.bk;
+        const int stages = (dst > 2 && ksteps >= conv_deep_nk()) ? dst : 2;     // ring depth rule of launch_conv_t
+        snprintf(buf, sizeof buf, "f8::conv_igemm_kernel<%d, %d, %d, %d, %d, %s, %s, %d, %s>", nd.tile.bm, nd.tile.bn, nd.tile.bk, wpx, wco,
+                 (d.pad > 0 && !nd.stem) ? "true" : "false", (st.res_t >= 0 || nd.dual >= 0) ? "true" : "false", stages,
+                 nd.dual >= 0 ? "true" : "false");
+    }
+    st.kernel = buf;
+}
+
 int f8_net_finalize(f8_net* net, int max_batch) {
     if (!net) return fail(F8_ERR_INVALID, "f8_net_finalize: null net");
     if (net->finalized) return fail(F8_ERR_STATE, "f8_net_finalize: already finalized");
@@ -818,33 +852,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 st.bytes_per_img = b;
                 st.bytes_const = nd.depthwise ? (double)s.Cs * 13 : (double)nd.coutP * (nd.ktot + 4);
                 if (nd.dual >= 0) st.bytes_const += (double)ND[nd.dual].coutP * (ND[nd.dual].ktot + 4);
-                char buf[160];
-                if (nd.depthwise) snprintf(buf, sizeof buf, "dwconv3x3s%d:%s", d.stride, tname(net, nd.out).c_str());
-                else snprintf(buf, sizeof buf, "conv%dx%ds%d_t%dx%dx%d%s%s:%s", d.kernel, d.kernel, d.stride, nd.tile.bm, nd.tile.bn,
-                              nd.tile.bk, nd.stem ? "_stem" : "", st.res_t >= 0 ? "_res" : (nd.dual >= 0 ? "_dual" : ""),
-                              (nd.dual >= 0 ? tname(net, ND[nd.dual].out) + "+" + tname(net, nd.out) : tname(net, nd.out)).c_str());
-                if (nd.c1_bn > 0) snprintf(buf, sizeof buf, "conv1x1s%d_blk128x%d%s:%s", d.stride, nd.c1_bn, st.res_t >= 0 ? "_res" : (nd.dual >= 0 ? "_dual" : ""),
-                                           (nd.dual >= 0 ? tname(net, ND[nd.dual].out) + "+" + tname(net, nd.out) : tname(net, nd.out)).c_str());
-                if (nd.p3_R > 0) snprintf(buf, sizeof buf, "conv3x3s1_patch_R%dx%d_bn%d%s:%s", nd.p3_R, nd.p3_imgs, nd.p3_bn, st.res_t >= 0 ? "_res" : "",
-                                          tname(net, nd.out).c_str());
-                st.name = buf;
-                if (nd.depthwise) snprintf(buf, sizeof buf, "f8::dwconv3x3_dot4_kernel<%d, 2>", d.stride);
-                else if (nd.c1_bn > 0) snprintf(buf, sizeof buf, "f8::conv1x1_block_kernel<%d, %s, %s>", nd.c1_bn, (st.res_t >= 0 || nd.dual >= 0) ? "true" : "false",
-                                                nd.dual >= 0 ? "true" : "false");
-                else if (nd.p3_R > 0) snprintf(buf, sizeof buf, "f8::conv3x3_patch_kernel<%d, %d, %d, %d, %d, %d, %s>", d.cin, s.W, nd.p3_R, nd.p3_imgs, nd.p3_bn,
-                                               d.cin == 64 ? 64 : (nd.p3_bn == 128 ? 128 : 256), st.res_t >= 0 ? "true" : "false");   // keep in sync with launch_conv3x3_patch
-                else {
-                    const int wpx = (nd.tile.bm == 128 && nd.tile.bn <= 64) ? 4 : 2, wco = 4 / wpx;
-                    // keep in sync with launch_conv_t (f8_kernels.hip)
-                    const int tile_b = (nd.tile.bm + nd.tile.bn) * nd.tile.bk;
-                    const int dst = (4 * tile_b <= 65536) ? 4 : ((3 * tile_b <= 65536) ? 3 : 2);
-                    const int ksteps = (nd.ktot + (nd.dual >= 0 ? ND[nd.dual].ktot : 0)) / nd.tile.bk;
-                    const int stages = (dst > 2 && ksteps >= conv_deep_nk()) ? dst : 2;     // ring depth rule of launch_conv_t
-                    snprintf(buf, sizeof buf, "f8::conv_igemm_kernel<%d, %d, %d, %d, %d, %s, %s, %d, %s>", nd.tile.bm, nd.tile.bn, nd.tile.bk, wpx, wco,
-                             (d.pad > 0 && !nd.stem) ? "true" : "false", (st.res_t >= 0 || nd.dual >= 0) ? "true" : "false", stages,
-                             nd.dual >= 0 ? "true" : "false");
-                }
-                st.kernel = buf;
+                label_conv_step(net, st, nd);
                 break;
             }
             case N_ADD: {
@@ -1198,6 +1206,56 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
     }
     if (e != hipSuccess) return hip_fail(e, st.name.c_str());
     return F8_OK;
+}
+
+static int split_batch(const f8_net* net, int N, int cut[5]);
+
+// Measured tile choice: every implicit-GEMM conv step is timed on the device with each tile that has a kernel
+// instance (HIP events, best of a few repetitions, on garbage activations: integer kernels are data-independent in
+// time) and keeps the fastest.  Results are bit-identical for every tile; only the plan description changes.
+int f8_net_autotune(f8_net* net, int N, void* stream) {
+    if (!net || !net->finalized) return fail(F8_ERR_STATE, "f8_net_autotune: not finalized");
+    if (N < 1 || N > net->max_batch) return fail(F8_ERR_INVALID, "f8_net_autotune: N=%d outside [1,%d]", N, net->max_batch);
+    int rc = f8_net_upload(net);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    int cut[5];
+    (void)split_batch(net, N, cut);
+    const int n_launch = cut[1] - cut[0];                      // images of one sub-batch launch
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(F8_ERR_HIP, "f8_net_autotune: events");
+    static const int cand_bm[4] = {128, 128, 64, 64}, cand_bn[4] = {128, 64, 128, 64};
+    int changed = 0;
+    for (auto& st : net->steps) {
+        if (st.kind != S_CONV) continue;
+        Node& nd = net->nodes[st.node];
+        if (nd.c1_bn > 0 || nd.p3_R > 0) continue;
+        const ConvTile keep = nd.tile;
+        ConvTile best = keep; float best_ms = 1e30f;
+        for (int c = 0; c < 4; ++c) {
+            ConvTile t = keep; t.bm = cand_bm[c]; t.bn = cand_bn[c];
+            if (t.bn > 64 && nd.coutP <= 64) continue;
+            if (nd.dual >= 0 && !(t.bn == 64 || (t.bn == 128 && t.bm == 128))) continue;     // dual-GEMM instances
+            if (t.bm == 64 && t.bn == 32) continue;
+            nd.tile = t;
+            if (run_step(net, st, nullptr, nullptr, 0, n_launch, 0, s) != F8_OK) { (void)hipGetLastError(); continue; }   // no instance
+            float ms_min = 1e30f;
+            for (int rep = 0; rep < 3; ++rep) {
+                (void)hipEventRecord(e0, s);
+                for (int k = 0; k < 4; ++k) (void)run_step(net, st, nullptr, nullptr, 0, n_launch, 0, s);
+                (void)hipEventRecord(e1, s);
+                if (hipEventSynchronize(e1) != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return fail(F8_ERR_HIP, "f8_net_autotune: sync"); }
+                float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+                if (ms < ms_min) ms_min = ms;
+            }
+            const float bias = (t.bm == keep.bm && t.bn == keep.bn) ? 0.97f : 1.0f;   // switch only for a clear (> 3 %) win
+            if (ms_min * bias < best_ms) { best_ms = ms_min * bias; best = t; }
+        }
+        nd.tile = best;
+        if (best.bm != keep.bm || best.bn != keep.bn) { ++changed; label_conv_step(net, st, nd); }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return changed;
 }
 
 // Cuts the batch into up to F8_SPLIT (default 2, max 4) sub-batches; every I32T form needs each cut at a

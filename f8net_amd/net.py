@@ -162,6 +162,14 @@ class F8Net:
             check(self._L.f8_net_run(self._h, x.data_ptr(), out.data_ptr(), N, ctypes.c_void_p(stream)))
         return out
 
+    def autotune(self, N, device=None):
+        """Measured tile selection for runs of N images (f8_net_autotune).  Returns the number of launches re-tiled."""
+        import torch
+        dev = torch.device('cuda', torch.cuda.current_device()) if device is None else device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            return check(self._L.f8_net_autotune(self._h, int(N), ctypes.c_void_p(stream)))
+
     def set_pipelined(self, on=True):
         """Let consecutive runs overlap (f8_net_set_pipelined): the caller keeps inputs / outputs of consecutive runs in
         buffers that were ready one call earlier (static input, double-buffered outputs)."""

@@ -177,6 +177,12 @@ int f8_net_run(f8_net* net, const int32_t* input_dev, void* output_dev, int N, v
  * images_dev: float32 NCHW [N,C,H,W].  F8_ERR_INVALID if normalize == 0 and the net's input fraclen is not 8. */
 int f8_net_run_f32(f8_net* net, const float* images_dev, int normalize, void* output_dev, int N, void* stream);
 
+/* Optional measured tile selection: times every implicit-GEMM convolution launch of a sub-batch of an N-image run on
+ * the current device with each tile shape that has a kernel instance (HIP events on `stream`) and keeps the fastest; a
+ * tile only replaces the planner's choice for a > 3 % win.  Outputs are bit-identical for every tile.  Blocks until
+ * done (tens of milliseconds); returns the number of launches whose tile changed, or a negative status. */
+int f8_net_autotune(f8_net* net, int N, void* stream);
+
 /* Pipelined submission (off by default).  By default a run starts after everything enqueued on `stream` before it,
  * which includes the PREVIOUS run's join: consecutive runs execute back to back.  With pipelining on, the caller
  * promises one call of slack on its buffers — the input of run i was complete, and the output buffer of run i free,

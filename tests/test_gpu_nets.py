@@ -132,3 +132,17 @@ def test_pipelined_runs_overlap_safely(dev):
     net.set_pipelined(False)
     for rep, y in enumerate(hist):
         np.testing.assert_array_equal(y.cpu().numpy(), want[rep % 3])
+
+
+def test_autotuned_plan_is_bit_identical(dev, golden_dir):
+    """f8_net_autotune only re-tiles launches: the logits still equal the reference golden."""
+    from f8net_amd.net import build_net
+    g = np.load(os.path.join(golden_dir, 'net_resnet50.npz'))
+    spec = topology.get('resnet50', normalize=bool(g['normalize']))
+    params = synth.make_params(spec, seed=1234, fraclens=topology.R50_NVIDIA_FRACLENS)
+    x, _ = synth.make_input(spec, params, 1, 224, seed=7)
+    net = build_net(spec, params, max_batch=4, hw=224)
+    before = net.describe()
+    changed = net.autotune(4, dev)
+    assert changed >= 0 and (changed == 0) == (net.describe() == before)
+    np.testing.assert_array_equal(net.run(torch.from_numpy(x).to(dev)).cpu().numpy(), g['s1234_hw224_n1/logits'])
