@@ -47,7 +47,10 @@ struct FusedCfg {
     static constexpr int LDS_BYTES = PATCH_BYTES + MID2_BYTES + 2 * RING;
 };
 
-template <int C, int MID, int W, int R>
+// DS = the stage's FIRST bottleneck when it keeps the resolution (ResNet-50 stage 0: 64 -> 64 -> 64 -> 256 with a 1x1
+// shortcut conv 64 -> 256 instead of an identity): P3 has no residual stream to read; the join's second operand is a
+// second product Wsc . x over the same pixels, whose x fragments are still in LDS from P1 (C == 64: one K step).
+template <int C, int MID, int W, int R, int COUT = C, bool DS = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MID <= 128 ? 4 : 2)))
 fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so that two workgroups share a CU (LDS allows it)
     using Cfg = FusedCfg<C, MID, W, R>;
@@ -59,7 +62,9 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
     constexpr int CMW = CM / 2;                          // co tiles per wave in P1 / P2
     constexpr int NK1 = C / 64;                          // P1 K steps
     constexpr int NK2 = 9 * (MID / 64);                  // P2 K steps (tap-major, 64-byte channel chunks)
-    constexpr int NC3 = C / 64;                          // P3 chunks of 64 output channels
+    constexpr int NC3 = COUT / 64;                       // P3 chunks of 64 output channels
+    static_assert(DS || COUT == C, "identity blocks keep the channel count");
+    static_assert(!DS || (C == 64 && MID == 64), "DS instance: one P1 K step, 4 KB weight tiles");
     constexpr int KK3 = MID / 32;
     constexpr int X1_BYTES = Cfg::X1_BYTES, RING = Cfg::RING;
     constexpr int PATCH_BYTES = Cfg::PATCH_BYTES, MID2_BYTES = Cfg::MID2_BYTES;
@@ -97,6 +102,7 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
     const __amdgpu_buffer_rsrc_t rw0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w0, 0, a.w0_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2, 0, a.w2_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw4 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w4, 0, a.w4_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwsc = __builtin_amdgcn_make_buffer_rsrc((void*)(DS ? a.wsc : a.w4), 0, DS ? a.wsc_bytes : 0u, 0x00020000);
 
 #ifdef F8_TRACE
     unsigned long long tt[8]; tt[0] = __builtin_readcyclecounter();
@@ -159,6 +165,13 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
     };
     auto issue_w4 = [&](int c, int slot) {               // 64 output channels x MID bytes
         char* base = ring + slot * RING;
+        if (DS && wave >= 4) {                           // DS: waves 4..7 fetch the shortcut tile (64 couts x C bytes) behind the W4 tile
+            const int sl = tid - 256;
+            const int row = sl >> 2, chunk = (sl & 3) ^ S64::f(row);
+            const unsigned woff = (unsigned)((c * 64 + row) * C + chunk * 16);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwsc, (__attribute__((address_space(3))) void*)(base + 4096 + (wave - 4) * 1024), 16, woff, 0, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < WL; ++j) {
             const unsigned woff = w4b[j] + (unsigned)(c * 64 * MID);
@@ -166,6 +179,14 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw4, (__attribute__((address_space(3))) void*)(base + j * 8192 + wave * 1024), 16, woff, 0, 0, 0);
         }
     };
+
+    v4i xs[2] = {};                                      // DS: x fragments of the shortcut product (read at the end of P1)
+    int* const bias_lds = (int*)(lds + Cfg::LDS_BYTES);  // DS: b4[COUT] then bsc[COUT] (a global bias load per chunk would expose its latency:
+    if (DS) {                                            //     there is no residual stream whose prefetch could hide it)
+        static_assert(!DS || COUT * 2 <= 512, "one bias word per thread");
+        if (tid < COUT) bias_lds[tid] = a.b4[tid];
+        else if (tid < 2 * COUT) bias_lds[tid] = a.bsc[tid - COUT];
+    }
 
     // =========================================================================================
     // P1: mid1 = requant(relu(W0 . x8 + b0)) on (R+2) x W pixels  ->  patch
@@ -217,6 +238,12 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
             }
         }
         F8_TT(1);
+        if (DS) {   // the shortcut's x fragments (this wave's output pixel tile, all of K = C) from the P1 stage, before P2 reuses the slot
+            const int op = wa * 32 + l31;
+            const int prow = W + (op < OUT_PX ? op : OUT_PX - 1);        // P1 pixel index of the output pixel (skip the halo row)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) xs[kk] = *(const v4i*)(ring + ((NK1 - 1) & 1) * RING + prow * 64 + (((kk * 2 + lh) ^ S64::f(prow)) << 4));
+        }
         // first W2 stage can already travel: its slot was last read two steps ago
         issue_w2(0, NK1 & 1);
 
@@ -259,7 +286,7 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
     const bool opix_ok = opix < rows_out * W;
     const int m = m_tile + opix;                         // global output pixel
     const int mc = opix_ok ? m : m_tile;                 // padding lanes: any valid pixel (loads only)
-    v4i rv[4], rn[4];                                    // residual of the current / next 64-channel chunk (this wave: 32 ch)
+    v4i rv[4] = {}, rn[4] = {};                          // residual of the current / next 64-channel chunk (this wave: 32 ch)
     auto load_res = [&](v4i (&dst)[4], int c) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) dst[g] = *(const v4i*)(a.xr + i32t_index(mc, c * 64 + wb * 32 + 8 * g + 4 * lh, C));
@@ -312,7 +339,7 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
         asm volatile("" ::: "memory");
         issue_w4(0, (S0 + NK2) & 1);
         asm volatile("" ::: "memory");   // the loads below must stay behind this DMA (counted wait in P3)
-        load_res(rv, 0);
+        if (!DS) load_res(rv, 0);
 
         const int floor0 = a.relu_b ? 0 : INT32_MIN;
 #pragma unroll
@@ -352,7 +379,17 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
             // stores (4 for the int32 form + 1 per int8 form; every wave has live lanes, so all of them issue).
             // A smaller count would be safe but would drain the residual prefetch on every chunk (measured: P3
             // 30k -> cycles per tile); a larger one would race.
-            if (c == 0) wait_vmcnt<4>();
+            if (DS) {                                    // no residual prefetch: only the previous chunk's stores are newer than the DMA
+                if (c == 0) wait_vmcnt<0>();
+                else switch (n_store) {
+                    case 1: wait_vmcnt<1>(); break;
+                    case 2: wait_vmcnt<2>(); break;
+                    case 4: wait_vmcnt<4>(); break;
+                    case 5: wait_vmcnt<5>(); break;
+                    case 6: wait_vmcnt<6>(); break;
+                    default: wait_vmcnt<0>(); break;
+                }
+            } else if (c == 0) wait_vmcnt<4>();
             else switch (n_store) {
                 case 1: wait_vmcnt<5>(); break;
                 case 2: wait_vmcnt<6>(); break;
@@ -364,13 +401,18 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                // chunk 0: also "mid2 complete"
             const int cot = c * 64 + wb * 32;
-            v4i bq4[4];                                  // this chunk's bias: requested before the DMA / prefetch below
+            v4i bq4[4], bqs[DS ? 4 : 1];                 // this chunk's biases: requested before the DMA / prefetch below
+            if (DS) {                                    // ... or read from LDS (visible since the P1 / P2 barriers)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bq4[g] = *(const v4i*)(a.b4 + cot + 8 * g + 4 * lh);
+                for (int g = 0; g < 4; ++g) { bq4[g] = *(const v4i*)(bias_lds + cot + 8 * g + 4 * lh); bqs[g] = *(const v4i*)(bias_lds + COUT + cot + 8 * g + 4 * lh); }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bq4[g] = *(const v4i*)(a.b4 + cot + 8 * g + 4 * lh);
+            }
             asm volatile("" ::: "memory");
             if (c + 1 < NC3) issue_w4(c + 1, (S0 + c + 1) & 1);
             asm volatile("" ::: "memory");
-            load_res(nxt, c + 1 < NC3 ? c + 1 : c);      // always 4 loads per wave: the counted wait relies on it
+            if (!DS) load_res(nxt, c + 1 < NC3 ? c + 1 : c);   // always 4 loads per wave: the counted wait relies on it
             const char* base = ring + ((S0 + c) & 1) * RING;
             if (c == 0) {
 #pragma unroll
@@ -384,14 +426,26 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
                 const v4i wf = *(const v4i*)(base + SM::off(wb * 32 + l31, kk * 2 + lh));
                 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, xf[kk], acc, 0, 0, 0);
             }
+            v16i acs;                                    // DS: shortcut product Wsc . x of this chunk
+            if (DS) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acs[r] = 0;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const v4i wf = *(const v4i*)(base + 4096 + (wb * 32 + l31) * 64 + (((kk * 2 + lh) ^ S64::f(l31)) << 4));
+                    acs = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, xs[kk], acs, 0, 0, 0);
+                }
+            }
             int y[4][4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const v4i bv = bq4[g];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const unsigned v = (unsigned)acc[4 * g + e] + (unsigned)bv[e];
-                    const unsigned s = (v << a.acc_shl) + ((unsigned)cur[g][e] << a.res_shl);
+                    unsigned v = (unsigned)acc[4 * g + e] + (unsigned)bv[e];          // body.4 (+ bias)
+                    unsigned o = (unsigned)cur[g][e];                                  // identity block: the block input
+                    if (DS) { o = v; v = (unsigned)acs[4 * g + e] + (unsigned)bqs[g][e]; }   // DS: the shortcut conv hosts the join
+                    const unsigned s = (v << a.acc_shl) + (o << a.res_shl);
                     y[g][e] = max(clamp_sym31((int)s), floor1);
                 }
             }
@@ -399,7 +453,7 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     v4i o = {y[g][0], y[g][1], y[g][2], y[g][3]};
-                    *(v4i*)(a.out32 + i32t_index(m, cot + 8 * g + 4 * lh, C)) = o;
+                    *(v4i*)(a.out32 + i32t_index(m, cot + 8 * g + 4 * lh, COUT)) = o;
                 }
             }
 #pragma unroll
@@ -414,7 +468,7 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
                 auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
                 if (opix_ok) {
                     v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
-                    *(v4i*)(a.q[k].ptr + (size_t)m * C + cot + 16 * lh) = o;
+                    *(v4i*)(a.q[k].ptr + (size_t)m * COUT + cot + 16 * lh) = o;
                 }
             }
         };
@@ -433,12 +487,13 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
 #endif
 }
 
-template <int C, int MID, int W, int R>
+template <int C, int MID, int W, int R, int COUT = C, bool DS = false>
 static hipError_t launch_fused_t(const FusedArgs& a, hipStream_t s) {
     using Cfg = FusedCfg<C, MID, W, R>;
+    constexpr int LDS = Cfg::LDS_BYTES + (DS ? 2 * COUT * 4 : 0);
     static bool attr_set = false;
     if (!attr_set) {   // dynamic LDS above 64 KB must be opted into once per kernel
-        hipError_t e = hipFuncSetAttribute((const void*)fused_bottleneck_kernel<C, MID, W, R>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)fused_bottleneck_kernel<C, MID, W, R, COUT, DS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -449,7 +504,7 @@ static hipError_t launch_fused_t(const FusedArgs& a, hipStream_t s) {
     FusedArgs b = a;
     const bool tracing = (count++ == want);
     if (tracing) { if (!tbuf) (void)hipMalloc((void**)&tbuf, (size_t)1 << 22); (void)hipMemsetAsync(tbuf, 0, (size_t)grid * 64, s); b.trace = tbuf; }
-    hipLaunchKernelGGL((fused_bottleneck_kernel<C, MID, W, R>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, b);
+    hipLaunchKernelGGL((fused_bottleneck_kernel<C, MID, W, R, COUT, DS>), dim3(grid), dim3(512), LDS, s, b);
     if (tracing) {
         (void)hipStreamSynchronize(s);
         unsigned long long* h = new unsigned long long[(size_t)grid * 8];
@@ -462,16 +517,27 @@ static hipError_t launch_fused_t(const FusedArgs& a, hipStream_t s) {
     }
     return hipGetLastError();
 #else
-    hipLaunchKernelGGL((fused_bottleneck_kernel<C, MID, W, R>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((fused_bottleneck_kernel<C, MID, W, R, COUT, DS>), dim3(grid), dim3(512), LDS, s, a);
     return hipGetLastError();
 #endif
 }
 
 hipError_t launch_fused_bottleneck(const FusedArgs& a, hipStream_t s) {
+    if (a.wsc) {
+        if (a.C == 64 && a.MID == 64 && a.COUT == 256 && a.W == 56 && a.R == 2) return launch_fused_t<64, 64, 56, 2, 256, true>(a, s);
+        return hipErrorInvalidValue;
+    }
     if (a.C == 256 && a.MID == 64 && a.W == 56 && a.R == 2) return launch_fused_t<256, 64, 56, 2>(a, s);
     if (a.C == 512 && a.MID == 128 && a.W == 28 && a.R == 4) return launch_fused_t<512, 128, 28, 4>(a, s);
     if (a.C == 1024 && a.MID == 256 && a.W == 14 && a.R == 7) return launch_fused_t<1024, 256, 14, 7>(a, s);
     return hipErrorInvalidValue;
+}
+
+// stage-opening bottleneck at unchanged resolution (1x1 -> 3x3 -> [1x1 + 1x1 shortcut]): the ResNet-50 stage-0 shape
+bool fused_ds_supported(int C, int MID, int COUT, int H, int W, int* R) {
+    static const int on = [] { const char* e = getenv("F8_FUSE_DS"); return e ? atoi(e) : 1; }();
+    if (on && C == 64 && MID == 64 && COUT == 256 && W == 56 && H % 2 == 0) { *R = 2; return true; }
+    return false;
 }
 
 bool fused_bottleneck_supported(int C, int MID, int H, int W, int* R) {

@@ -102,6 +102,8 @@ struct FusedArgs {
     const int32_t* xr;                     // block input, int32 I32T (residual operand)
     const int8_t* w0; const int8_t* w2; const int8_t* w4; uint32_t w0_bytes, w2_bytes, w4_bytes;   // [MID][C], [MID][9][MID], [C][MID]
     const int32_t* b0; const int32_t* b2; const int32_t* b4;                                        // offset-corrected biases
+    // DS variant (wsc != nullptr): the join's other operand is the shortcut conv Wsc[COUT][C] . x (+ bsc) instead of xr
+    const int8_t* wsc; uint32_t wsc_bytes; const int32_t* bsc; int32_t COUT;
     int32_t N, H, W, C, MID, R, tiles_per_img;
     int32_t n1, lo1, hi1; uint32_t xor1;   // requant body.0 output -> body.2 input format
     int32_t n2, lo2, hi2; uint32_t xor2;   // requant body.2 output -> body.4 input format
@@ -121,6 +123,7 @@ int  conv_deep_nk();
 hipError_t launch_conv(const ConvArgs& a, const ConvTile& t, hipStream_t s);
 hipError_t launch_fused_bottleneck(const FusedArgs& a, hipStream_t s);
 bool fused_bottleneck_supported(int C, int MID, int H, int W, int* R);
+bool fused_ds_supported(int C, int MID, int COUT, int H, int W, int* R);
 // 3x3 / stride 1 / pad 1 with the input patch resident in LDS (f8_conv3x3.hip); config = false: no instance
 bool conv3x3_patch_config(int cin, int H, int W, int coutP, int* R, int* IMGS, int* BN);
 hipError_t launch_conv3x3_patch(const ConvArgs& a, int cin, hipStream_t s);

@@ -77,6 +77,7 @@ struct Node {
     bool stem = false, depthwise = false;
     int absorbed_by = -1;              // conv swallowed by a fused bottleneck launch (node id of its last conv)
     int fb_a = -1, fb_b = -1, fb_R = 0;  // last conv of a fused bottleneck: its first two convs, rows per tile
+    int fbd_a = -1, fbd_b = -1;          // shortcut conv hosting a fused stage-opening block (DS): body.0 / body.2 (body.4 = `dual`)
     int dual = -1;                     // 1x1 conv hosting a join whose other operand is ANOTHER 1x1 conv (node id): one dual-GEMM launch
     int dual_host = -1;                // ... and that other conv: the node that carries it
     int c1_bn = 0;                     // 1x1 conv on the 8-wave block kernel (cout tile 64 / 128), 0 = implicit-GEMM kernel
@@ -649,6 +650,34 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         h.dual = T[other].prod; g.dual_host = i;
     }
 
+    // ---- 1d. stage-opening bottleneck at unchanged resolution: body.0 -> body.2 -> [body.4 + shortcut] in ONE launch
+    for (int i = 0; fuse_blocks && i < nn; ++i) {
+        Node& h = ND[i];
+        if (h.kind != N_CONV || h.dual < 0 || h.cd.stride != 1 || h.cd.relu || !h.cd.quant_input) continue;
+        Node& g = ND[h.dual];
+        if (g.cd.stride != 1 || !g.cd.quant_input) continue;
+        const Tensor& tb = T[g.a];
+        if (tb.consumers.size() != 1 || g.a == net->out_t) continue;
+        Node& b = ND[tb.prod];
+        if (b.kind != N_CONV || b.fused_add >= 0 || b.absorbed_by >= 0 || b.cd.groups != 1 || b.cd.kernel != 3 || b.cd.stride != 1 || b.cd.pad != 1 ||
+            !b.cd.quant_input) continue;
+        const Tensor& ta = T[b.a];
+        if (ta.consumers.size() != 1 || b.a == net->out_t) continue;
+        Node& a0 = ND[ta.prod];
+        if (a0.kind != N_CONV || a0.fused_add >= 0 || a0.absorbed_by >= 0 || a0.cd.groups != 1 || a0.cd.kernel != 1 || a0.cd.stride != 1 ||
+            a0.cd.pad != 0 || !a0.cd.quant_input || a0.a != h.a) continue;
+        const Tensor& x = T[h.a];
+        int na = 0, nh = 0;
+        if (consumer_format(x, a0.cd, &na, "finalize") || consumer_format(x, h.cd, &nh, "finalize")) continue;
+        if (na != nh || a0.cd.input_signed != h.cd.input_signed) continue;      // one int8 form of the block input serves both
+        const int C = a0.cd.cin, MID = a0.cd.cout;
+        if (b.cd.cin != MID || b.cd.cout != MID || g.cd.cin != MID || g.cd.cout != h.cd.cout || h.cd.cin != C) continue;
+        int R = 0;
+        if (!fused_ds_supported(C, MID, h.cd.cout, x.H, x.W, &R)) continue;
+        a0.absorbed_by = i; b.absorbed_by = i; b.no_classes = true;
+        h.fbd_a = ta.prod; h.fbd_b = tb.prod; h.fb_R = R;
+    }
+
     // ---- 2. which forms does each tensor need?  (reverse order: consumers before producers)
     {
         Tensor& O = T[net->out_t];
@@ -664,6 +693,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 int n = 0;
                 consumer_format(s, nd.cd, &n, "finalize");
                 nd.depthwise = nd.cd.groups != 1;
+                if ((nd.absorbed_by >= 0 && ND[nd.absorbed_by].fbd_b == i) || (nd.dual_host >= 0 && ND[nd.dual_host].fbd_a >= 0)) break;   // DS: in LDS
                 if (nd.fb_a >= 0 || (nd.absorbed_by >= 0 && ND[nd.absorbed_by].fb_b == i)) {
                     // source lives in LDS inside the fused launch: no HBM form.  (The block's first conv
                     // still reads the block input from HBM and falls through to the generic case.)
@@ -757,6 +787,41 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 break;
             }
             case N_CONV: case N_LINEAR: {
+                if (nd.fbd_a >= 0) {
+                    // ---- fused stage-opening block (DS): nd is the shortcut conv, nd.dual the block's last body conv
+                    Node& na = ND[nd.fbd_a]; Node& nb = ND[nd.fbd_b]; Node& ng = ND[nd.dual];
+                    Tensor& x = T[nd.a];
+                    st.kind = S_FUSED;
+                    st.src_t = nd.a;
+                    int n0 = 0; consumer_format(x, na.cd, &n0, "finalize");
+                    st.src_f = find_form(x, FORM_I8, n0, na.cd.input_signed ? 1 : 0);
+                    pack_conv_weights(net, na, x, T[na.out]);
+                    pack_conv_weights(net, nb, T[nb.a], T[nb.out]);
+                    pack_conv_weights(net, ng, T[ng.a], T[ng.out]);
+                    pack_conv_weights(net, nd, x, T[nd.out]);
+                    const Node& ad = ND[nd.fused_add];
+                    const int dfl = T[nd.out].fl - T[ng.out].fl;          // > 0: body.4's result shifts left
+                    st.acc_shl = dfl < 0 ? -dfl : 0; st.res_shl = dfl > 0 ? dfl : 0;
+                    st.relu1 = ad.relu;
+                    out_t = ad.out;
+                    select_outputs(net, out_t, &st.out, &extra);
+                    Tensor& o = T[out_t];
+                    const double px = (double)x.H * x.W;
+                    st.ops_per_img = 2.0 * px * ((double)na.cd.cin * na.cd.cout + 9.0 * nb.cd.cin * nb.cd.cout + (double)ng.cd.cin * ng.cd.cout +
+                                                 (double)nd.cd.cin * nd.cd.cout);
+                    double b = px * x.Cs;                                           // int8 input once
+                    if (st.out.f32 >= 0) b += px * o.Cs * 4;
+                    for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += px * o.Cs;
+                    st.bytes_per_img = b;
+                    st.bytes_const = (double)na.coutP * (na.ktot + 4) + (double)nb.coutP * (nb.ktot + 4) + (double)ng.coutP * (ng.ktot + 4) +
+                                     (double)nd.coutP * (nd.ktot + 4);
+                    st.name = "fused_bottleneck_ds_R" + std::to_string(nd.fb_R) + ":" + tname(net, na.out) + "+" + tname(net, nb.out) + "+" + tname(net, ng.out) + "+" +
+                              tname(net, nd.out);
+                    char kb[160];
+                    snprintf(kb, sizeof kb, "f8::fused_bottleneck_kernel<%d, %d, %d, %d, %d, true>", na.cd.cin, na.cd.cout, x.W, nd.fb_R, nd.cd.cout);
+                    st.kernel = kb;
+                    break;
+                }
                 if (nd.fb_a >= 0) {
                     // ---- fused bottleneck block: nd is its last conv
                     Node& na = ND[nd.fb_a]; Node& nb = ND[nd.fb_b];
@@ -785,7 +850,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     st.bytes_const = (double)na.coutP * (na.ktot + 4) + (double)nb.coutP * (nb.ktot + 4) + (double)nd.coutP * (nd.ktot + 4);
                     st.name = "fused_bottleneck_R" + std::to_string(nd.fb_R) + ":" + tname(net, na.out) + "+" + tname(net, nb.out) + "+" + tname(net, nd.out);
                     char kb[160];
-                    snprintf(kb, sizeof kb, "f8::fused_bottleneck_kernel<%d, %d, %d, %d>", na.cd.cin, na.cd.cout, x.W, nd.fb_R);
+                    snprintf(kb, sizeof kb, "f8::fused_bottleneck_kernel<%d, %d, %d, %d, %d, false>", na.cd.cin, na.cd.cout, x.W, nd.fb_R, na.cd.cin);
                     st.kernel = kb;
                     break;
                 }
@@ -1130,6 +1195,32 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             break;
         }
         case S_FUSED: {
+            if (nd.fbd_a >= 0) {      // stage-opening block: nd = shortcut conv, nd.dual = body.4
+                const Node& na = net->nodes[nd.fbd_a]; const Node& nb = net->nodes[nd.fbd_b]; const Node& ng = net->nodes[nd.dual];
+                const Tensor& x = T[st.src_t]; const Form& xF = x.forms[st.src_f];
+                FusedArgs a{};
+                a.x8 = (const int8_t*)fp(xF); a.x_bytes = (uint32_t)(xF.bytes_per_img * N);
+                a.w0 = (const int8_t*)(net->d_w + na.w_off); a.w0_bytes = (uint32_t)((size_t)na.coutP * na.ktot);
+                a.w2 = (const int8_t*)(net->d_w + nb.w_off); a.w2_bytes = (uint32_t)((size_t)nb.coutP * nb.ktot);
+                a.w4 = (const int8_t*)(net->d_w + ng.w_off); a.w4_bytes = (uint32_t)((size_t)ng.coutP * ng.ktot);
+                a.wsc = (const int8_t*)(net->d_w + nd.w_off); a.wsc_bytes = (uint32_t)((size_t)nd.coutP * nd.ktot);
+                a.b0 = (const int32_t*)(net->d_w + na.b_off); a.b2 = (const int32_t*)(net->d_w + nb.b_off);
+                a.b4 = (const int32_t*)(net->d_w + ng.b_off); a.bsc = (const int32_t*)(net->d_w + nd.b_off);
+                a.N = N; a.H = x.H; a.W = x.W; a.C = na.cd.cin; a.MID = na.cd.cout; a.COUT = nd.cd.cout; a.R = nd.fb_R;
+                a.tiles_per_img = (x.H + nd.fb_R - 1) / nd.fb_R;
+                auto fmt = [&](const Node& cons, const Tensor& src, int32_t* n, int32_t* lo, int32_t* hi, uint32_t* x_or) {
+                    int nn = 0; consumer_format(src, cons.cd, &nn, "run");
+                    *n = nn; *lo = cons.cd.input_signed ? -127 : 0; *hi = cons.cd.input_signed ? 127 : 255;
+                    *x_or = cons.cd.input_signed ? 0u : 0x80808080u;
+                };
+                fmt(nb, T[nb.a], &a.n1, &a.lo1, &a.hi1, &a.xor1);
+                fmt(ng, T[ng.a], &a.n2, &a.lo2, &a.hi2, &a.xor2);
+                a.relu_a = na.cd.relu; a.relu_b = nb.cd.relu;
+                a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1;
+                fill_out(&a.out32, a.q);
+                e = launch_fused_bottleneck(a, s);
+                break;
+            }
             const Node& na = net->nodes[nd.fb_a]; const Node& nb = net->nodes[nd.fb_b];
             const Tensor& x = T[st.src_t]; const Form& xF = x.forms[st.src_f];
             FusedArgs a{};

@@ -110,6 +110,9 @@ def test_plan_keeps_int32_only_where_semantics_need_it():
     # downsample blocks: no int32 tensor between body.4 and the shortcut conv (one dual-GEMM launch)
     import re
     assert not any(re.search(r'conv1x1s1_t\d+x\d+x\d+:stage_\d_layer_0\.body\.4 ', l) for l in lines)
+    # the stage-0 opening block (body.0 and shortcut.0 share one int8 form of the block input in the real fraclen table)
+    # is ONE launch: 1x1 -> 3x3 -> [1x1 + shortcut 1x1] + join
+    assert sum('fused_bottleneck_ds' in l for l in lines) == 1 and net.num_launches == 42
     # the stem emits int8 straight into an int8 max-pool (requant commutes with max)
     assert any('maxpool_i8' in l for l in lines)
     # algorithmic bytes are reported per launch and sum to less than the structural model

@@ -249,3 +249,50 @@ def test_downsample_block_dual_gemm_matches_oracle(dev, shape, variant):
     assert net.output_fraclen == want_fl
     np.testing.assert_array_equal(got, want)
     assert (np.abs(want.astype(np.int64)) > 2**30).any()       # the join ran at full int32 width (wrap-around arithmetic)
+
+
+@pytest.mark.parametrize('variant', ['body_shifts_left', 'shortcut_shifts_left', 'different_input_formats'])
+def test_stage_opening_block_fused_matches_oracle(dev, variant):
+    """ResNet-50's stage-0 opening block (64 -> 64 -> 64 -> 256 + 1x1 shortcut, stride 1, 56 wide) as a net of its own:
+    planned as ONE fused launch when body.0 and the shortcut read the same int8 form of the block input, as separate
+    launches otherwise; either way the int32 block output equals the oracle's IntBlock.forward."""
+    from f8net_amd import topology
+    from f8net_amd.net import F8Net
+    Cin, MID, Cout, H, W, N = 64, 64, 256, 6, 56, 3
+    body = [topology.ConvSpec('blk.body.0', Cin, MID, 1, 1, 0, relu=True),
+            topology.ConvSpec('blk.body.2', MID, MID, 3, 1, 1, relu=True),
+            topology.ConvSpec('blk.body.4', MID, Cout, 1, 1, 0)]
+    sc = topology.ConvSpec('blk.shortcut.0', Cin, Cout, 1, 1, 0)
+    b = topology.BlockSpec('blk', body, sc, residual=True, post_relu=True)
+    fls = {'blk.body.0': (4, 7), 'blk.body.2': (3, 6), 'blk.body.4': (3, 5), 'blk.shortcut.0': (4, 7)}       # 8 vs 11
+    if variant == 'shortcut_shifts_left':
+        fls.update({'blk.body.4': (6, 7), 'blk.shortcut.0': (4, 6)})                                             # 13 vs 10
+    if variant == 'different_input_formats':
+        fls['blk.shortcut.0'] = (5, 7)
+    x_fl = 9
+    params = {}
+    for c in body + [sc]:
+        in_fl, w_fl = fls[c.key]
+        params[c.key + '.weight'] = np.clip(synth.rand_normal_int(25, c.key + 'w' + variant, (c.cout, c.cin, c.k, c.k), 50.0), -127, 127).astype(np.int32)
+        params[c.key + '.bias'] = synth.rand_normal_int(26, c.key + 'b', (c.cout,), 2.0 ** 27).astype(np.int32)
+        params[c.key + '.weight_fraclen'] = np.array(w_fl, np.int32)
+        params[c.key + '.input_fraclen'] = np.array([in_fl], np.int32)
+    x = synth.rand_normal_int(27, 'dsf' + variant, (N, Cin, H, W), 2.0e3).astype(np.int32)
+    net = F8Net()
+    t = net.input(Cin, H, W, x_fl)
+    r = t
+    for c in body:
+        r = net.conv(r, params[c.key + '.weight'], params[c.key + '.bias'], stride=1, pad=c.pad, groups=1,
+                     weight_fl=fls[c.key][1], input_fl=fls[c.key][0], input_signed=False, quant_input=True, relu=c.relu)
+    s = net.conv(t, params[sc.key + '.weight'], params[sc.key + '.bias'], stride=1, pad=0, groups=1,
+                 weight_fl=fls[sc.key][1], input_fl=fls[sc.key][0], input_signed=False, quant_input=True, relu=False)
+    r = net.add(r, s, relu=True)
+    net.output(r, as_float=False)
+    net.finalize(N)
+    plan = net.describe()
+    assert ('fused_bottleneck_ds' in plan) == (variant != 'different_input_formats'), plan
+    got = net.run(_t(x, dev)).cpu().numpy().reshape(N, Cout, H, W)
+    want, want_fl = oracle.block_forward(b, params, x, x_fl)
+    assert net.output_fraclen == want_fl
+    np.testing.assert_array_equal(got, want)
+    assert (np.abs(want.astype(np.int64)) > 2**30).any()
