@@ -18,13 +18,18 @@ __device__ __forceinline__ int med3i(int v, int lo, int hi) {
 }
 
 // int_op_only_fix_quant on one value; n, lo, hi are wave-uniform.
-// n > 0: q = (v + 2^(n-1)) >> n, with the LSB cleared on an exact tie (== ((r >> (n+1)) << 1)):
-//        tie <=> low n bits of r = v + 2^(n-1) are all zero.  Branch-free on purpose (a data-dependent
-//        `if` here makes hipcc emit an exec-mask branch per value).
-__device__ __forceinline__ int requant_shr(int v, int n, unsigned half, unsigned mask, int lo, int hi) {
-    const unsigned r = (unsigned)v + half;
-    const int keep = ((r & mask) == 0u) ? ~1 : ~0;
-    return med3i(((int)r >> n) & keep, lo, hi);
+// n > 0 (fix_quant_ops.py:99-104): q = (v + 2^(n-1)) >> n, except on an exact tie (v mod 2^n == 2^(n-1)), where the result
+// is ((v + 2^(n-1)) >> (n+1)) << 1, i.e. the even neighbour.  With v = k*2^n + f (k = v >> n arithmetic, 0 <= f < 2^n) both
+// cases are   q = (v + (2^(n-1) - 1) + (k & 1)) >> n :
+//   the carry into bit n happens iff f + (k&1) >= 2^(n-1) + 1: k even -> f > half (a tie stays at k, even);
+//   k odd -> f >= half (a tie goes to k+1, even).  Overflow: v + half and v + half - 1 + (k&1) wrap together (when v + half
+//   == 2^31 exactly, f == half and k is odd), and 2^32 is a multiple of 2^n, so the identity also holds mod 2^32.
+// Four VALU operations (v_bfe_u32, v_add3_u32, v_ashrrev_i32, v_med3_i32) instead of seven, branch-free; the epilogues of
+// the small convolutions are VALU-bound (f8_stem.hip: ~2300 of ~6000 cycles per tile were requant arithmetic).
+__device__ __forceinline__ int requant_shr(int v, int n, unsigned half, unsigned /*mask*/, int lo, int hi) {
+    const unsigned odd = __builtin_amdgcn_ubfe((unsigned)v, (unsigned)n, 1u);
+    const int r = (int)((unsigned)v + (half - 1u) + odd);
+    return med3i(r >> n, lo, hi);
 }
 __device__ __forceinline__ int requant_shl(int v, int n, int lo, int hi) {   // n <= 0
     return med3i((int)((unsigned)v << (-n)), lo, hi);

@@ -113,6 +113,17 @@ struct FusedArgs {
     void* trace;                           // tuning builds (F8_TRACE) only
 };
 
+// ResNet head in one launch: 7x7/2 conv + ReLU + requant (unsigned 8-bit) + 3x3/2 max-pool (f8_stem.hip).
+struct StemPoolArgs {
+    const int8_t* x; uint32_t x_bytes;     // haloed NHWC4 input [N][Hp][Wp][4], halo = conv pad + org pixels
+    const int8_t* w; uint32_t w_bytes;     // [64][7][32 B]
+    const int32_t* bias;                   // [64], offset-corrected (single class: the halo is biased zero)
+    int32_t N, Hp, Wp, org;
+    int32_t Pc, Qc, P, Q;                  // conv output size, pooled size
+    int32_t relu0, qn, qlo, qhi; uint32_t bias_xor;
+    int8_t* out;                           // pooled int8 NHWC, 64 channels
+};
+
 struct ConvTile { int bm, bn, bk; };
 
 // Tile choice for a conv; returns false if no kernel instance fits (ck % bk).
@@ -131,6 +142,8 @@ hipError_t launch_conv3x3_patch(const ConvArgs& a, int cin, hipStream_t s);
 // mode 0 plain, 1 residual-carrying, 2 dual; M = output pixels of one launch
 int conv1x1_block_config(int M, int coutP, int ktot, int ktot2, int mode);
 hipError_t launch_conv1x1_block(const ConvArgs& a, int bn, hipStream_t s);
+bool stem_pool_supported(int cin, int cout, int k, int stride, int pad, int pool_k, int pool_s, int pool_p, int P, int Q);
+hipError_t launch_stem_pool(const StemPoolArgs& a, hipStream_t s);
 hipError_t launch_dwconv(const DwArgs& a, hipStream_t s);
 hipError_t launch_maxpool(const PoolArgs& a, hipStream_t s);
 hipError_t launch_avgpool(const AvgArgs& a, hipStream_t s);

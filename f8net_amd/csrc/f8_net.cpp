@@ -77,6 +77,7 @@ struct Node {
     bool stem = false, depthwise = false;
     int absorbed_by = -1;              // conv swallowed by a fused bottleneck launch (node id of its last conv)
     int fb_a = -1, fb_b = -1, fb_R = 0;  // last conv of a fused bottleneck: its first two convs, rows per tile
+    int sp_pool = -1, sp_conv = -1;      // stem conv <-> max-pool fused into one launch (f8_stem.hip)
     int fbd_a = -1, fbd_b = -1;          // shortcut conv hosting a fused stage-opening block (DS): body.0 / body.2 (body.4 = `dual`)
     int dual = -1;                     // 1x1 conv hosting a join whose other operand is ANOTHER 1x1 conv (node id): one dual-GEMM launch
     int dual_host = -1;                // ... and that other conv: the node that carries it
@@ -87,7 +88,7 @@ struct Node {
     size_t rc_off = 0, cc_off = 0; int ncc = 0;      // border-class tables (0 = single class)
     ConvTile tile{};
 };
-enum StepKind { S_INPUT, S_CONV, S_DW, S_ADD, S_MAXPOOL, S_AVGPOOL, S_REQUANT, S_OUTPUT, S_FUSED };
+enum StepKind { S_INPUT, S_CONV, S_DW, S_ADD, S_MAXPOOL, S_AVGPOOL, S_REQUANT, S_OUTPUT, S_FUSED, S_STEMPOOL };
 struct OutSel { int t = -1; int f32 = -1; int f8[2] = {-1, -1}; };
 struct Step {
     int kind; int node;
@@ -705,16 +706,16 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     break;
                 }
                 nd.stem = !nd.depthwise && nd.cd.cin <= 4 && ND[s.prod].kind == N_INPUT && nd.cd.kernel <= 8 &&
-                          s.consumers.size() == 1 && nd.a != net->out_t;
+                          s.consumers.size() == 1 && nd.a != net->out_t && n == 0;
                 if (nd.stem) {
                     const int P = T[nd.out].H, Q = T[nd.out].W;
                     (void)P;
                     const int f = add_form(s, FORM_STEM, 0, 0);
                     Form& F = s.forms[f];
                     F.sgn = nd.cd.input_signed ? 1 : 0;
-                    F.pad = nd.cd.pad;
-                    F.Hp = s.H + 2 * nd.cd.pad;
-                    F.Wp = round_up(std::max(s.W + 2 * nd.cd.pad, nd.cd.stride * (Q - 1) + 8), 2);
+                    F.pad = nd.cd.pad + (nd.sp_pool >= 0 ? 2 : 0);      // fused stem + pool: 2 more halo pixels keep every tile's patch in memory
+                    F.Hp = s.H + 2 * F.pad;
+                    F.Wp = round_up(std::max(s.W + 2 * F.pad, nd.cd.stride * (Q - 1) + 8), nd.sp_pool >= 0 ? 4 : 2);
                 } else {
                     add_form(s, FORM_I8, n, nd.cd.input_signed ? 1 : 0);
                 }
@@ -730,6 +731,16 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 break;
             case N_MAXPOOL: {
                 Tensor& o = T[nd.out];
+                if (o.forms.size() == 1 && o.forms[0].kind == FORM_I8 && o.forms[0].sgn == 0 && T[nd.a].consumers.size() == 1 && nd.a != net->out_t) {
+                    // ResNet head: 7x7/2 stem conv + this pool in one launch (the conv output never leaves LDS)
+                    Node& c = ND[T[nd.a].prod];
+                    if (c.kind == N_CONV && c.cd.groups == 1 && c.fused_add < 0 && ND[T[c.a].prod].kind == N_INPUT && T[c.a].consumers.size() == 1 &&
+                        c.a != net->out_t && (!c.cd.quant_input || T[c.a].fl == c.cd.input_fl) &&
+                        stem_pool_supported(c.cd.cin, c.cd.cout, c.cd.kernel, c.cd.stride, c.cd.pad, nd.pk, nd.pstride, nd.ppad, o.H, o.W)) {
+                        c.sp_pool = i; nd.sp_conv = T[nd.a].prod;
+                        break;                                   // no HBM form of the conv output
+                    }
+                }
                 if (o.forms.size() == 1 && o.forms[0].kind == FORM_I8)
                     add_form(T[nd.a], FORM_I8, o.forms[0].n, o.forms[0].sgn);
                 else
@@ -766,6 +777,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         Node& nd = ND[i];
         if (nd.kind == N_ADD && nd.fused_into >= 0) continue;
         if (nd.kind == N_CONV && (nd.absorbed_by >= 0 || nd.dual_host >= 0)) continue;
+        if (nd.kind == N_MAXPOOL && nd.sp_conv >= 0) continue;
         Step st; st.node = i;
         std::vector<int> extra;
         int out_t = nd.out;
@@ -787,6 +799,25 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 break;
             }
             case N_CONV: case N_LINEAR: {
+                if (nd.sp_pool >= 0 && nd.stem) {
+                    // ---- ResNet head: stem conv + max-pool in one launch
+                    const Node& pl = ND[nd.sp_pool];
+                    Tensor& s = T[nd.a]; Tensor& o = T[pl.out];
+                    st.kind = S_STEMPOOL;
+                    st.src_t = nd.a; st.src_f = find_form(s, FORM_STEM, 0, 0);
+                    st.relu0 = nd.cd.relu;
+                    pack_conv_weights(net, nd, s, T[nd.out]);
+                    out_t = pl.out;
+                    select_outputs(net, out_t, &st.out, &extra);
+                    const f8_conv_desc& d = nd.cd;
+                    const double cpx = (double)T[nd.out].H * T[nd.out].W;
+                    st.ops_per_img = 2.0 * cpx * d.cout * d.cin * d.kernel * d.kernel;
+                    st.bytes_per_img = (double)s.H * s.W * 4 + (double)o.H * o.W * o.Cs;
+                    st.bytes_const = (double)nd.coutP * (nd.ktot + 4);
+                    st.name = "stem7x7s2+maxpool3x3s2:" + tname(net, nd.out) + "+" + tname(net, pl.out);
+                    st.kernel = "f8::stem_pool_kernel";
+                    break;
+                }
                 if (nd.fbd_a >= 0) {
                     // ---- fused stage-opening block (DS): nd is the shortcut conv, nd.dual the block's last body conv
                     Node& na = ND[nd.fbd_a]; Node& nb = ND[nd.fbd_b]; Node& ng = ND[nd.dual];
@@ -1192,6 +1223,23 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             }
             fill_out(&a.out32, a.q);
             e = nd.c1_bn > 0 ? launch_conv1x1_block(a, nd.c1_bn, s) : (nd.p3_R > 0 ? launch_conv3x3_patch(a, d.cin, s) : launch_conv(a, nd.tile, s));
+            break;
+        }
+        case S_STEMPOOL: {
+            const Node& pl = net->nodes[nd.sp_pool];
+            const Tensor& sT = T[st.src_t]; const Form& sF = sT.forms[st.src_f];
+            const Tensor& cT = T[nd.out]; const Tensor& oT = T[pl.out];
+            StemPoolArgs a{};
+            a.x = (const int8_t*)fp(sF); a.x_bytes = (uint32_t)(sF.bytes_per_img * N);
+            a.w = (const int8_t*)(net->d_w + nd.w_off); a.w_bytes = (uint32_t)((size_t)nd.coutP * nd.ktot);
+            a.bias = (const int32_t*)(net->d_w + nd.b_off);
+            a.N = N; a.Hp = sF.Hp; a.Wp = sF.Wp; a.org = sF.pad - nd.cd.pad;
+            a.Pc = cT.H; a.Qc = cT.W; a.P = oT.H; a.Q = oT.W;
+            a.relu0 = st.relu0;
+            const Form& oF = oT.forms[st.out.f8[0]];
+            a.qn = oF.n; a.qlo = 0; a.qhi = 255; a.bias_xor = 0x80808080u;
+            a.out = (int8_t*)fp(oF);
+            e = launch_stem_pool(a, s);
             break;
         }
         case S_FUSED: {
