@@ -34,12 +34,16 @@ __device__ __forceinline__ int requant_shr(int v, int n, unsigned half, unsigned
 __device__ __forceinline__ int requant_shl(int v, int n, int lo, int hi) {   // n <= 0
     return med3i((int)((unsigned)v << (-n)), lo, hi);
 }
+// Either direction, BRANCH-FREE (n is wave-uniform, but an `if (n > 0)` per value survives unrolling as one scalar branch
+// per value with register shuffles around it: the stem / fused / patch epilogues spent more time there than in the
+// arithmetic).  n > 0: the sum above; n <= 0: v << -n (fix_quant_ops.py:105-106); the selects below are scalar and hoisted.
 __device__ __forceinline__ int requant1(int v, int n, int lo, int hi) {
-    if (n > 0) {
-        const unsigned half = 1u << (n - 1);
-        return requant_shr(v, n, half, (half << 1) - 1u, lo, hi);
-    }
-    return requant_shl(v, n, lo, hi);
+    const int shr = n > 0 ? n : 0, shl = n > 0 ? 0 : -n;
+    const unsigned hm1 = n > 0 ? (1u << (shr - (n > 0 ? 1 : 0))) - 1u : 0u;
+    const unsigned width = n > 0 ? 1u : 0u;                                  // v_bfe_u32 with width 0 yields 0
+    const unsigned odd = __builtin_amdgcn_ubfe((unsigned)v, (unsigned)shr, width);
+    const int r = (int)(((unsigned)v << shl) + hm1 + odd);
+    return med3i(r >> shr, lo, hi);
 }
 
 // q = n / d for a divisor known on the host: q = (t + ((n - t) >> sh1)) >> sh2, t = mulhi(n, magic)
