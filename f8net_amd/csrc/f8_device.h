@@ -53,9 +53,11 @@ __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic, int sh1
     return (t + ((n - t) >> sh1)) >> sh2;
 }
 
+// low bytes of four values -> one dword (a = byte 0): three v_perm_b32 instead of and / and / and / shift-or x3
 __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d) {
-    return ((unsigned)a & 0xffu) | (((unsigned)b & 0xffu) << 8) | (((unsigned)c & 0xffu) << 16) |
-           ((unsigned)d << 24);
+    const unsigned lo = __builtin_amdgcn_perm((unsigned)b, (unsigned)a, 0x0c0c0400u);   // {a.b0, b.b0, 0, 0}
+    const unsigned hi = __builtin_amdgcn_perm((unsigned)d, (unsigned)c, 0x0c0c0400u);   // {c.b0, d.b0, 0, 0}
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);                                    // {lo.b0, lo.b1, hi.b0, hi.b1}
 }
 
 // int32 tensors live in an MFMA-fragment-tiled layout ("I32T"), not NHWC: blocks of 32 pixels x 32
