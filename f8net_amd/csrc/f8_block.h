@@ -79,7 +79,7 @@ __device__ __forceinline__ void block_exchange(v16i (&acc)[2][2], v4i* park, int
 template <int NF, bool HAS_RES>
 __device__ __forceinline__ void block_finish(const ConvArgs& a, v4i (&fin)[NF][4], v4i (&bq)[NF][4], v4i (&rv)[HAS_RES ? NF : 1][4],
                                              int cot0, int m, bool pix_ok, int lh) {
-    const int floor0 = a.relu0 ? 0 : INT32_MIN, floor1 = a.relu1 ? 0 : INT32_MIN;
+    const int floor0 = a.relu0 ? 0 : INT32_MIN, floor1 = a.relu1 ? 0 : -2147483647 /* the join's clamp_(min=-(2^31-1)) and the ReLU floor are one max */;
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
         const int cot = cot0 + i * 32;
@@ -92,7 +92,7 @@ __device__ __forceinline__ void block_finish(const ConvArgs& a, v4i (&fin)[NF][4
                 int v = max((int)((unsigned)fin[i][g][e] + (unsigned)bq[i][g][e]), floor0);
                 if (HAS_RES) {
                     const unsigned s = ((unsigned)v << a.acc_shl) + ((unsigned)rv[i][g][e] << a.res_shl);
-                    v = max(clamp_sym31((int)s), floor1);
+                    v = max((int)s, floor1);
                 }
                 y[g][e] = v;
             }

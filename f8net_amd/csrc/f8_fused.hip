@@ -368,7 +368,7 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
     // =========================================================================================
     {
         constexpr int S0 = (NK1 + NK2) & 1;
-        const int floor1 = a.relu1 ? 0 : INT32_MIN;
+        const int floor1 = a.relu1 ? 0 : -2147483647 /* the join's clamp_(min=-(2^31-1)) and the ReLU floor are one max */;
         const int n_store = (a.out32 ? 4 : 0) + (a.q[0].ptr ? 1 : 0) + (a.q[1].ptr ? 1 : 0);   // store instructions per wave per chunk
         static_assert((NPO - 1) * 32 < OUT_PX, "every pixel tile has live lanes (store count in the counted wait)");
         v4i xf[KK3];                                     // this wave's mid2 fragments are chunk-invariant: read once
@@ -446,7 +446,7 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
                     unsigned o = (unsigned)cur[g][e];                                  // identity block: the block input
                     if (DS) { o = v; v = (unsigned)acs[4 * g + e] + (unsigned)bqs[g][e]; }   // DS: the shortcut conv hosts the join
                     const unsigned s = (v << a.acc_shl) + (o << a.res_shl);
-                    y[g][e] = max(clamp_sym31((int)s), floor1);
+                    y[g][e] = max((int)s, floor1);
                 }
             }
             if (a.out32 && opix_ok) {

@@ -28,7 +28,7 @@ namespace f8 {
 template <int BM, int BN, int WPX, int WCO, bool HAS_RES, int TCO, int TPX>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, v16i (&acc)[TCO][TPX], v4i (&rv)[HAS_RES ? TCO : 1][HAS_RES ? TPX : 1][4],
                                               int m0, int co0, int wpx, int wco, int l31, int lh) {
-    const int floor0 = a.relu0 ? 0 : INT32_MIN, floor1 = a.relu1 ? 0 : INT32_MIN;
+    const int floor0 = a.relu0 ? 0 : INT32_MIN, floor1 = a.relu1 ? 0 : -2147483647 /* the join's clamp_(min=-(2^31-1)) and the ReLU floor are one max */;
 #pragma unroll
     for (int j = 0; j < TPX; ++j) {
         const int m = m0 + wpx * (BM / WPX) + j * 32 + l31;
@@ -54,7 +54,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, v16i (&acc)[TCO
                     int v = max((int)((unsigned)acc[i][j][4 * g + e] + (unsigned)bv[e]), floor0);
                     if (HAS_RES) {
                         const unsigned s = ((unsigned)v << a.acc_shl) + ((unsigned)rv[i][j][g][e] << a.res_shl);
-                        v = max(clamp_sym31((int)s), floor1);
+                        v = max((int)s, floor1);
                     }
                     y[g][e] = v;
                 }
