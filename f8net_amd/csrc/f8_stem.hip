@@ -84,7 +84,9 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemPoolArgs a) {
     };
     const int t0 = blockIdx.x, step = gridDim.x;
     if (t0 < ntiles) issue_patch(t0, 0);
-    const int floor0 = a.relu0 ? 0 : INT32_MIN;
+    // ReLU before a requant whose clamp starts at 0 is absorbed by the clamp (requant is monotone, requant(v <= 0) <= 0):
+    // the max below then only runs for formats with a negative lower bound
+    const int floor0 = (a.relu0 && a.qlo < 0) ? 0 : INT32_MIN;
     const char* wrow = wl + l31 * WROW + lh * 16;
 
     int it = 0;
@@ -103,11 +105,11 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemPoolArgs a) {
         // ---- conv: 7 K steps (kernel rows); B fragment = 16 of the 32 row bytes of this lane's pixel (two 8-byte reads:
         //      the stride-2 pixel pitch makes odd columns 8-byte aligned only)
         const char* xrow = lds + cur * PATCH_BYTES + ((2 * ri) * PWD + 2 * rj + 4 * lh) * 4;
-        v16i acc[2];
+        v16i acc[2];                                                 // accumulators start at the bias: no add in the epilogue
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0;
+            for (int r = 0; r < 16; ++r) acc[i][r] = bq[i][r >> 2][r & 3];
 #pragma unroll
         for (int r = 0; r < 7; ++r) {
             const v2i x0 = *(const v2i*)(xrow + r * PWD * 4), x1 = *(const v2i*)(xrow + r * PWD * 4 + 8);
@@ -129,7 +131,7 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemPoolArgs a) {
             for (int g = 0; g < 4; ++g) {
                 int y[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = requant1(max((int)((unsigned)acc[i][4 * g + e] + (unsigned)bq[i][g][e]), floor0), a.qn, a.qlo, a.qhi);
+                for (int e = 0; e < 4; ++e) y[e] = requant1(max(acc[i][4 * g + e], floor0), a.qn, a.qlo, a.qhi);
                 d[g] = inside ? pack4(y[0], y[1], y[2], y[3]) : 0u;
             }
             auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);

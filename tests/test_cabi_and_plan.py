@@ -112,9 +112,9 @@ def test_plan_keeps_int32_only_where_semantics_need_it():
     assert not any(re.search(r'conv1x1s1_t\d+x\d+x\d+:stage_\d_layer_0\.body\.4 ', l) for l in lines)
     # the stage-0 opening block (body.0 and shortcut.0 share one int8 form of the block input in the real fraclen table)
     # is ONE launch: 1x1 -> 3x3 -> [1x1 + shortcut 1x1] + join
-    assert sum('fused_bottleneck_ds' in l for l in lines) == 1 and net.num_launches == 42
-    # the stem emits int8 straight into an int8 max-pool (requant commutes with max)
-    assert any('maxpool_i8' in l for l in lines)
+    assert sum('fused_bottleneck_ds' in l for l in lines) == 1 and net.num_launches == 41
+    # the head is ONE launch: stem conv + ReLU + requant + max-pool (requant commutes with max; the 112x112 map stays in LDS)
+    assert any('stem7x7s2+maxpool3x3s2' in l for l in lines) and not any('maxpool_i' in l for l in lines)
     # algorithmic bytes are reported per launch and sum to less than the structural model
     total = sum(net.launch_info(i, 128)[1] for i in range(net.num_launches)) / 128
     assert 40e6 < total < 93.444e6
