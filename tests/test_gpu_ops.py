@@ -296,3 +296,33 @@ def test_stage_opening_block_fused_matches_oracle(dev, variant):
     assert net.output_fraclen == want_fl
     np.testing.assert_array_equal(got, want)
     assert (np.abs(want.astype(np.int64)) > 2**30).any()
+
+
+@pytest.mark.parametrize('case', [(3, 112, 224, True), (2, 224, 224, False), (1, 56, 64, False)], ids=lambda c: 'x'.join(map(str, c)))
+def test_fused_head_stem_conv_maxpool(dev, case):
+    """ResNet head as ONE launch (f8_stem.hip): 7x7/2 conv + ReLU + [requant] + 3x3/2 max-pool, followed by a 1x1 conv that
+    fixes the pool output's int8 format.  Non-square maps, odd batch, signed (normalize) and unsigned inputs, image borders."""
+    from f8net_amd.net import F8Net
+    N, H, W, signed = case
+    lo, hi = (-127, 127) if signed else (0, 255)
+    x = synth.rand_uniform_int(31, f'hx{case}', (N, 3, H, W), lo, hi).astype(np.int32)
+    w1 = np.clip(synth.rand_normal_int(32, 'hw1', (64, 3, 7, 7), 40.0), -127, 127).astype(np.int32)
+    b1 = synth.rand_normal_int(33, 'hb1', (64,), 3.0e4).astype(np.int32)
+    w2 = np.clip(synth.rand_normal_int(34, 'hw2', (32, 64, 1, 1), 40.0), -127, 127).astype(np.int32)
+    b2 = synth.rand_normal_int(35, 'hb2', (32,), 1.0e3).astype(np.int32)
+    in_fl, w_fl, fl2 = (5 if signed else 8), 6, 4
+    net = F8Net()
+    t = net.input(3, H, W, in_fl)
+    c = net.conv(t, w1, b1, stride=2, pad=3, groups=1, weight_fl=w_fl, input_fl=in_fl, input_signed=signed, quant_input=False, relu=True)
+    p = net.maxpool(c, 3, 2, 1)
+    o = net.conv(p, w2, b2, stride=1, pad=0, groups=1, weight_fl=5, input_fl=fl2, input_signed=False, quant_input=True, relu=False)
+    net.output(o, as_float=False)
+    net.finalize(N)
+    P, Q = H // 4, W // 4
+    assert ('stem7x7s2+maxpool3x3s2' in net.describe()) == (P % 7 == 0 and Q % 8 == 0), net.describe()
+    got = net.run(_t(x, dev)).cpu().numpy().reshape(N, 32, P, Q)
+    y = oracle.relu(oracle.conv2d(x, w1, b1, 2, 3))
+    y = oracle.maxpool(y, 3, 2, 1)
+    y = oracle.requant(y, fl2, in_fl + w_fl, False)
+    want = oracle.conv2d(y, w2, b2, 1, 0)
+    np.testing.assert_array_equal(got, want)
