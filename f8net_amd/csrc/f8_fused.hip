@@ -72,10 +72,21 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
     constexpr int WS = MID * 4, WL = (WS + 511) / 512;                  // W0 / W2 tile slots (rows of 64 B); the W4 tile has the same count
     static_assert(NC3 % 2 == 0, "chunk loop is unrolled by two (residual ping-pong)");
 
+    // ALLW (MID == 64, the 56x56 kernels): operands are small enough to sit in LDS WHOLE — all NK1 stages of P1 at once
+    // (laid over the regions that only come alive later) and all of W2 (36 KB) — so P1 and P2 are one wait + one barrier
+    // followed by MFMAs, instead of 4 + 9 latency-bound ring steps (per-workgroup traces: 13.0k + 10.0k cycles of a 44k life).
+    constexpr bool ALLW = (MID == 64);
+    constexpr int W4STAGE = (MID * 64) * (DS ? 2 : 1);                   // one P3 stage: W4 tile (+ shortcut tile)
+    constexpr int W2ALL = NK2 * (MID * 64);
+
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const patch = lds;
     char* const mid2 = lds + PATCH_BYTES;
-    char* const ring = lds + PATCH_BYTES + MID2_BYTES;
+    char* const ring = lds + PATCH_BYTES + MID2_BYTES;                   // !ALLW: two (X1 + W) stages; ALLW: W2 whole, then the W4 ring
+    char* const w4ring = ALLW ? ring + W2ALL : ring;
+    constexpr int W4STRIDE = ALLW ? W4STAGE : RING;
+    constexpr int LDS_END = ALLW ? ((NK1 * RING > PATCH_BYTES + MID2_BYTES + W2ALL + 2 * W4STAGE) ? NK1 * RING : PATCH_BYTES + MID2_BYTES + W2ALL + 2 * W4STAGE)
+                                 : Cfg::LDS_BYTES;
 
     using S64 = Swz<64>;
     using SM = Swz<MID>;
@@ -110,12 +121,13 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
 #else
 #define F8_TT(i)
 #endif
-    // ---- patch <- biased zero everywhere (border and out-of-image rows keep it)
-    {
+    // ---- patch <- biased zero everywhere (border and out-of-image rows keep it); ALLW: after P1 (its stages lie over the patch)
+    auto zero_patch = [&]() {
         const unsigned z = a.xor1;
         const v4i zv = {(int)z, (int)z, (int)z, (int)z};
         for (int o = tid * 16; o < PATCH_BYTES; o += 512 * 16) *(v4i*)(patch + o) = zv;
-    }
+    };
+    if (!ALLW) zero_patch();
 
     // ---- gather descriptors
     unsigned xb1[XL1];
@@ -140,7 +152,7 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
     }
 
     auto issue_p1 = [&](int ks, int slot) {
-        char* base = ring + slot * RING;
+        char* base = ALLW ? lds + slot * RING : ring + slot * RING;
 #pragma unroll
         for (int i = 0; i < XL1; ++i) {
             const unsigned off = xb1[i] == kOOB ? kOOB : xb1[i] + (unsigned)(ks * 64);
@@ -164,12 +176,12 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
         }
     };
     auto issue_w4 = [&](int c, int slot) {               // 64 output channels x MID bytes
-        char* base = ring + slot * RING;
+        char* base = w4ring + slot * W4STRIDE;
         if (DS && wave >= 4) {                           // DS: waves 4..7 fetch the shortcut tile (64 couts x C bytes) behind the W4 tile
             const int sl = tid - 256;
             const int row = sl >> 2, chunk = (sl & 3) ^ S64::f(row);
             const unsigned woff = (unsigned)((c * 64 + row) * C + chunk * 16);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwsc, (__attribute__((address_space(3))) void*)(base + 4096 + (wave - 4) * 1024), 16, woff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwsc, (__attribute__((address_space(3))) void*)(base + MID * 64 + (wave - 4) * 1024), 16, woff, 0, 0, 0);
             return;
         }
 #pragma unroll
@@ -181,7 +193,7 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
     };
 
     v4i xs[2] = {};                                      // DS: x fragments of the shortcut product (read at the end of P1)
-    int* const bias_lds = (int*)(lds + Cfg::LDS_BYTES);  // DS: b4[COUT] then bsc[COUT] (a global bias load per chunk would expose its latency:
+    int* const bias_lds = (int*)(lds + LDS_END);  // DS: b4[COUT] then bsc[COUT] (a global bias load per chunk would expose its latency:
     if (DS) {                                            //     there is no residual stream whose prefetch could hide it)
         static_assert(!DS || COUT * 2 <= 512, "one bias word per thread");
         if (tid < COUT) bias_lds[tid] = a.b4[tid];
@@ -211,13 +223,7 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
 #pragma unroll
             for (int g = 0; g < 4; ++g) bq0[i][g] = *(const v4i*)(a.b0 + (wb * CMW + i) * 32 + 8 * g + 4 * lh);
 
-        issue_p1(0, 0);
-        for (int ks = 0; ks < NK1; ++ks) {
-            wait_vmcnt<0>();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (ks + 1 < NK1) issue_p1(ks + 1, (ks + 1) & 1);
-            const char* base = ring + (ks & 1) * RING;
+        auto p1_mma = [&](const char* base) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 v4i wf[CMW], xf[NP1W];
@@ -236,16 +242,52 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
                         for (int i = 0; i < CMW; ++i) acc[j][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xf[j], acc[j][i], 0, 0, 0);
                 }
             }
+        };
+        if constexpr (ALLW) {
+            // every P1 stage at once (over the patch / mid2 / W2 regions, which are not live yet): one wait, one barrier
+#pragma unroll
+            for (int ks = 0; ks < NK1; ++ks) issue_p1(ks, ks);
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int ks = 0; ks < NK1; ++ks) p1_mma(lds + ks * RING);
+        } else {
+            issue_p1(0, 0);
+            for (int ks = 0; ks < NK1; ++ks) {
+                wait_vmcnt<0>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (ks + 1 < NK1) issue_p1(ks + 1, (ks + 1) & 1);
+                p1_mma(ring + (ks & 1) * RING);
+            }
         }
         F8_TT(1);
         if (DS) {   // the shortcut's x fragments (this wave's output pixel tile, all of K = C) from the P1 stage, before P2 reuses the slot
             const int op = wa * 32 + l31;
             const int prow = W + (op < OUT_PX ? op : OUT_PX - 1);        // P1 pixel index of the output pixel (skip the halo row)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) xs[kk] = *(const v4i*)(ring + ((NK1 - 1) & 1) * RING + prow * 64 + (((kk * 2 + lh) ^ S64::f(prow)) << 4));
+            for (int kk = 0; kk < 2; ++kk) xs[kk] = *(const v4i*)((ALLW ? lds + (NK1 - 1) * RING : ring + ((NK1 - 1) & 1) * RING) + prow * 64 + (((kk * 2 + lh) ^ S64::f(prow)) << 4));
         }
-        // first W2 stage can already travel: its slot was last read two steps ago
-        issue_w2(0, NK1 & 1);
+        if constexpr (ALLW) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                // every wave is done reading the P1 stages
+            // all of W2 (NK2 stages of MID x 64 bytes, stage-major = the order P2 consumes them) travels during the epilogue
+#pragma unroll
+            for (int i = 0; i < (NK2 * WS + 511) / 512; ++i) {
+                const int gs = tid + i * 512;
+                const int j2 = gs / WS, wi = gs - j2 * WS;
+                const int row = wi >> 2, chunk = (wi & 3) ^ S64::f(row);
+                const unsigned woff = (unsigned)(row * (9 * MID) + chunk * 16 + j2 * 64);
+                if ((i * 512 + wave * 64) < NK2 * WS)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw2, (__attribute__((address_space(3))) void*)(ring + i * 8192 + wave * 1024), 16, woff, 0, 0, 0);
+            }
+            zero_patch();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                // the zero fill is complete before anyone writes real pixels
+        } else {
+            // first W2 stage can already travel: its slot was last read two steps ago
+            issue_w2(0, NK1 & 1);
+        }
 
         // epilogue: bias, ReLU, requant to body.2's input format, into the patch
         const int floor0 = a.relu_a ? 0 : INT32_MIN;
@@ -317,12 +359,7 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
         constexpr int S0 = NK1 & 1;                      // ring slot of W2 step 0
         constexpr int CH = MID / 64;                     // 64-byte channel chunks per tap
         int tr = 0, ts = 0, tc = 0;
-        for (int j = 0; j < NK2; ++j) {
-            wait_vmcnt<0>();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                // step 0: also "patch complete"
-            if (j + 1 < NK2) issue_w2(j + 1, (S0 + j + 1) & 1);
-            const char* base = ring + ((S0 + j) & 1) * RING;
+        auto p2_mma = [&](const char* base) {
             const int ppx = bpx + tr * PW + ts;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -334,10 +371,25 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
                 }
             }
             if (++tc == CH) { tc = 0; if (++ts == 3) { ts = 0; ++tr; } }
+        };
+        if constexpr (ALLW) {
+            wait_vmcnt<0>();                             // all of W2 landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                // ... everywhere, and the patch is complete
+#pragma unroll
+            for (int j = 0; j < NK2; ++j) p2_mma(ring + j * (MID * 64));
+        } else {
+            for (int j = 0; j < NK2; ++j) {
+                wait_vmcnt<0>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                // step 0: also "patch complete"
+                if (j + 1 < NK2) issue_w2(j + 1, (S0 + j + 1) & 1);
+                p2_mma(ring + ((S0 + j) & 1) * RING);
+            }
         }
         F8_TT(3);
         asm volatile("" ::: "memory");
-        issue_w4(0, (S0 + NK2) & 1);
+        issue_w4(0, ALLW ? 0 : ((S0 + NK2) & 1));        // ALLW: the W4 ring is its own region (under the last P1 stage: free since the post-P1 barrier)
         asm volatile("" ::: "memory");   // the loads below must stay behind this DMA (counted wait in P3)
         if (!DS) load_res(rv, 0);
 
@@ -410,10 +462,10 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
                 for (int g = 0; g < 4; ++g) bq4[g] = *(const v4i*)(a.b4 + cot + 8 * g + 4 * lh);
             }
             asm volatile("" ::: "memory");
-            if (c + 1 < NC3) issue_w4(c + 1, (S0 + c + 1) & 1);
+            if (c + 1 < NC3) issue_w4(c + 1, ALLW ? ((c + 1) & 1) : ((S0 + c + 1) & 1));
             asm volatile("" ::: "memory");
             if (!DS) load_res(nxt, c + 1 < NC3 ? c + 1 : c);   // always 4 loads per wave: the counted wait relies on it
-            const char* base = ring + ((S0 + c) & 1) * RING;
+            const char* base = w4ring + (ALLW ? (c & 1) : ((S0 + c) & 1)) * W4STRIDE;
             if (c == 0) {
 #pragma unroll
                 for (int kk = 0; kk < KK3; ++kk) xf[kk] = *(const v4i*)(mid2 + SM::off(opix, kk * 2 + lh));
@@ -432,7 +484,7 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
                 for (int r = 0; r < 16; ++r) acs[r] = 0;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
-                    const v4i wf = *(const v4i*)(base + 4096 + (wb * 32 + l31) * 64 + (((kk * 2 + lh) ^ S64::f(l31)) << 4));
+                    const v4i wf = *(const v4i*)(base + MID * 64 + (wb * 32 + l31) * 64 + (((kk * 2 + lh) ^ S64::f(l31)) << 4));
                     acs = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, xs[kk], acs, 0, 0, 0);
                 }
             }
@@ -490,7 +542,11 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
 template <int C, int MID, int W, int R, int COUT = C, bool DS = false>
 static hipError_t launch_fused_t(const FusedArgs& a, hipStream_t s) {
     using Cfg = FusedCfg<C, MID, W, R>;
-    constexpr int LDS = Cfg::LDS_BYTES + (DS ? 2 * COUT * 4 : 0);
+    constexpr int NK1 = C / 64, W2ALL = 9 * (MID / 64) * (MID * 64), W4STAGE = (MID * 64) * (DS ? 2 : 1);      // keep in sync with the kernel
+    constexpr int ALLW_END = (NK1 * Cfg::RING > Cfg::PATCH_BYTES + Cfg::MID2_BYTES + W2ALL + 2 * W4STAGE) ? NK1 * Cfg::RING
+                                                                                                   : Cfg::PATCH_BYTES + Cfg::MID2_BYTES + W2ALL + 2 * W4STAGE;
+    constexpr int LDS = (MID == 64 ? ALLW_END : Cfg::LDS_BYTES) + (DS ? 2 * COUT * 4 : 0);
+    static_assert(LDS <= 80 * 1024 || MID > 64, "two workgroups per CU");
     static bool attr_set = false;
     if (!attr_set) {   // dynamic LDS above 64 KB must be opted into once per kernel
         hipError_t e = hipFuncSetAttribute((const void*)fused_bottleneck_kernel<C, MID, W, R, COUT, DS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
