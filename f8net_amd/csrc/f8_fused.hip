@@ -166,8 +166,14 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw0, (__attribute__((address_space(3))) void*)(base + X1_BYTES + j * 8192 + wave * 1024), 16, woff, 0, 0, 0);
         }
     };
+    // !ALLW: W2 streams through NS2 stages of MID x 64 bytes laid over the two P1 slots (P1's last stage sits in slot 1, so only
+    // the stages inside slot 0 may be issued before P2's first barrier)
+    constexpr int W2B = MID * 64;
+    constexpr int NS2 = (2 * RING / W2B) < 5 ? (2 * RING / W2B) : 5;
+    constexpr int PRE2 = (RING / W2B) < (NS2 - 1) ? (RING / W2B) : (NS2 - 1);
+    static_assert(ALLW || ((NK1 & 1) == 0 && PRE2 >= 1 && (NK2 - 1) % NS2 != 0), "W2 ring placement");
     auto issue_w2 = [&](int j2, int slot) {              // step j2: bytes [j2*64, j2*64+64) of every W2 row (tap-major K)
-        char* base = ring + slot * RING;
+        char* base = ring + slot * W2B;
 #pragma unroll
         for (int j = 0; j < WL; ++j) {
             const unsigned woff = w2b[j] + (unsigned)(j2 * 64);
@@ -285,8 +291,9 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                // the zero fill is complete before anyone writes real pixels
         } else {
-            // first W2 stage can already travel: its slot was last read two steps ago
-            issue_w2(0, NK1 & 1);
+            // the first W2 stages can already travel: slot 0 of the P1 ring was last read two steps ago
+#pragma unroll
+            for (int k = 0; k < PRE2; ++k) issue_w2(k, k);
         }
 
         // epilogue: bias, ReLU, requant to body.2's input format, into the patch
@@ -379,12 +386,22 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
 #pragma unroll
             for (int j = 0; j < NK2; ++j) p2_mma(ring + j * (MID * 64));
         } else {
+            int ldw2 = 0;                                // W2-stage DMA instructions of this wave
+#pragma unroll
+            for (int q = 0; q < WL; ++q) ldw2 += ((q * 512 + wave * 64) < WS) ? 1 : 0;
+            int issued = PRE2;
             for (int j = 0; j < NK2; ++j) {
-                wait_vmcnt<0>();
+                // stage j landed; the stages issued after it may stay in flight (at j == 0 the bias loads above are newer than
+                // the prologue stages, which only makes this first wait conservative)
+                switch ((issued - 1 - j) * ldw2) {
+                    case 0: wait_vmcnt<0>(); break;  case 1: wait_vmcnt<1>(); break;  case 2: wait_vmcnt<2>(); break;
+                    case 3: wait_vmcnt<3>(); break;  case 4: wait_vmcnt<4>(); break;  case 5: wait_vmcnt<5>(); break;
+                    case 6: wait_vmcnt<6>(); break;  case 7: wait_vmcnt<7>(); break;  default: wait_vmcnt<8>(); break;
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();                // step 0: also "patch complete"
-                if (j + 1 < NK2) issue_w2(j + 1, (S0 + j + 1) & 1);
-                p2_mma(ring + ((S0 + j) & 1) * RING);
+                __builtin_amdgcn_s_barrier();            // step 0: also "patch complete" and "P1 ring free"
+                while (issued < NK2 && issued < j + NS2) { issue_w2(issued, issued % NS2); ++issued; }
+                p2_mma(ring + (j % NS2) * W2B);
             }
         }
         F8_TT(3);
