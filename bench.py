@@ -41,10 +41,11 @@ def cpu_baseline(spec, params, x_np, x_fl, ref_logits):
     import numpy as np
     from oracle import oracle
     oracle.build()
+    y1 = oracle.net_forward(spec, params, x_np[:1], x_fl)            # warm-up (thread pool, page faults), also checked below
     t0 = time.time()
-    y1 = oracle.net_forward(spec, params, x_np[:1], x_fl)
-    t1 = time.time() - t0
-    n = int(max(1, min(x_np.shape[0], 64, 15.0 / max(t1, 1e-3))))
+    oracle.net_forward(spec, params, x_np[:4], x_fl)
+    t4 = (time.time() - t0) / 4                                     # seconds per image at a small batch
+    n = int(max(1, min(x_np.shape[0], 12.0 / max(t4, 1e-3))))      # ~10-15 s of CPU work
     t0 = time.time()
     y = oracle.net_forward(spec, params, x_np[:n], x_fl)
     dt = time.time() - t0
