@@ -211,13 +211,7 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
     //     wave (wa, wb): px tiles {wa, wa+4}, co tiles {wb*CMW .. wb*CMW+CMW-1}
     // =========================================================================================
     {
-        v16i acc[NP1W][CMW];
-#pragma unroll
-        for (int j = 0; j < NP1W; ++j)
-#pragma unroll
-            for (int i = 0; i < CMW; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][i][r] = 0;
+        v16i acc[NP1W][CMW];                             // start at the bias (below): no add per value in the epilogue
         unsigned cof[2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) cof[kk] = (unsigned)(((kk * 2 + lh) ^ S64::f(l31)) << 4);
@@ -228,6 +222,12 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
         for (int i = 0; i < CMW; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) bq0[i][g] = *(const v4i*)(a.b0 + (wb * CMW + i) * 32 + 8 * g + 4 * lh);
+#pragma unroll
+        for (int j = 0; j < NP1W; ++j)
+#pragma unroll
+            for (int i = 0; i < CMW; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][i][r] = bq0[i][r >> 2][r & 3];
 
         auto p1_mma = [&](const char* base) {
 #pragma unroll
@@ -313,10 +313,9 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
                 unsigned d[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const v4i bv = bq0[i][g];
                     int y[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) y[e] = requant1(max((int)((unsigned)acc[j][i][4 * g + e] + (unsigned)bv[e]), floor0), a.n1, a.lo1, a.hi1);
+                    for (int e = 0; e < 4; ++e) y[e] = requant1(max(acc[j][i][4 * g + e], floor0), a.n1, a.lo1, a.hi1);
                     d[g] = pack4(y[0], y[1], y[2], y[3]) ^ a.xor1;
                 }
                 auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
@@ -347,10 +346,6 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
     // =========================================================================================
     {
         v16i acc[CMW];
-#pragma unroll
-        for (int i = 0; i < CMW; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0;
         const int oc = opix < OUT_PX ? opix : OUT_PX - 1;   // padding lanes read a valid pixel, result unused
         const int orow = oc / W, ocol = oc - orow * W;
         const int bpx = orow * PW + ocol;                // patch pixel of tap (0,0)
@@ -363,6 +358,10 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
         for (int i = 0; i < CMW; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) bq2[i][g] = *(const v4i*)(a.b2 + (wb * CMW + i) * 32 + 8 * g + 4 * lh);
+#pragma unroll
+        for (int i = 0; i < CMW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = bq2[i][r >> 2][r & 3];
         constexpr int S0 = NK1 & 1;                      // ring slot of W2 step 0
         constexpr int CH = MID / 64;                     // 64-byte channel chunks per tap
         int tr = 0, ts = 0, tc = 0;
@@ -417,10 +416,9 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
             unsigned d[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const v4i bv = bq2[i][g];
                 int y[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = requant1(max((int)((unsigned)acc[i][4 * g + e] + (unsigned)bv[e]), floor0), a.n2, a.lo2, a.hi2);
+                for (int e = 0; e < 4; ++e) y[e] = requant1(max(acc[i][4 * g + e], floor0), a.n2, a.lo2, a.hi2);
                 d[g] = pack4(y[0], y[1], y[2], y[3]) ^ a.xor2;
             }
             auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
@@ -489,7 +487,7 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
             }
             v16i acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0;
+            for (int r = 0; r < 16; ++r) acc[r] = bq4[r >> 2][r & 3];
 #pragma unroll
             for (int kk = 0; kk < KK3; ++kk) {
                 const v4i wf = *(const v4i*)(base + SM::off(wb * 32 + l31, kk * 2 + lh));
@@ -498,7 +496,7 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
             v16i acs;                                    // DS: shortcut product Wsc . x of this chunk
             if (DS) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acs[r] = 0;
+                for (int r = 0; r < 16; ++r) acs[r] = bqs[r >> 2][r & 3];
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     const v4i wf = *(const v4i*)(base + MID * 64 + (wb * 32 + l31) * 64 + (((kk * 2 + lh) ^ S64::f(l31)) << 4));
@@ -508,12 +506,11 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
             int y[4][4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const v4i bv = bq4[g];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    unsigned v = (unsigned)acc[4 * g + e] + (unsigned)bv[e];          // body.4 (+ bias)
+                    unsigned v = (unsigned)acc[4 * g + e];                            // body.4 (the accumulator started at its bias)
                     unsigned o = (unsigned)cur[g][e];                                  // identity block: the block input
-                    if (DS) { o = v; v = (unsigned)acs[4 * g + e] + (unsigned)bqs[g][e]; }   // DS: the shortcut conv hosts the join
+                    if (DS) { o = v; v = (unsigned)acs[4 * g + e]; }                   // DS: the shortcut conv hosts the join
                     const unsigned s = (v << a.acc_shl) + (o << a.res_shl);
                     y[g][e] = max((int)s, floor1);
                 }
