@@ -120,8 +120,9 @@ struct StemPoolArgs {
     const int32_t* bias;                   // [64], offset-corrected (single class: the halo is biased zero)
     int32_t N, Hp, Wp, org;
     int32_t Pc, Qc, P, Q;                  // conv output size, pooled size
-    int32_t relu0, qn, qlo, qhi; uint32_t bias_xor;
-    int8_t* out;                           // pooled int8 NHWC, 64 channels
+    int32_t relu0;
+    int32_t* out32;                        // pooled int32 (I32T, 64 channels) or nullptr
+    QuantOut q[2];                         // pooled int8 NHWC (64 channels) in up to two formats
 };
 
 struct ConvTile { int bm, bn, bk; };

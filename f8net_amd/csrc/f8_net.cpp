@@ -731,7 +731,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 break;
             case N_MAXPOOL: {
                 Tensor& o = T[nd.out];
-                if (o.forms.size() == 1 && o.forms[0].kind == FORM_I8 && o.forms[0].sgn == 0 && T[nd.a].consumers.size() == 1 && nd.a != net->out_t) {
+                if (!o.forms.empty() && T[nd.a].consumers.size() == 1 && nd.a != net->out_t) {
                     // ResNet head: 7x7/2 stem conv + this pool in one launch (the conv output never leaves LDS)
                     Node& c = ND[T[nd.a].prod];
                     if (c.kind == N_CONV && c.cd.groups == 1 && c.fused_add < 0 && ND[T[c.a].prod].kind == N_INPUT && T[c.a].consumers.size() == 1 &&
@@ -812,7 +812,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     const f8_conv_desc& d = nd.cd;
                     const double cpx = (double)T[nd.out].H * T[nd.out].W;
                     st.ops_per_img = 2.0 * cpx * d.cout * d.cin * d.kernel * d.kernel;
-                    st.bytes_per_img = (double)s.H * s.W * 4 + (double)o.H * o.W * o.Cs;
+                    st.bytes_per_img = (double)s.H * s.W * 4 + (double)o.H * o.W * o.Cs * ((st.out.f32 >= 0 ? 4 : 0) + (st.out.f8[0] >= 0) + (st.out.f8[1] >= 0));
                     st.bytes_const = (double)nd.coutP * (nd.ktot + 4);
                     st.name = "stem7x7s2+maxpool3x3s2:" + tname(net, nd.out) + "+" + tname(net, pl.out);
                     st.kernel = "f8::stem_pool_kernel";
@@ -1236,9 +1236,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             a.N = N; a.Hp = sF.Hp; a.Wp = sF.Wp; a.org = sF.pad - nd.cd.pad;
             a.Pc = cT.H; a.Qc = cT.W; a.P = oT.H; a.Q = oT.W;
             a.relu0 = st.relu0;
-            const Form& oF = oT.forms[st.out.f8[0]];
-            a.qn = oF.n; a.qlo = 0; a.qhi = 255; a.bias_xor = 0x80808080u;
-            a.out = (int8_t*)fp(oF);
+            fill_out(&a.out32, a.q);
             e = launch_stem_pool(a, s);
             break;
         }

@@ -7,8 +7,10 @@
 //   * the 35x40-pixel NHWC4 input patch (5.6 KB) and ALL weights (64 couts x 7 kernel rows x 32 B, rows padded to
 //     240 B for conflict-free fragment reads) arrive by LDS-direct DMA once; one kernel row of 8 pixels x 4 channels is
 //     one 32-byte K step, so the conv is 7 MFMA steps per tile with no barrier in between;
-//   * epilogue -> int8 tile in LDS (conv pixels outside the image hold 0: post-ReLU unsigned values make 0 the identity
-//     of max, and every pool window has an in-image tap); pool = packed 16-bit max over 9 LDS reads per 16 channels.
+//   * per 32-channel half: bias + ReLU'd int32 accumulators -> LDS tile (conv pixels outside the image hold the identity of
+//     max: 0 after a ReLU, INT32_MIN otherwise; every pool window has an in-image tap), 3x3 max over int32, THEN the
+//     requantisation(s) on the 56 pooled pixels instead of the 255 conv pixels (requant is monotone, so it commutes with
+//     max; pooling first costs 2.7x fewer vector instructions) -> int32 (I32T) and / or int8 outputs.
 // Arithmetic: the stem of conv_igemm_kernel + maxpool_kernel, bit for bit (reference: fix_resnet.py:354-359; the float
 // MaxPool detour there is exact; requant commutes with max because it is monotone).
 #include "f8_device.h"
@@ -30,7 +32,8 @@ constexpr int PATCH_BYTES = (PSLOTS * 16 + 1023) / 1024 * 1024;
 constexpr int WROW = 240, WCH = WROW / 16;          // weight row: 7 x 32 B + 16 B pad
 constexpr int WSLOTS = 64 * WCH;                    // 960
 constexpr int W_BYTES = WSLOTS * 16;
-constexpr int CT_BYTES = 256 * 64;                  // conv tile: 256 pixel rows x 64 int8 channels
+constexpr int CT_PITCH = 144;                       // one conv-tile row: 32 int32 channels + 16 B pad (conflict-free column access)
+constexpr int CT_BYTES = 256 * CT_PITCH;            // conv tile of ONE 32-channel half
 constexpr int LDS_TOTAL = 2 * PATCH_BYTES + W_BYTES + CT_BYTES;      // two patch slots
 }
 
@@ -84,9 +87,7 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemPoolArgs a) {
     };
     const int t0 = blockIdx.x, step = gridDim.x;
     if (t0 < ntiles) issue_patch(t0, 0);
-    // ReLU before a requant whose clamp starts at 0 is absorbed by the clamp (requant is monotone, requant(v <= 0) <= 0):
-    // the max below then only runs for formats with a negative lower bound
-    const int floor0 = (a.relu0 && a.qlo < 0) ? 0 : INT32_MIN;
+    const int floor0 = a.relu0 ? 0 : INT32_MIN;
     const char* wrow = wl + l31 * WROW + lh * 16;
 
     int it = 0;
@@ -94,10 +95,9 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemPoolArgs a) {
         const int cur = it & 1;
         const bool more = t + step < ntiles;
         if (more) issue_patch(t + step, cur ^ 1);                    // that slot's tile was consumed before the previous epilogue barrier
-        // patch(t) (and, the first time, the weights) landed: only what this wave issued AFTER it may stay in flight —
-        // the next patch (waves 0..5) and the previous tile's pooled store (waves 0..3)
-        const int newer = ((more && dma_wave) ? 1 : 0) + ((it > 0 && wave < 4) ? 1 : 0);
-        if (newer == 0) wait_vmcnt<0>(); else if (newer == 1) wait_vmcnt<1>(); else wait_vmcnt<2>();
+        // patch(t) (and, the first time, the weights) landed: only the next patch (waves 0..5), issued after it, may stay in
+        // flight; the previous tile's output stores are waited for as well (a handful of small stores per wave)
+        if (more && dma_wave) wait_vmcnt<1>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
 
         int n, tp, tq; tile_of(t, &n, &tp, &tq);
@@ -105,11 +105,11 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemPoolArgs a) {
         // ---- conv: 7 K steps (kernel rows); B fragment = 16 of the 32 row bytes of this lane's pixel (two 8-byte reads:
         //      the stride-2 pixel pitch makes odd columns 8-byte aligned only)
         const char* xrow = lds + cur * PATCH_BYTES + ((2 * ri) * PWD + 2 * rj + 4 * lh) * 4;
-        v16i acc[2];                                                 // accumulators start at the bias: no add in the epilogue
+        v16i acc[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = bq[i][r >> 2][r & 3];
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0;
 #pragma unroll
         for (int r = 0; r < 7; ++r) {
             const v2i x0 = *(const v2i*)(xrow + r * PWD * 4), x1 = *(const v2i*)(xrow + r * PWD * 4 + 8);
@@ -120,52 +120,44 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemPoolArgs a) {
                 acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, xf, acc[i], 0, 0, 0);
             }
         }
-        // ---- epilogue -> int8 conv tile in LDS; conv pixels outside the image hold unsigned 0 (plain bytes: the pool
-        //      compares them as unsigned; the HBM copy is biased at the very end)
+        // ---- per 32-channel half: accumulators (+ bias, ReLU) -> int32 tile in LDS -> 3x3 / stride 2 max -> outputs
         const int cp = cp0 + ri, cq = cq0 + rj;
         const bool inside = pix < RPX && cp >= 0 && cp < a.Pc && cq >= 0 && cq < a.Qc;
+        const int ident = a.relu0 ? 0 : INT32_MIN;                   // identity of max for conv pixels outside the image
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            unsigned d[4];
+        for (int h = 0; h < 2; ++h) {
+            if (h) __builtin_amdgcn_s_barrier();                     // half 0's pool reads are done before the tile is rewritten
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                int y[4];
+                v4i o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = requant1(max(acc[i][4 * g + e], floor0), a.qn, a.qlo, a.qhi);
-                d[g] = inside ? pack4(y[0], y[1], y[2], y[3]) : 0u;
+                for (int e = 0; e < 4; ++e) o[e] = inside ? max((int)((unsigned)acc[h][4 * g + e] + (unsigned)bq[h][g][e]), floor0) : ident;
+                *(v4i*)(ct + pix * CT_PITCH + (8 * g + 4 * lh) * 4) = o;
             }
-            auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
-            auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
-            v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
-            *(v4i*)(ct + pix * 64 + i * 32 + 16 * lh) = o;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-
-        // ---- 3x3 / stride 2 max-pool from the tile: thread = (pooled pixel, 16 channels)
-        if (tid < TP * TQ * 4) {
-            const int pp = tid >> 2, c16 = tid & 3;
-            const int pr = pp / TQ, pc = pp - pr * TQ;
-            us2 ev[4], od[4];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (tid < TP * TQ * 8) {                                  // thread = (pooled pixel, 4 channels)
+                const int pp = tid >> 3, c4 = tid & 7;
+                const int pr = pp / TQ, pc = pp - pr * TQ;
+                v4i mx = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { ev[k] = us2{0, 0}; od[k] = us2{0, 0}; }
+                for (int dr = 0; dr < 3; ++dr)
 #pragma unroll
-            for (int dr = 0; dr < 3; ++dr)
+                    for (int dc = 0; dc < 3; ++dc) {
+                        const v4i v = *(const v4i*)(ct + ((2 * pr + dr) * RW + 2 * pc + dc) * CT_PITCH + c4 * 16);
 #pragma unroll
-                for (int dc = 0; dc < 3; ++dc) {
-                    const v4i v = *(const v4i*)(ct + ((2 * pr + dr) * RW + 2 * pc + dc) * 64 + c16 * 16);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const unsigned u = (unsigned)v[k];
-                        ev[k] = __builtin_elementwise_max(ev[k], __builtin_bit_cast(us2, u & 0x00ff00ffu));
-                        od[k] = __builtin_elementwise_max(od[k], __builtin_bit_cast(us2, (u >> 8) & 0x00ff00ffu));
+                        for (int e = 0; e < 4; ++e) mx[e] = max(mx[e], v[e]);
                     }
-                }
-            v4i o;
+                const int m = (n * a.P + TP * tp + pr) * a.Q + TQ * tq + pc;
+                const int c = h * 32 + c4 * 4;
+                if (a.out32) *(v4i*)(a.out32 + i32t_index(m, c, 64)) = mx;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = (int)((__builtin_bit_cast(unsigned, ev[k]) | (__builtin_bit_cast(unsigned, od[k]) << 8)) ^ a.bias_xor);
-            const size_t m = ((size_t)n * a.P + TP * tp + pr) * a.Q + TQ * tq + pc;
-            *(v4i*)(a.out + m * 64 + c16 * 16) = o;
+                for (int k = 0; k < 2; ++k)
+                    if (a.q[k].ptr)
+                        *(unsigned*)(a.q[k].ptr + (size_t)m * 64 + c) =
+                            pack4(requant1(mx[0], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(mx[1], a.q[k].n, a.q[k].lo, a.q[k].hi),
+                                  requant1(mx[2], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(mx[3], a.q[k].n, a.q[k].lo, a.q[k].hi)) ^ a.q[k].bias_xor;
+            }
         }
         // the next iteration's first barrier separates these ct reads from the next epilogue's ct writes
     }
@@ -179,7 +171,7 @@ bool stem_pool_supported(int cin, int cout, int k, int stride, int pad, int pool
 
 hipError_t launch_stem_pool(const StemPoolArgs& a, hipStream_t s) {
     const int ntiles = a.N * (a.P / TP) * (a.Q / TQ);
-    static const int wpc = [] { const char* e = getenv("F8_STEM_WPC"); return e ? atoi(e) : 3; }();     // resident workgroups per CU (44 KB LDS each)
+    static const int wpc = [] { const char* e = getenv("F8_STEM_WPC"); return e ? atoi(e) : 2; }();     // resident workgroups per CU (63 KB LDS each)
     static int ncu = 0;
     if (!ncu) { int dev = 0; hipDeviceProp_t p; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
     const int grid = ntiles < ncu * wpc ? ntiles : ncu * wpc;
