@@ -223,6 +223,69 @@ def child_export(case):
     print(f'[gen_golden] export {case}: {len(names)} layers, weight fraclens {sorted(set(wfl))}, wrote export_{case}.npz')
 
 
+ONNX_LSHIFT = {'stage_0_layer_0.body.0': (6, 0), 'stage_0_layer_0.body.2': (8, 5),      # n = 6 - 8 = -2
+               'stage_1_layer_0.body.0': (5, 1), 'stage_1_layer_0.body.2': (7, 6)}      # n = 6 - 7 = -1
+
+
+def child_onnx(arch):
+    """ONNX importer fixtures: the reference IntModel holding our synthetic integers is exported exactly
+    as the reference does it (myutils/export.py:4-31: torch.onnx.export, opset 11, batch 1, dynamic batch axis); the
+    fixture keeps the file with the payload of its large initializers dropped (the test regenerates them from the same
+    seed) and the logits the PyTorch IntModel returns for a 2-image batch."""
+    import io
+    import torch
+    sys.path.insert(0, REPO)
+    from f8net_amd import onnx_io, synth, topology
+    tag, arch = arch, arch.split('+')[0]                   # 'resnet18+lshift': fraclens that force left-shift requants
+    int_model, FLAGS = build_reference_int_model(arch)
+    normalize = bool(getattr(FLAGS, 'normalize', False))
+    spec = topology.get(arch, normalize=normalize)
+    mods = dict(int_model.named_modules())
+    fr = topology.R50_NVIDIA_FRACLENS if arch == 'resnet50' else (ONNX_LSHIFT if tag.endswith('+lshift') else None)
+    params = synth.make_params(spec, seed=4321, fraclens=fr)
+    with torch.no_grad():
+        for key in spec.layer_keys():
+            m = mods[key]
+            m.weight.data = torch.from_numpy(params[key + '.weight']).clone()
+            m.bias.data = torch.from_numpy(params[key + '.bias']).clone()
+            m.weight_fraclen.copy_(torch.from_numpy(params[key + '.weight_fraclen']))
+            m.input_fraclen.copy_(torch.from_numpy(params[key + '.input_fraclen']))
+    hw = 64
+    x_np, x_fl = synth.make_input(spec, params, 2, hw, seed=11)
+    x = torch.from_numpy(x_np)
+    setattr(x, 'output_fraclen', x_fl)
+    with torch.no_grad():
+        logits = int_model(x).numpy().astype(np.float32)
+    assert np.count_nonzero(logits) > 0.9 * logits.size, 'degenerate logits'
+    # torch's exporter only needs the `onnx` package (absent here) to splice onnxscript functions in; there are none
+    from torch.onnx._internal.torchscript_exporter import onnx_proto_utils
+    onnx_proto_utils._add_onnxscript_fn = lambda proto, custom_opsets: proto
+    # myutils/export.py:7-13 draws randn().to(int32) — its values are irrelevant to the trace; the attribute the
+    # int forward asserts on (fix_resnet.py:353) has to be there, as it is when fix_train.py:683-692 makes the input
+    dummy = torch.from_numpy(x_np[:1].copy())
+    setattr(dummy, 'output_fraclen', x_fl)
+    buf = io.BytesIO()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        torch.onnx.export(int_model, dummy, buf, export_params=True, opset_version=11, do_constant_folding=True,
+                          input_names=['input'], output_names=['output'],
+                          dynamic_axes={'input': {0: 'batch_size'}, 'output': {0: 'batch_size'}}, dynamo=False)
+    full = buf.getvalue()
+    skeleton, stripped = onnx_io.strip_initializers(full, 4096)
+    g = onnx_io.load_graph(full)
+    for name in stripped:                                   # the test refills these from synth.make_params
+        assert name in params and np.array_equal(g.initializers[name], params[name]), name
+    out = {'skeleton': np.frombuffer(skeleton, np.uint8), 'stripped': np.array(stripped), 'seed': np.array(4321),
+           'input_seed': np.array(11), 'hw': np.array(hw), 'normalize': np.array(normalize), 'logits': logits,
+           'full_bytes': np.array(len(full))}
+    for key in spec.layer_keys():
+        out[f'fl/{key}'] = np.array([int(params[key + '.input_fraclen'].reshape(-1)[0]),
+                                     int(params[key + '.weight_fraclen'].reshape(-1)[0])])
+    np.savez_compressed(os.path.join(GOLD, f'onnx_{tag.replace("+", "_")}.npz'), **out)
+    print(f'[gen_golden] onnx {tag}: {len(full)} B file -> {len(skeleton)} B skeleton, {len(stripped)} stripped')
+
+
 def child_ops():
     """Op-level known answers from the reference's own functions / the torch ops it calls."""
     import torch
@@ -362,13 +425,15 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     if args.child == 'ops':
         child_ops()
+    elif args.child and args.child.startswith('onnx:'):
+        child_onnx(args.child.split(':', 1)[1])
     elif args.child and args.child.startswith('export:'):
         child_export(args.child.split(':', 1)[1])
     elif args.child:
         child_model(args.child)
     else:
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
-        for c in ['ops'] + list(YMLS) + [f'export:{c}' for c in EXPORT_CASES]:
+        for c in ['ops'] + list(YMLS) + [f'export:{c}' for c in EXPORT_CASES] + [f'onnx:{a}' for a in list(YMLS) + ['resnet18+lshift']]:
             subprocess.check_call([sys.executable, os.path.abspath(__file__), '--child', c], env=env)
 
 

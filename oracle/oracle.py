@@ -241,3 +241,32 @@ def quantize_input_normalized(x, head_in_fl: int):
     """fix_train.py:683-687 via fix_quant (fix_quant_ops.py:64-87): round(x*2^fl) clamp +-127, fl."""
     v = np.rint(np.asarray(x, dtype=np.float32) * np.float32(2.0 ** head_in_fl))
     return np.clip(v, -127, 127).astype(np.int32), head_in_fl
+
+
+def graph_forward(ig, x, input_fraclen=None):
+    """Interpreter for an imported ONNX program (f8net_amd.onnx_import.IntGraph) over the op-level functions above:
+    the same walk IntModel.forward does, driven by the graph instead of the topology table."""
+    V, layer = ig.solve_fraclens(input_fraclen)
+    t = {}
+    for i, o in enumerate(ig.ops):
+        if o.kind == 'input':
+            t[i] = _i32(x)
+        elif o.kind in ('conv', 'linear'):
+            s = t[o.src]
+            if o.shift is not None:
+                s = requant(s, layer[i][0], V[o.src], o.signed)
+            if o.kind == 'conv':
+                y = conv2d(s, o.weight, o.bias, o.stride, o.pad, o.groups)
+            else:
+                y = linear(s.reshape(s.shape[0], -1), o.weight, o.bias)
+            t[i] = relu(y) if o.relu else y
+        elif o.kind == 'add':
+            y, fl = add_align(t[o.src], t[o.src2], V[o.src], V[o.src2])
+            assert fl == V[i]
+            t[i] = relu(y) if o.relu else y
+        elif o.kind == 'maxpool':
+            t[i] = maxpool(t[o.src], o.kernel, o.stride, o.pad)
+        elif o.kind == 'avgpool':
+            t[i] = avgpool_sum(t[o.src])
+    y = t[ig.output]
+    return y.astype(np.float32) if ig.output_float else y
