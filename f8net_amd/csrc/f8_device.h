@@ -113,4 +113,24 @@ template <int ROWB> struct Swz {                       // LDS bank rows are 256 
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
+// wave-uniform run-time count (the immediate has 6 bits on gfx9): a scalar jump table; counts it does not list wait for all
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+    switch (n) {
+        case 1: wait_vmcnt<1>(); break; case 2: wait_vmcnt<2>(); break; case 3: wait_vmcnt<3>(); break;
+         case 4: wait_vmcnt<4>(); break; case 5: wait_vmcnt<5>(); break; case 6: wait_vmcnt<6>(); break; case 7: wait_vmcnt<7>(); break;
+         case 8: wait_vmcnt<8>(); break; case 9: wait_vmcnt<9>(); break; case 10: wait_vmcnt<10>(); break; case 11: wait_vmcnt<11>(); break;
+         case 12: wait_vmcnt<12>(); break; case 13: wait_vmcnt<13>(); break; case 14: wait_vmcnt<14>(); break; case 15: wait_vmcnt<15>(); break;
+         case 16: wait_vmcnt<16>(); break; case 17: wait_vmcnt<17>(); break; case 18: wait_vmcnt<18>(); break; case 19: wait_vmcnt<19>(); break;
+         case 20: wait_vmcnt<20>(); break; case 21: wait_vmcnt<21>(); break; case 22: wait_vmcnt<22>(); break; case 23: wait_vmcnt<23>(); break;
+         case 24: wait_vmcnt<24>(); break; case 25: wait_vmcnt<25>(); break; case 26: wait_vmcnt<26>(); break; case 27: wait_vmcnt<27>(); break;
+         case 28: wait_vmcnt<28>(); break; case 29: wait_vmcnt<29>(); break; case 30: wait_vmcnt<30>(); break; case 31: wait_vmcnt<31>(); break;
+         case 32: wait_vmcnt<32>(); break; case 33: wait_vmcnt<33>(); break; case 34: wait_vmcnt<34>(); break; case 35: wait_vmcnt<35>(); break;
+         case 36: wait_vmcnt<36>(); break; case 37: wait_vmcnt<37>(); break; case 38: wait_vmcnt<38>(); break; case 39: wait_vmcnt<39>(); break;
+         case 40: wait_vmcnt<40>(); break; case 41: wait_vmcnt<41>(); break; case 42: wait_vmcnt<42>(); break; case 43: wait_vmcnt<43>(); break;
+         case 44: wait_vmcnt<44>(); break; case 45: wait_vmcnt<45>(); break; case 46: wait_vmcnt<46>(); break; case 47: wait_vmcnt<47>(); break;
+        
+        default: wait_vmcnt<0>(); break;
+    }
+}
+
 }  // namespace f8

@@ -26,6 +26,7 @@
 // A = weights, B = activations as in conv_igemm_kernel; all LDS rows are XOR-swizzled per 16-byte
 // chunk (see f8_kernels.hip).  LDS is dynamic (up to ~120 KB for MID = 256).
 #include "f8_device.h"
+#include <type_traits>
 #include <cstdlib>
 #include <cstdio>
 
@@ -85,8 +86,9 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
     char* const ring = lds + PATCH_BYTES + MID2_BYTES;                   // !ALLW: two (X1 + W) stages; ALLW: W2 whole, then the W4 ring
     char* const w4ring = ALLW ? ring + W2ALL : ring;
     constexpr int W4STRIDE = ALLW ? W4STAGE : RING;
+    constexpr int NS1 = (!ALLW && MID == 256) ? 4 : 2;                  // P1 ring depth (see issue_p1)
     constexpr int LDS_END = ALLW ? ((NK1 * RING > PATCH_BYTES + MID2_BYTES + W2ALL + 2 * W4STAGE) ? NK1 * RING : PATCH_BYTES + MID2_BYTES + W2ALL + 2 * W4STAGE)
-                                 : Cfg::LDS_BYTES;
+                                 : (NS1 > 2 ? PATCH_BYTES + NS1 * RING : Cfg::LDS_BYTES);
 
     using S64 = Swz<64>;
     using SM = Swz<MID>;
@@ -151,8 +153,28 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
         w4b[j] = (unsigned)(r4 * MID + c4 * 16);
     }
 
+    // fragment ping-pong (MID == 256): MFMAs have no memory semantics, so the scheduler is free to hoist them above the barrier,
+    // next to the reads that feed them — which turns the pipeline back into read-then-multiply.  Passing the fragments through
+    // an empty asm AFTER the next stage's reads are issued pins the multiplies behind those reads.
+    auto pin = [](auto& wf, auto& xf) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            asm volatile("" : "+v"(xf[kk]) :: "memory");
+#pragma unroll
+            for (int i = 0; i < (int)(sizeof(wf[0]) / sizeof(wf[0][0])); ++i) asm volatile("" : "+v"(wf[kk][i]) :: "memory");
+        }
+    };
+    // !ALLW, MID == 256 (one workgroup per CU, LDS to spare): the P1 ring is four stages deep and starts at `mid2`, which is
+    // not live before P2's epilogue.  All workgroups stream their x8 tiles at the same time, so the stream runs at the chip's
+    // HBM rate (~10 B/clk/CU) with a loaded latency of several thousand cycles: the ring has to cover that (ablation: P1
+    // 26.5k cycles, 15.0k with the DMA removed, HBM floor 13k; a 2-stage ring took 30.6k)
+    static_assert(ALLW || NS1 == 2 || (PATCH_BYTES + NS1 * RING + 4 * COUT <= 160 * 1024 && (XS1 % 512) == 0 && (WS % 512) == 0), "deep P1 ring: fits, uniform DMA count per thread");
+    char* const p1ring = NS1 == 2 ? ring : mid2;
     auto issue_p1 = [&](int ks, int slot) {
-        char* base = ALLW ? lds + slot * RING : ring + slot * RING;
+#ifdef F8_ABL_NODMA
+        if (MID == 256) return;
+#endif
+        char* base = ALLW ? lds + slot * RING : p1ring + slot * RING;
 #pragma unroll
         for (int i = 0; i < XL1; ++i) {
             const unsigned off = xb1[i] == kOOB ? kOOB : xb1[i] + (unsigned)(ks * 64);
@@ -173,6 +195,9 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
     constexpr int PRE2 = (RING / W2B) < (NS2 - 1) ? (RING / W2B) : (NS2 - 1);
     static_assert(ALLW || ((NK1 & 1) == 0 && PRE2 >= 1 && (NK2 - 1) % NS2 != 0), "W2 ring placement");
     auto issue_w2 = [&](int j2, int slot) {              // step j2: bytes [j2*64, j2*64+64) of every W2 row (tap-major K)
+#ifdef F8_ABL_NODMA
+        if (MID == 256) return;
+#endif
         char* base = ring + slot * W2B;
 #pragma unroll
         for (int j = 0; j < WL; ++j) {
@@ -198,8 +223,15 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
         }
     };
 
+    // MID == 256 (one workgroup per CU): P3 runs D3 = 4 chunks deep — W4 tiles and residual chunks are requested three chunks
+    // ahead, so a chunk waits for the stores issued FOUR chunks ago instead of two (VMEM retires in order and loads share the
+    // counter with stores: with the 2-deep pipeline every chunk lasted one store round trip, 5.7k cycles in the trace).
+    constexpr int D3 = (!ALLW && MID == 256 && !DS) ? 4 : 2;
     v4i xs[2] = {};                                      // DS: x fragments of the shortcut product (read at the end of P1)
     int* const bias_lds = (int*)(lds + LDS_END);  // DS: b4[COUT] then bsc[COUT] (a global bias load per chunk would expose its latency:
+    if (D3 == 4) {                                       // deep P3: b4[COUT], so that no bias load sits in the VMEM queue
+        for (int i = tid; i < COUT; i += 512) bias_lds[i] = a.b4[i];
+    }
     if (DS) {                                            //     there is no residual stream whose prefetch could hide it)
         static_assert(!DS || COUT * 2 <= 512, "one bias word per thread");
         if (tid < COUT) bias_lds[tid] = a.b4[tid];
@@ -257,7 +289,7 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
             __builtin_amdgcn_s_barrier();
 #pragma unroll
             for (int ks = 0; ks < NK1; ++ks) p1_mma(lds + ks * RING);
-        } else {
+        } else if constexpr (NS1 == 2) {
             issue_p1(0, 0);
             for (int ks = 0; ks < NK1; ++ks) {
                 wait_vmcnt<0>();
@@ -266,6 +298,58 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
                 if (ks + 1 < NK1) issue_p1(ks + 1, (ks + 1) & 1);
                 p1_mma(ring + (ks & 1) * RING);
             }
+        } else {
+            constexpr int L1 = XL1 + WL;                 // DMA instructions per thread and stage (uniform, see the assert)
+            static_assert(NK1 >= NS1, "ring no deeper than the loop");
+#pragma unroll
+            for (int k = 0; k < NS1 - 1; ++k) issue_p1(k, k);
+            // software pipeline over the barrier: the fragments of stage ks are read while the MFMAs of stage ks-1 run (with
+            // read-then-multiply inside one step all eight waves hit LDS together, then the matrix cores together:
+            // 640 + 512 cycles per step in the trace instead of max(640, 512))
+            static_assert(NP1W == 1 && (NK1 % 2) == 0, "fragment ping-pong: one px tile per wave, even step count");
+            v4i wfa[2][CMW], xfa[2], wfb[2][CMW], xfb[2];
+            auto p1_read = [&](const char* base, v4i (&wf)[2][CMW], v4i (&xf)[2]) {
+#ifdef F8_ABL_NOREAD
+                return;
+#endif
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                    for (int i = 0; i < CMW; ++i) wf[kk][i] = *(const v4i*)(base + X1_BYTES + ((wb * CMW + i) * 32 + l31) * 64 + cof[kk]);
+                    xf[kk] = *(const v4i*)(base + (wa * 32 + l31) * 64 + cof[kk]);
+                }
+            };
+            auto p1_mul = [&](const v4i (&wf)[2][CMW], const v4i (&xf)[2]) {
+#ifdef F8_ABL_NOMUL
+                return;
+#endif
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < CMW; ++i) acc[0][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[kk][i], xf[kk], acc[0][i], 0, 0, 0);
+            };
+            auto p1_step = [&](int ks) {
+                if (ks + NS1 - 2 < NK1) wait_vmcnt<(NS1 - 2) * L1>(); else wait_vmcnt<0>();   // stage ks landed; the next one may fly
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (ks + NS1 - 1 < NK1) issue_p1(ks + NS1 - 1, (ks + NS1 - 1) % NS1);
+            };
+            p1_step(0);
+            p1_read(p1ring, wfa, xfa);
+            for (int ks = 0; ks < NK1; ks += 2) {
+                p1_step(ks + 1);
+                p1_read(p1ring + ((ks + 1) % NS1) * RING, wfb, xfb);
+                pin(wfa, xfa);
+                p1_mul(wfa, xfa);
+                if (ks + 2 < NK1) {
+                    p1_step(ks + 2);
+                    p1_read(p1ring + ((ks + 2) % NS1) * RING, wfa, xfa);
+                }
+                pin(wfb, xfb);
+                p1_mul(wfb, xfb);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                // every wave is done with the P1 ring before W2 stages land in it
         }
         F8_TT(1);
         if (DS) {   // the shortcut's x fragments (this wave's output pixel tile, all of K = C) from the P1 stage, before P2 reuses the slot
@@ -340,6 +424,17 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
         for (int g = 0; g < 4; ++g) dst[g] = *(const v4i*)(a.xr + i32t_index(mc, c * 64 + wb * 32 + 8 * g + 4 * lh, C));
     };
 
+    v4i rq[D3 == 4 ? 4 : 1][4] = {};                     // deep P3: residual chunks c .. c+3
+    auto w4slot = [&](int slot) -> char* { return slot < 3 ? ring + slot * (MID * 64) : patch; };
+    auto issue_w4d = [&](int c, int slot) {              // deep P3: 64 output channels x MID bytes into slot (c % 4)
+        char* base = w4slot(slot);
+#pragma unroll
+        for (int j = 0; j < WL; ++j) {
+            const unsigned woff = w4b[j] + (unsigned)(c * 64 * MID);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw4, (__attribute__((address_space(3))) void*)(base + j * 8192 + wave * 1024), 16, woff, 0, 0, 0);
+        }
+    };
+
     // =========================================================================================
     // P2: mid2 = requant(relu(conv3x3(mid1) + b2)) on R x W pixels  ->  mid2
     //     wave (wa, wb): px tile wa, co tiles {wb*CMW ..}
@@ -389,7 +484,7 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
 #pragma unroll
             for (int q = 0; q < WL; ++q) ldw2 += ((q * 512 + wave * 64) < WS) ? 1 : 0;
             int issued = PRE2;
-            for (int j = 0; j < NK2; ++j) {
+            auto p2_step = [&](int j) {
                 // stage j landed; the stages issued after it may stay in flight (at j == 0 the bias loads above are newer than
                 // the prologue stages, which only makes this first wait conservative)
                 switch ((issued - 1 - j) * ldw2) {
@@ -400,14 +495,68 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();            // step 0: also "patch complete" and "P1 ring free"
                 while (issued < NK2 && issued < j + NS2) { issue_w2(issued, issued % NS2); ++issued; }
-                p2_mma(ring + (j % NS2) * W2B);
+            };
+            if constexpr (NS1 > 2) {
+                // as in P1: fragments of step j are read while the MFMAs of step j-1 run
+                static_assert((NK2 % 2) == 0, "fragment ping-pong");
+                v4i wfa[2][CMW], xfa[2], wfb[2][CMW], xfb[2];
+                auto p2_read = [&](const char* base, v4i (&wf)[2][CMW], v4i (&xf)[2]) {
+#ifdef F8_ABL_NOREAD
+                    return;
+#endif
+                    const int ppx = bpx + tr * PW + ts;
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        xf[kk] = *(const v4i*)(patch + SM::off(ppx, tc * 4 + kk * 2 + lh));
+#pragma unroll
+                        for (int i = 0; i < CMW; ++i) wf[kk][i] = *(const v4i*)(base + ((wb * CMW + i) * 32 + l31) * 64 + cof[kk]);
+                    }
+                    if (++tc == CH) { tc = 0; if (++ts == 3) { ts = 0; ++tr; } }
+                };
+                auto p2_mul = [&](const v4i (&wf)[2][CMW], const v4i (&xf)[2]) {
+#ifdef F8_ABL_NOMUL
+                    return;
+#endif
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int i = 0; i < CMW; ++i) acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[kk][i], xf[kk], acc[i], 0, 0, 0);
+                };
+                p2_step(0);
+                p2_read(ring, wfa, xfa);
+                for (int j = 0; j < NK2; j += 2) {
+                    p2_step(j + 1);
+                    p2_read(ring + ((j + 1) % NS2) * W2B, wfb, xfb);
+                    pin(wfa, xfa);
+                    p2_mul(wfa, xfa);
+                    if (j + 2 < NK2) {
+                        p2_step(j + 2);
+                        p2_read(ring + ((j + 2) % NS2) * W2B, wfa, xfa);
+                    }
+                    pin(wfb, xfb);
+                    p2_mul(wfb, xfb);
+                }
+            } else {
+                for (int j = 0; j < NK2; ++j) {
+                    p2_step(j);
+                    p2_mma(ring + (j % NS2) * W2B);
+                }
             }
         }
         F8_TT(3);
         asm volatile("" ::: "memory");
-        issue_w4(0, ALLW ? 0 : ((S0 + NK2) & 1));        // ALLW: the W4 ring is its own region (under the last P1 stage: free since the post-P1 barrier)
-        asm volatile("" ::: "memory");   // the loads below must stay behind this DMA (counted wait in P3)
-        if (!DS) load_res(rv, 0);
+        if constexpr (D3 == 4) {
+            // the W4 ring takes over the W2 ring (3 slots) and the head of the patch: both must be done with everywhere
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            issue_w4d(0, 0); asm volatile("" ::: "memory"); load_res(rq[0], 0); asm volatile("" ::: "memory");
+            issue_w4d(1, 1); asm volatile("" ::: "memory"); load_res(rq[1], 1); asm volatile("" ::: "memory");
+            issue_w4d(2, 2); asm volatile("" ::: "memory"); load_res(rq[2], 2); asm volatile("" ::: "memory");
+        } else {
+            issue_w4(0, ALLW ? 0 : ((S0 + NK2) & 1));    // ALLW: the W4 ring is its own region (under the last P1 stage: free since the post-P1 barrier)
+            asm volatile("" ::: "memory");   // the loads below must stay behind this DMA (counted wait in P3)
+            if (!DS) load_res(rv, 0);
+        }
 
         const int floor0 = a.relu_b ? 0 : INT32_MIN;
 #pragma unroll
@@ -538,9 +687,83 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
                 }
             }
         };
-        for (int c = 0; c < NC3; c += 2) {
-            chunk(c, rv, rn);
-            chunk(c + 1, rn, rv);
+        // deep variant of `chunk`: slot / buffer index k = c % 4 is a compile-time constant of the unrolled body
+        auto chunk4 = [&](int c, auto kc) {
+            constexpr int k = decltype(kc)::value;
+            // newer than res(c) in the queue: per earlier chunk of the window its stores, and the W4 + residual requests of the
+            // two later chunks (WL + 4 each); everything older — including the stores of chunk c-4 — has to be back
+            const int st = c < 3 ? c : 3;
+            wait_vmcnt_dyn(2 * (WL + 4) + st * n_store);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                // chunk 0: also "mid2 complete"; slot (c+3)%4 was read in chunk c-1
+            const int cot = c * 64 + wb * 32;
+            v4i bq4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bq4[g] = *(const v4i*)(bias_lds + cot + 8 * g + 4 * lh);
+            asm volatile("" ::: "memory");
+            {   // always issued (the tail re-requests the last chunk): the counted wait relies on a fixed count per chunk
+                const int cn = c + 3 < NC3 ? c + 3 : NC3 - 1;
+                issue_w4d(cn, (k + 3) & 3);
+                asm volatile("" ::: "memory");
+                load_res(rq[(k + 3) & 3], cn);
+            }
+            const char* base = w4slot(k);
+            if (c == 0) {
+#pragma unroll
+                for (int kk = 0; kk < KK3; ++kk) xf[kk] = *(const v4i*)(mid2 + SM::off(opix, kk * 2 + lh));
+            }
+            v16i acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = bq4[r >> 2][r & 3];
+#pragma unroll
+            for (int kk = 0; kk < KK3; ++kk) {
+                const v4i wf = *(const v4i*)(base + SM::off(wb * 32 + l31, kk * 2 + lh));
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, xf[kk], acc, 0, 0, 0);
+            }
+            int y[4][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned sres = ((unsigned)acc[4 * g + e] << a.acc_shl) + ((unsigned)rq[k][g][e] << a.res_shl);
+                    y[g][e] = max((int)sres, floor1);
+                }
+            if (a.out32 && opix_ok) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    v4i o = {y[g][0], y[g][1], y[g][2], y[g][3]};
+                    *(v4i*)(a.out32 + i32t_index(m, cot + 8 * g + 4 * lh, COUT)) = o;
+                }
+            }
+#pragma unroll
+            for (int kq = 0; kq < 2; ++kq) {
+                if (!a.q[kq].ptr) continue;
+                unsigned d[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    d[g] = pack4(requant1(y[g][0], a.q[kq].n, a.q[kq].lo, a.q[kq].hi), requant1(y[g][1], a.q[kq].n, a.q[kq].lo, a.q[kq].hi),
+                                 requant1(y[g][2], a.q[kq].n, a.q[kq].lo, a.q[kq].hi), requant1(y[g][3], a.q[kq].n, a.q[kq].lo, a.q[kq].hi)) ^ a.q[kq].bias_xor;
+                auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+                auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+                if (opix_ok) {
+                    v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
+                    *(v4i*)(a.q[kq].ptr + (size_t)m * COUT + cot + 16 * lh) = o;
+                }
+            }
+        };
+        if constexpr (D3 == 4) {
+            static_assert(D3 != 4 || NC3 % 4 == 0, "chunk loop is unrolled by four");
+            for (int c = 0; c < NC3; c += 4) {
+                chunk4(c, std::integral_constant<int, 0>{});
+                chunk4(c + 1, std::integral_constant<int, 1>{});
+                chunk4(c + 2, std::integral_constant<int, 2>{});
+                chunk4(c + 3, std::integral_constant<int, 3>{});
+            }
+        } else {
+            for (int c = 0; c < NC3; c += 2) {
+                chunk(c, rv, rn);
+                chunk(c + 1, rn, rv);
+            }
         }
     }
 #ifdef F8_TRACE
@@ -559,7 +782,7 @@ static hipError_t launch_fused_t(const FusedArgs& a, hipStream_t s) {
     constexpr int NK1 = C / 64, W2ALL = 9 * (MID / 64) * (MID * 64), W4STAGE = (MID * 64) * (DS ? 2 : 1);      // keep in sync with the kernel
     constexpr int ALLW_END = (NK1 * Cfg::RING > Cfg::PATCH_BYTES + Cfg::MID2_BYTES + W2ALL + 2 * W4STAGE) ? NK1 * Cfg::RING
                                                                                                    : Cfg::PATCH_BYTES + Cfg::MID2_BYTES + W2ALL + 2 * W4STAGE;
-    constexpr int LDS = (MID == 64 ? ALLW_END : Cfg::LDS_BYTES) + (DS ? 2 * COUT * 4 : 0);
+    constexpr int LDS = (MID == 64 ? ALLW_END : (MID == 256 ? Cfg::PATCH_BYTES + 4 * Cfg::RING : Cfg::LDS_BYTES)) + (DS ? 2 * COUT * 4 : 0) + ((MID == 256 && !DS) ? COUT * 4 : 0);   // + bias_lds; MID == 256: 4-stage P1 ring
     static_assert(LDS <= 80 * 1024 || MID > 64, "two workgroups per CU");
     static bool attr_set = false;
     if (!attr_set) {   // dynamic LDS above 64 KB must be opted into once per kernel
@@ -610,12 +833,19 @@ bool fused_ds_supported(int C, int MID, int COUT, int H, int W, int* R) {
     return false;
 }
 
-bool fused_bottleneck_supported(int C, int MID, int H, int W, int* R) {
-    static const int mask = [] { const char* e = getenv("F8_FUSE_STAGES"); return e ? atoi(e) : 3; }();   // bit s = stage s; measured (100-step A/B, bs 128):
-    // none 55.5k, stage 0 55.6k, stages 0+1 56.0k, +stage 2 52.5k img/s (256 tiles of 98 px cannot fill 256 CUs with 1 WG each)
+bool fused_bottleneck_supported(int C, int MID, int H, int W, int imgs_per_launch, int* R) {
+    // bit s = stage s.  Unset: stages 0 and 1 always, stage 2 when one launch fills at least half the chip.
+    static const int mask = [] { const char* e = getenv("F8_FUSE_STAGES"); return e ? atoi(e) : -1; }();
     if ((mask & 1) && C == 256 && MID == 64 && W == 56 && H % 2 == 0) { *R = 2; return true; }
     if ((mask & 2) && C == 512 && MID == 128 && W == 28 && H % 4 == 0) { *R = 4; return true; }
-    if ((mask & 4) && C == 1024 && MID == 256 && W == 14 && H % 7 == 0) { *R = 7; return true; }
+    if (C == 1024 && MID == 256 && W == 14 && H % 7 == 0) {
+        // One workgroup per CU (124 KB LDS), two tiles of 98 px per image: measured against the unfused three launches,
+        // two concurrent sub-batches, ResNet-50 img/s:  bs 256 (256 workgroups per launch) 74.9k vs 71.6k; bs 128 (128)
+        // 71.2k vs 70.7k; bs 64 (64) 58.6k vs 63.6k; bs 32 42.7k vs 49.7k — a launch that leaves most CUs without a
+        // workgroup loses to three launches of smaller tiles.  (With the 2-deep P1 / P3 pipelines it lost 4 % at bs 128.)
+        const bool fill = imgs_per_launch * (H / 7) >= 128;
+        if (mask < 0 ? fill : (mask & 4) != 0) { *R = 7; return true; }
+    }
     return false;
 }
 

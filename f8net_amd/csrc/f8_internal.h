@@ -134,7 +134,7 @@ int  conv_deep_nk();
 
 hipError_t launch_conv(const ConvArgs& a, const ConvTile& t, hipStream_t s);
 hipError_t launch_fused_bottleneck(const FusedArgs& a, hipStream_t s);
-bool fused_bottleneck_supported(int C, int MID, int H, int W, int* R);
+bool fused_bottleneck_supported(int C, int MID, int H, int W, int imgs_per_launch, int* R);
 bool fused_ds_supported(int C, int MID, int COUT, int H, int W, int* R);
 // 3x3 / stride 1 / pad 1 with the input patch resident in LDS (f8_conv3x3.hip); config = false: no instance
 bool conv3x3_patch_config(int cin, int H, int W, int coutP, int* R, int* IMGS, int* BN);

@@ -629,7 +629,8 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         const int C = a0.cd.cin, MID = a0.cd.cout;
         if (c.cd.cout != C || b.cd.cin != MID || b.cd.cout != MID || c.cd.cin != MID) continue;
         int R = 0;
-        if (!fused_bottleneck_supported(C, MID, x.H, x.W, &R)) continue;
+        static const int split_env = [] { const char* e = getenv("F8_SPLIT"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+        if (!fused_bottleneck_supported(C, MID, x.H, x.W, std::max(1, max_batch / split_env), &R)) continue;
         a0.absorbed_by = i; b.absorbed_by = i; b.no_classes = true;
         c.fb_a = ta.prod; c.fb_b = tb.prod; c.fb_R = R;
     }

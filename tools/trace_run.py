@@ -1,0 +1,20 @@
+"""Runs a few ResNet-50 bs-128 forwards so that a -DF8_TRACE build prints its per-workgroup phase
+timings: F8_TRACE_FUSED=<k> / F8_TRACE_PATCH=<k> / F8_TRACE_LAUNCH=<k> select the k-th call of each kernel instance."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from f8net_amd import synth, topology
+from f8net_amd.net import build_net
+
+spec = topology.get('resnet50', normalize=True)
+params = synth.make_params(spec, seed=1234, fraclens=topology.R50_NVIDIA_FRACLENS)
+net = build_net(spec, params, max_batch=128, hw=224)
+x, fl = synth.make_input(spec, params, 128, 224, seed=7)
+xd = torch.from_numpy(x).cuda()
+for i in range(6):
+    net.run(xd)
+    torch.cuda.synchronize()

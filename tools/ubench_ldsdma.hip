@@ -88,6 +88,13 @@ int main() {
     run<16384, 4, false>("weights", small, small_bytes, 2304, 1, d_cyc);
     run<16384, 4, false>("weights", small, small_bytes, 2304, 2, d_cyc);
     run<24576, 3, false>("weights", small, small_bytes, 2304, 1, d_cyc);
+    printf("== shared L2-resident source, power-of-two pitches (1x1 conv weights [Cout][K], K = 1024 / 2048) vs odd pitch\n");
+    run<16384, 4, false>("pitch1024", small, small_bytes, 1024, 1, d_cyc);
+    run<16384, 4, false>("pitch2048", small, small_bytes, 2048, 1, d_cyc);
+    run<16384, 4, false>("pitch1088", small, small_bytes, 1088, 1, d_cyc);
+    run<16384, 4, false>("pitch2304", small, small_bytes, 2304, 1, d_cyc);
+    run<24576, 3, false>("pitch1024", small, small_bytes, 1024, 1, d_cyc);
+    run<24576, 3, false>("pitch1088", small, small_bytes, 1088, 1, d_cyc);
     printf("== shared L2-resident source, contiguous (pitch 64)\n");
     run<8192, 4, false>("contig", small, small_bytes, 64, 1, d_cyc);
     run<16384, 4, false>("contig", small, small_bytes, 64, 2, d_cyc);
