@@ -191,6 +191,8 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
     // !ALLW: W2 streams through NS2 stages of MID x 64 bytes laid over the two P1 slots (P1's last stage sits in slot 1, so only
     // the stages inside slot 0 may be issued before P2's first barrier)
     constexpr int W2B = MID * 64;
+    constexpr int RS2 = 6;                               // deep variant (MID == 256): W2 ring stages, from `mid2` (dead until P2's epilogue)
+    static_assert(NS1 == 2 || RS2 * W2B <= NS1 * RING, "deep W2 ring lies inside the dead P1 ring");
     constexpr int NS2 = (2 * RING / W2B) < 5 ? (2 * RING / W2B) : 5;
     constexpr int PRE2 = (RING / W2B) < (NS2 - 1) ? (RING / W2B) : (NS2 - 1);
     static_assert(ALLW || ((NK1 & 1) == 0 && PRE2 >= 1 && (NK2 - 1) % NS2 != 0), "W2 ring placement");
@@ -198,7 +200,7 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
 #ifdef F8_ABL_NODMA
         if (MID == 256) return;
 #endif
-        char* base = ring + slot * W2B;
+        char* base = (NS1 > 2 ? mid2 : ring) + slot * W2B;   // deep variant: RS2 stages over mid2 + the old ring (see P2)
 #pragma unroll
         for (int j = 0; j < WL; ++j) {
             const unsigned woff = w2b[j] + (unsigned)(j2 * 64);
@@ -328,8 +330,10 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
 #pragma unroll
                     for (int i = 0; i < CMW; ++i) acc[0][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[kk][i], xf[kk], acc[0][i], 0, 0, 0);
             };
+            // (two stages per barrier as in P2 was tried here and lost 2 us per launch: the x8 stream is HBM-latency bound and a
+            // 4-stage ring that validates two stages at a time drains at every barrier)
             auto p1_step = [&](int ks) {
-                if (ks + NS1 - 2 < NK1) wait_vmcnt<(NS1 - 2) * L1>(); else wait_vmcnt<0>();   // stage ks landed; the next one may fly
+                if (ks + NS1 - 2 < NK1) wait_vmcnt<(NS1 - 2) * L1>(); else wait_vmcnt<0>();   // stage ks landed; the next ones may fly
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 if (ks + NS1 - 1 < NK1) issue_p1(ks + NS1 - 1, (ks + NS1 - 1) % NS1);
@@ -375,9 +379,10 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                // the zero fill is complete before anyone writes real pixels
         } else {
-            // the first W2 stages can already travel: slot 0 of the P1 ring was last read two steps ago
+            // the first W2 stages can already travel: slot 0 of the P1 ring was last read two steps ago (deep variant: the
+            // whole P1 ring is dead since the barrier above)
 #pragma unroll
-            for (int k = 0; k < PRE2; ++k) issue_w2(k, k);
+            for (int k = 0; k < (NS1 > 2 ? RS2 - 1 : PRE2); ++k) issue_w2(k, k);
         }
 
         // epilogue: bias, ReLU, requant to body.2's input format, into the patch
@@ -522,17 +527,28 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
 #pragma unroll
                         for (int i = 0; i < CMW; ++i) acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[kk][i], xf[kk], acc[i], 0, 0, 0);
                 };
-                p2_step(0);
-                p2_read(ring, wfa, xfa);
+                // SEVERAL K stages per barrier: the fixed cost of a step (counted wait, barrier skew, DMA issue, address
+                // arithmetic; ablation: ~1000 of 1360 cycles with neither reads nor MFMAs) is paid 18 times instead of 36
+                // (49 k -> 39 k cycles).  A barrier validates the stages up to `upto` (stage 0: prologue);
+                // stages <= `freed` are read by then, so stage s may be issued once s <= freed + RS2.
+                issued = RS2 - 1;
+                auto p2_super = [&](int upto, int freed) {   // stages <= upto landed; stages <= freed are free slots
+                    int fly = issued - 1 - upto; if (fly < 0) fly = 0;
+                    wait_vmcnt_dyn(fly * ldw2);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();        // first call: also "patch complete"
+                    while (issued < NK2 && issued <= freed + RS2) { issue_w2(issued, issued % RS2); ++issued; }
+                };
+                p2_super(0, -1);
+                p2_read(mid2, wfa, xfa);
+                // two stages per barrier: barrier u validates stages 2u+1 and 2u+2, frees stages <= 2u (three per barrier measured
+                // the same: the W2 stages then have only one super-step to travel)
                 for (int j = 0; j < NK2; j += 2) {
-                    p2_step(j + 1);
-                    p2_read(ring + ((j + 1) % NS2) * W2B, wfb, xfb);
+                    p2_super(j + 2 < NK2 ? j + 2 : NK2 - 1, j);
+                    p2_read(mid2 + ((j + 1) % RS2) * W2B, wfb, xfb);
                     pin(wfa, xfa);
                     p2_mul(wfa, xfa);
-                    if (j + 2 < NK2) {
-                        p2_step(j + 2);
-                        p2_read(ring + ((j + 2) % NS2) * W2B, wfa, xfa);
-                    }
+                    if (j + 2 < NK2) p2_read(mid2 + ((j + 2) % RS2) * W2B, wfa, xfa);
                     pin(wfb, xfb);
                     p2_mul(wfb, xfb);
                 }
@@ -549,9 +565,13 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
             // the W4 ring takes over the W2 ring (3 slots) and the head of the patch: both must be done with everywhere
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+#ifdef F8_ABL_P3_NORES
+            issue_w4d(0, 0); issue_w4d(1, 1); issue_w4d(2, 2); asm volatile("" ::: "memory");
+#else
             issue_w4d(0, 0); asm volatile("" ::: "memory"); load_res(rq[0], 0); asm volatile("" ::: "memory");
             issue_w4d(1, 1); asm volatile("" ::: "memory"); load_res(rq[1], 1); asm volatile("" ::: "memory");
             issue_w4d(2, 2); asm volatile("" ::: "memory"); load_res(rq[2], 2); asm volatile("" ::: "memory");
+#endif
         } else {
             issue_w4(0, ALLW ? 0 : ((S0 + NK2) & 1));    // ALLW: the W4 ring is its own region (under the last P1 stage: free since the post-P1 barrier)
             asm volatile("" ::: "memory");   // the loads below must stay behind this DMA (counted wait in P3)
@@ -693,7 +713,17 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
             // newer than res(c) in the queue: per earlier chunk of the window its stores, and the W4 + residual requests of the
             // two later chunks (WL + 4 each); everything older — including the stores of chunk c-4 — has to be back
             const int st = c < 3 ? c : 3;
+#if defined(F8_ABL_P3_NORES)
+            wait_vmcnt_dyn(2 * (WL + 0) + st * n_store);
+#elif defined(F8_ABL_P3_NOSTORE)
+            wait_vmcnt_dyn(2 * (WL + 4));
+#elif defined(F8_ABL_P3_NOSTORE8)
+            wait_vmcnt_dyn(2 * (WL + 4) + st * (n_store - 1));
+#elif defined(F8_ABL_P3_NOSTORE32)
+            wait_vmcnt_dyn(2 * (WL + 4) + st * (n_store - 4));
+#else
             wait_vmcnt_dyn(2 * (WL + 4) + st * n_store);
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                // chunk 0: also "mid2 complete"; slot (c+3)%4 was read in chunk c-1
             const int cot = c * 64 + wb * 32;
@@ -705,7 +735,9 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
                 const int cn = c + 3 < NC3 ? c + 3 : NC3 - 1;
                 issue_w4d(cn, (k + 3) & 3);
                 asm volatile("" ::: "memory");
+#ifndef F8_ABL_P3_NORES
                 load_res(rq[(k + 3) & 3], cn);
+#endif
             }
             const char* base = w4slot(k);
             if (c == 0) {
@@ -717,8 +749,10 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
             for (int r = 0; r < 16; ++r) acc[r] = bq4[r >> 2][r & 3];
 #pragma unroll
             for (int kk = 0; kk < KK3; ++kk) {
+#ifndef F8_ABL_P3_NOMMA
                 const v4i wf = *(const v4i*)(base + SM::off(wb * 32 + l31, kk * 2 + lh));
                 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, xf[kk], acc, 0, 0, 0);
+#endif
             }
             int y[4][4];
 #pragma unroll
@@ -728,6 +762,9 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
                     const unsigned sres = ((unsigned)acc[4 * g + e] << a.acc_shl) + ((unsigned)rq[k][g][e] << a.res_shl);
                     y[g][e] = max((int)sres, floor1);
                 }
+#if defined(F8_ABL_P3_NOSTORE) || defined(F8_ABL_P3_NOSTORE32)
+            if (y[0][0] == 0x12345678 && y[3][3] == 0x7654321 && y[1][2] == 77 && y[2][1] == 78)
+#endif
             if (a.out32 && opix_ok) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -745,6 +782,9 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
                                  requant1(y[g][2], a.q[kq].n, a.q[kq].lo, a.q[kq].hi), requant1(y[g][3], a.q[kq].n, a.q[kq].lo, a.q[kq].hi)) ^ a.q[kq].bias_xor;
                 auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
                 auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+#if defined(F8_ABL_P3_NOSTORE) || defined(F8_ABL_P3_NOSTORE8)
+                if (s0[0] == 0x12345678 && s1[1] == 0x7654321)
+#endif
                 if (opix_ok) {
                     v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
                     *(v4i*)(a.q[kq].ptr + (size_t)m * COUT + cot + 16 * lh) = o;
