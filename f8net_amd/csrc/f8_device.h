@@ -1,6 +1,8 @@
 // f8_device.h — device-side helpers shared by the HIP translation units (gfx950 only).
 #pragma once
 #include "f8_internal.h"
+#include <type_traits>
+#include <utility>
 
 namespace f8 {
 
@@ -112,6 +114,10 @@ template <int ROWB> struct Swz {                       // LDS bank rows are 256 
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+// f(integral_constant<int, 0>{}) ... f(integral_constant<int, N-1>{}): a loop whose index is a constant expression in the body
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // wave-uniform run-time count (the immediate has 6 bits on gfx9): a scalar jump table; counts it does not list wait for all
 __device__ __forceinline__ void wait_vmcnt_dyn(int n) {

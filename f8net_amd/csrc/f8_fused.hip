@@ -177,7 +177,7 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
         char* base = ALLW ? lds + slot * RING : p1ring + slot * RING;
 #pragma unroll
         for (int i = 0; i < XL1; ++i) {
-            const unsigned off = xb1[i] == kOOB ? kOOB : xb1[i] + (unsigned)(ks * 64);
+            const unsigned off = xb1[i] + (unsigned)(ks * 64);   // kOOB + ks*64 stays beyond any buffer (< 2 GiB): no select
             if ((i * 512 + wave * 64) < XS1)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(base + i * 8192 + wave * 1024), 16, off, 0, 0, 0);
         }
@@ -293,13 +293,14 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
             for (int ks = 0; ks < NK1; ++ks) p1_mma(lds + ks * RING);
         } else if constexpr (NS1 == 2) {
             issue_p1(0, 0);
-            for (int ks = 0; ks < NK1; ++ks) {
+            static_for<NK1>([&](auto kc) {               // unrolled: slots and K offsets are immediates
+                constexpr int KS = decltype(kc)::value;
                 wait_vmcnt<0>();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                if (ks + 1 < NK1) issue_p1(ks + 1, (ks + 1) & 1);
-                p1_mma(ring + (ks & 1) * RING);
-            }
+                if constexpr (KS + 1 < NK1) issue_p1(KS + 1, (KS + 1) & 1);
+                p1_mma(ring + (KS & 1) * RING);
+            });
         } else {
             constexpr int L1 = XL1 + WL;                 // DMA instructions per thread and stage (uniform, see the assert)
             static_assert(NK1 >= NS1, "ring no deeper than the loop");
@@ -332,26 +333,30 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
             };
             // (two stages per barrier as in P2 was tried here and lost 2 us per launch: the x8 stream is HBM-latency bound and a
             // 4-stage ring that validates two stages at a time drains at every barrier)
-            auto p1_step = [&](int ks) {
-                if (ks + NS1 - 2 < NK1) wait_vmcnt<(NS1 - 2) * L1>(); else wait_vmcnt<0>();   // stage ks landed; the next ones may fly
+            // completely unrolled with compile-time step numbers (ring slots, DMA K offsets and wait counts are immediates)
+            auto p1_step_c = [&](auto kc) {
+                constexpr int KS = decltype(kc)::value;
+                if constexpr (KS + NS1 - 2 < NK1) wait_vmcnt<(NS1 - 2) * L1>(); else wait_vmcnt<0>();   // stage KS landed; the next ones may fly
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                if (ks + NS1 - 1 < NK1) issue_p1(ks + NS1 - 1, (ks + NS1 - 1) % NS1);
+                if constexpr (KS + NS1 - 1 < NK1) issue_p1(KS + NS1 - 1, (KS + NS1 - 1) % NS1);
             };
-            p1_step(0);
+            p1_step_c(std::integral_constant<int, 0>{});
             p1_read(p1ring, wfa, xfa);
-            for (int ks = 0; ks < NK1; ks += 2) {
-                p1_step(ks + 1);
-                p1_read(p1ring + ((ks + 1) % NS1) * RING, wfb, xfb);
+            auto p1_pair = [&](auto uc) {
+                constexpr int KS = 2 * decltype(uc)::value;
+                p1_step_c(std::integral_constant<int, KS + 1>{});
+                p1_read(p1ring + ((KS + 1) % NS1) * RING, wfb, xfb);
                 pin(wfa, xfa);
                 p1_mul(wfa, xfa);
-                if (ks + 2 < NK1) {
-                    p1_step(ks + 2);
-                    p1_read(p1ring + ((ks + 2) % NS1) * RING, wfa, xfa);
+                if constexpr (KS + 2 < NK1) {
+                    p1_step_c(std::integral_constant<int, KS + 2>{});
+                    p1_read(p1ring + ((KS + 2) % NS1) * RING, wfa, xfa);
                 }
                 pin(wfb, xfb);
                 p1_mul(wfb, xfb);
-            }
+            };
+            static_for<NK1 / 2>(p1_pair);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                // every wave is done with the P1 ring before W2 stages land in it
         }
@@ -485,39 +490,10 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
 #pragma unroll
             for (int j = 0; j < NK2; ++j) p2_mma(ring + j * (MID * 64));
         } else {
-            int ldw2 = 0;                                // W2-stage DMA instructions of this wave
-#pragma unroll
-            for (int q = 0; q < WL; ++q) ldw2 += ((q * 512 + wave * 64) < WS) ? 1 : 0;
-            int issued = PRE2;
-            auto p2_step = [&](int j) {
-                // stage j landed; the stages issued after it may stay in flight (at j == 0 the bias loads above are newer than
-                // the prologue stages, which only makes this first wait conservative)
-                switch ((issued - 1 - j) * ldw2) {
-                    case 0: wait_vmcnt<0>(); break;  case 1: wait_vmcnt<1>(); break;  case 2: wait_vmcnt<2>(); break;
-                    case 3: wait_vmcnt<3>(); break;  case 4: wait_vmcnt<4>(); break;  case 5: wait_vmcnt<5>(); break;
-                    case 6: wait_vmcnt<6>(); break;  case 7: wait_vmcnt<7>(); break;  default: wait_vmcnt<8>(); break;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();            // step 0: also "patch complete" and "P1 ring free"
-                while (issued < NK2 && issued < j + NS2) { issue_w2(issued, issued % NS2); ++issued; }
-            };
             if constexpr (NS1 > 2) {
                 // as in P1: fragments of step j are read while the MFMAs of step j-1 run
                 static_assert((NK2 % 2) == 0, "fragment ping-pong");
                 v4i wfa[2][CMW], xfa[2], wfb[2][CMW], xfb[2];
-                auto p2_read = [&](const char* base, v4i (&wf)[2][CMW], v4i (&xf)[2]) {
-#ifdef F8_ABL_NOREAD
-                    return;
-#endif
-                    const int ppx = bpx + tr * PW + ts;
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        xf[kk] = *(const v4i*)(patch + SM::off(ppx, tc * 4 + kk * 2 + lh));
-#pragma unroll
-                        for (int i = 0; i < CMW; ++i) wf[kk][i] = *(const v4i*)(base + ((wb * CMW + i) * 32 + l31) * 64 + cof[kk]);
-                    }
-                    if (++tc == CH) { tc = 0; if (++ts == 3) { ts = 0; ++tr; } }
-                };
                 auto p2_mul = [&](const v4i (&wf)[2][CMW], const v4i (&xf)[2]) {
 #ifdef F8_ABL_NOMUL
                     return;
@@ -531,32 +507,79 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
                 // arithmetic; ablation: ~1000 of 1360 cycles with neither reads nor MFMAs) is paid 18 times instead of 36
                 // (49 k -> 39 k cycles).  A barrier validates the stages up to `upto` (stage 0: prologue);
                 // stages <= `freed` are read by then, so stage s may be issued once s <= freed + RS2.
-                issued = RS2 - 1;
-                auto p2_super = [&](int upto, int freed) {   // stages <= upto landed; stages <= freed are free slots
-                    int fly = issued - 1 - upto; if (fly < 0) fly = 0;
-                    wait_vmcnt_dyn(fly * ldw2);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();        // first call: also "patch complete"
-                    while (issued < NK2 && issued <= freed + RS2) { issue_w2(issued, issued % RS2); ++issued; }
+                // The loop is unrolled completely with compile-time stage numbers: ring slots, tap offsets, DMA offsets and wait
+                // counts become immediates (the rolled loop spent ~70 VALU + ~50 SALU per 8 MFMAs on that arithmetic — with two
+                // waves per SIMD that, not the matrix pipe, set the step time).
+                const char* const wrow = mid2 + ((wb * CMW) * 32 + l31) * 64;   // this lane's row of co tile wb*CMW in slot 0
+                const int pp[3] = {bpx, bpx + 1, bpx + 2};                        // patch pixel of tap column ts (row 0)
+                auto p2_read_c = [&](auto jc, v4i (&wf)[2][CMW], v4i (&xf)[2]) {
+#ifdef F8_ABL_NOREAD
+                    return;
+#endif
+                    constexpr int J = decltype(jc)::value;
+                    constexpr int TAP = J / CH, TC = J % CH, TR = TAP / 3, TS = TAP % 3, SLOT = J % RS2;
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        // SM::off(pp + TR*PW, c): PW == 16 keeps the swizzle term (row & 15) independent of TR
+                        xf[kk] = *(const v4i*)(patch + TR * PW * MID + SM::off(pp[TS], TC * 4 + kk * 2 + lh));
+#pragma unroll
+                        for (int i = 0; i < CMW; ++i) wf[kk][i] = *(const v4i*)(wrow + SLOT * W2B + i * 32 * 64 + cof[kk]);
+                    }
                 };
-                p2_super(0, -1);
-                p2_read(mid2, wfa, xfa);
-                // two stages per barrier: barrier u validates stages 2u+1 and 2u+2, frees stages <= 2u (three per barrier measured
-                // the same: the W2 stages then have only one super-step to travel)
-                for (int j = 0; j < NK2; j += 2) {
-                    p2_super(j + 2 < NK2 ? j + 2 : NK2 - 1, j);
-                    p2_read(mid2 + ((j + 1) % RS2) * W2B, wfb, xfb);
+                static_assert(PW == 16 && MID == 256, "patch rows of 16 pixels x 256 bytes: TR*PW pixels = TR*PW*MID bytes, swizzle unchanged");
+                // (the DMA builtin stays in the function-scope lambda `issue_w2`: defined in a lambda inside this `if constexpr`
+                // block, clang's host pass silently drops the kernel's host stub; stage and slot are constants after inlining)
+                auto issue_w2_c = [&](auto jc) { constexpr int J2 = decltype(jc)::value; issue_w2(J2, J2 % RS2); };
+                static_assert(NK2 * 64 < 4096, "W2 K offset fits the DMA's 12-bit immediate");
+                // barrier u = 0..NK2/2-1 validates stages <= min(2u+2, NK2-1) and frees stages <= 2u; before it, stages
+                // < B(u) = min(NK2, 2u + RS2 - 1) are issued (u = 0: RS2, the prologue barrier added one); after it, < B(u+1)
+                auto p2_super_c = [&](auto uc) {
+                    constexpr int U = decltype(uc)::value;
+                    constexpr int UPTO = (2 * U + 2 < NK2) ? 2 * U + 2 : NK2 - 1;
+                    constexpr int BEFORE = U == 0 ? RS2 : ((2 * U + RS2 - 1 < NK2) ? 2 * U + RS2 - 1 : NK2);
+                    constexpr int AFTER = (2 * U + RS2 + 1 < NK2) ? 2 * U + RS2 + 1 : NK2;
+                    constexpr int FLY = (BEFORE - 1 - UPTO) > 0 ? (BEFORE - 1 - UPTO) : 0;
+                    wait_vmcnt<FLY * WL>();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    if constexpr (BEFORE < AFTER) issue_w2_c(std::integral_constant<int, BEFORE>{});
+                    if constexpr (BEFORE + 1 < AFTER) issue_w2_c(std::integral_constant<int, BEFORE + 1>{});
+                    static_assert(AFTER - BEFORE <= 2, "at most two stages issued per barrier");
+                };
+                // prologue barrier: stage 0 landed (4 prologue stages may fly; the bias loads above are newer, which only makes
+                // this wait conservative), the patch is complete; one more stage issued
+                wait_vmcnt<(RS2 - 2) * WL>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                issue_w2_c(std::integral_constant<int, RS2 - 1>{});
+                p2_read_c(std::integral_constant<int, 0>{}, wfa, xfa);
+                auto p2_pair = [&](auto uc) {
+                    constexpr int U = decltype(uc)::value, J = 2 * U;
+                    p2_super_c(uc);
+                    p2_read_c(std::integral_constant<int, J + 1>{}, wfb, xfb);
                     pin(wfa, xfa);
                     p2_mul(wfa, xfa);
-                    if (j + 2 < NK2) p2_read(mid2 + ((j + 2) % RS2) * W2B, wfa, xfa);
+                    if constexpr (J + 2 < NK2) p2_read_c(std::integral_constant<int, J + 2>{}, wfa, xfa);
                     pin(wfb, xfb);
                     p2_mul(wfb, xfb);
-                }
+                };
+                static_for<NK2 / 2>(p2_pair);
             } else {
-                for (int j = 0; j < NK2; ++j) {
-                    p2_step(j);
-                    p2_mma(ring + (j % NS2) * W2B);
-                }
+                // unrolled with compile-time step numbers: ring slot, tap position, K offset and wait count are constants
+                // (the rolled loop's switch / modulo / tap bookkeeping competed with the MFMAs for issue slots)
+                static_assert((WS % 512) == 0, "every wave issues every W2 DMA instruction: wait counts are compile-time");
+                static_for<NK2>([&](auto jc) {
+                    constexpr int J = decltype(jc)::value;
+                    constexpr int BEFORE = J == 0 ? PRE2 : ((J - 1 + NS2 < NK2) ? J - 1 + NS2 : NK2);
+                    constexpr int AFTER = (J + NS2 < NK2) ? J + NS2 : NK2;
+                    wait_vmcnt<(BEFORE - 1 - J) * WL>();     // stage J landed; the stages issued after it may stay in flight
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();            // step 0: also "patch complete" and "P1 ring free"
+                    static_for<AFTER - BEFORE>([&](auto ic) { constexpr int S = BEFORE + decltype(ic)::value; issue_w2(S, S % NS2); });
+                    constexpr int TAP = J / CH;
+                    tr = TAP / 3; ts = TAP % 3; tc = J % CH;  // constants: p2_mma's address arithmetic folds
+                    p2_mma(ring + (J % NS2) * W2B);
+                });
             }
         }
         F8_TT(3);
@@ -793,6 +816,7 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
         };
         if constexpr (D3 == 4) {
             static_assert(D3 != 4 || NC3 % 4 == 0, "chunk loop is unrolled by four");
+            // (unrolling all 16 chunks with constant chunk numbers measured 1.4 us slower per launch: ~5k more instructions)
             for (int c = 0; c < NC3; c += 4) {
                 chunk4(c, std::integral_constant<int, 0>{});
                 chunk4(c + 1, std::integral_constant<int, 1>{});
