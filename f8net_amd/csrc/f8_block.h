@@ -1,4 +1,4 @@
-// f8_block.h — device helpers shared by the 8-wave "2x2 block + K split" conv kernels (f8_conv3x3.hip, f8_conv1x1.hip).
+// f8_block.h — device helpers of the 8-wave "2x2 block + K split" conv kernel (f8_conv3x3.hip).
 //
 // Workgroup tile = 4 pixel tiles x NCO cout tiles of 32x32 (NCO = 2 or 4).  NB = 2 * (NCO / 2) wave BLOCKS of 2x2 tiles;
 // the KS = 8 / NB waves of a block split the 32-byte K slices of every stage between them.  acc[i][j]: i = cout tile of

@@ -139,10 +139,6 @@ bool fused_ds_supported(int C, int MID, int COUT, int H, int W, int* R);
 // 3x3 / stride 1 / pad 1 with the input patch resident in LDS (f8_conv3x3.hip); config = false: no instance
 bool conv3x3_patch_config(int cin, int H, int W, int coutP, int* R, int* IMGS, int* BN);
 hipError_t launch_conv3x3_patch(const ConvArgs& a, int cin, hipStream_t s);
-// 1x1 / pad 0 as an 8-wave block GEMM (f8_conv1x1.hip).  config: cout tile (64 / 128) or 0 = no instance;
-// mode 0 plain, 1 residual-carrying, 2 dual; M = output pixels of one launch
-int conv1x1_block_config(int M, int coutP, int ktot, int ktot2, int mode);
-hipError_t launch_conv1x1_block(const ConvArgs& a, int bn, hipStream_t s);
 bool stem_pool_supported(int cin, int cout, int k, int stride, int pad, int pool_k, int pool_s, int pool_p, int P, int Q);
 hipError_t launch_stem_pool(const StemPoolArgs& a, hipStream_t s);
 hipError_t launch_dwconv(const DwArgs& a, hipStream_t s);

@@ -413,191 +413,6 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Persistent variant (no residual operand): a fixed grid of workgroups, each walking a strided list
-// of tiles.  The DMA ring runs AHEAD ACROSS TILE BOUNDARIES, so a tile's first operands are already in
-// LDS when its predecessor's epilogue finishes: no per-workgroup start-up bubble, the epilogue's
-// VALU/stores overlap the next tile's loads, and the work is balanced in units of tiles rather than
-// in rounds of resident workgroups (784 tiles on 768 slots no longer cost two rounds).
-// Tile order: XCD x owns a contiguous chunk of the (pixel-tile major, cout-tile minor) tile list;
-// its workgroups take tiles chunk_base + w, + w + G/8, ... so concurrently running workgroups of one
-// XCD sit on adjacent tiles (shared X rows / 3x3 halos hit that XCD's L2).
-// ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int BK, int WPX, int WCO, bool HAS_PAD, int STAGES>
-__global__ void __launch_bounds__(256) conv_igemm_persist_kernel(const ConvArgs a) {
-    static_assert(WPX * WCO == 4, "4 waves");
-    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
-    constexpr int CPR = BK / 16;
-    constexpr int RPB = 256 / BK;
-    constexpr int XCH = BM * CPR, WCH = BN * CPR;
-    constexpr int XL = (XCH + 255) / 256, WL = (WCH + 255) / 256;
-    constexpr int NLD = XL + WL;
-    constexpr int TPX = BM / WPX / 32, TCO = BN / WCO / 32;
-    constexpr int KK = BK / 32;
-    constexpr int XBYTES = BM * BK, TILE = (BM + BN) * BK;
-    static_assert(STAGES * TILE <= 65536, "static LDS");
-
-    __shared__ __attribute__((aligned(16))) char lds[STAGES * TILE];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 3;
-    const int wpx = wave / WCO, wco = wave % WCO;
-    const int l31 = lane & 31, lh = lane >> 5;
-
-    // ---- this workgroup's tile list
-    const int tilesN = (a.coutP + BN - 1) / BN;
-    const int tilesM = (a.M + BM - 1) / BM;
-    const int T = tilesM * tilesN;
-    const int G = gridDim.x, Gx = G >> 3;                 // host: G % 8 == 0
-    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
-    const int cb = (int)(((long long)T * xcd) >> 3), ce = (int)(((long long)T * (xcd + 1)) >> 3);
-    const int first = cb + w;
-    const int ntl = first < ce ? (ce - first + Gx - 1) / Gx : 0;
-    const int nk = a.ktot / BK;
-    const int total = ntl * nk;
-    if (total == 0) return;
-
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
-
-    // ---- issue-side state: gather descriptors of the tile whose stages are being requested
-    unsigned xbase[XL], wbase[WL];
-    int xh0[XL], xw0[XL];
-    int tr = 0, ts = 0, c0 = 0, kiss = 0;      // K position inside the issue tile
-    int ij = 0;                                 // index of the issue tile in my list
-    auto setup_issue_tile = [&](int t) {
-        const int tile_m = t / tilesN, tile_n = t - tile_m * tilesN;
-        const int m0 = tile_m * BM, co0 = tile_n * BN;
-#pragma unroll
-        for (int i = 0; i < XL; ++i) {
-            const int idx = tid + i * 256;
-            const int row = idx / CPR, chunk = (idx % CPR) ^ ((row / RPB) % CPR);
-            const int m = m0 + row;
-            xh0[i] = xw0[i] = -(1 << 24);
-            xbase[i] = kOOB;
-            if (idx < XCH && m < a.M) {
-                const int n = (int)fast_div((unsigned)m, a.mPQ, a.s1PQ, a.s2PQ), rem = m - n * a.PQ;
-                const int p = (int)fast_div((unsigned)rem, a.mQ, a.s1Q, a.s2Q), q = rem - p * a.Q;
-                xbase[i] = (unsigned)(n * a.sN + p * a.sP + q * a.sQ + a.origin + chunk * 16);
-                xh0[i] = p * a.stride - a.pad;
-                xw0[i] = q * a.stride - a.pad;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < WL; ++j) {
-            const int idx = tid + j * 256;
-            const int row = idx / CPR, chunk = (idx % CPR) ^ ((row / RPB) % CPR);
-            wbase[j] = (idx < WCH) ? (unsigned)((co0 + row) * a.ktot + chunk * 16) : kOOB;
-        }
-        tr = ts = c0 = kiss = 0;
-    };
-    auto issue_stage = [&](int slot) {
-        char* base = lds + slot * TILE;
-        const unsigned koffx = (unsigned)(tr * a.tapH + ts * a.tapW + c0);
-#pragma unroll
-        for (int i = 0; i < XL; ++i) {
-            unsigned off = xbase[i] + koffx;
-            if (HAS_PAD)
-                off = ((unsigned)(xh0[i] + tr) < (unsigned)a.H && (unsigned)(xw0[i] + ts) < (unsigned)a.W) ? off : kOOB;
-            if ((i * 256 + wave * 64) < XCH)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(base + i * 4096 + wave * 1024),
-                                                         16, off, 0, 0, 0);
-        }
-        const unsigned koffw = (unsigned)(kiss * BK);
-#pragma unroll
-        for (int j = 0; j < WL; ++j) {
-            const unsigned woff = wbase[j] + koffw;   // keep a scalar (see conv_igemm_kernel)
-            if ((j * 256 + wave * 64) < WCH)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(base + XBYTES + j * 4096 + wave * 1024),
-                                                         16, woff, 0, 0, 0);
-        }
-        ++kiss;
-        c0 += BK;
-        if (c0 == a.CK) {
-            c0 = 0; ++ts;
-            if (ts == a.kw) { ts = 0; ++tr; }
-        }
-        if (kiss == nk) {                       // crossed into my next tile
-            ++ij;
-            if (ij < ntl) setup_issue_tile(first + ij * Gx);
-        }
-    };
-    constexpr bool UNIFORM_LD = (XCH % 256 == 0) && (WCH % 256 == 0);
-    int my_ld = 0;
-    if (!UNIFORM_LD) {
-#pragma unroll
-        for (int i = 0; i < XL; ++i) my_ld += ((i * 256 + wave * 64) < XCH) ? 1 : 0;
-#pragma unroll
-        for (int j = 0; j < WL; ++j) my_ld += ((j * 256 + wave * 64) < WCH) ? 1 : 0;
-    }
-    // Counted wait.  Only DMA instructions are counted; epilogue stores issued since are NEWER than
-    // every pending DMA, so a count that ignores them can only wait for more than needed, never less.
-    auto wait_ahead = [&](int ahead) {
-        if (UNIFORM_LD) {
-            if (ahead >= 2 && STAGES >= 4) wait_vmcnt<2 * NLD>();
-            else if (ahead >= 1 && STAGES >= 3) wait_vmcnt<1 * NLD>();
-            else wait_vmcnt<0>();
-        } else {
-            const int n = ahead * my_ld;
-            if (n >= 4) wait_vmcnt<4>(); else if (n == 3) wait_vmcnt<3>(); else if (n == 2) wait_vmcnt<2>();
-            else if (n == 1) wait_vmcnt<1>(); else wait_vmcnt<0>();
-        }
-    };
-
-    // ---- per-lane fragment addresses
-    const int fl = (l31 / RPB) % CPR;
-    unsigned coff[KK];
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk) coff[kk] = (unsigned)(((kk * 2 + lh) ^ fl) << 4);
-    const unsigned xfrag0 = (unsigned)((wpx * (BM / WPX) + l31) * BK);
-    const unsigned wfrag0 = (unsigned)(XBYTES + (wco * (BN / WCO) + l31) * BK);
-
-    v16i acc[TCO][TPX];
-    v4i rv[1][1][4];      // no residual in the persistent variant
-
-    setup_issue_tile(first);
-#pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
-        if (s < total) issue_stage(s);
-
-    int cj = 0, ck = 0;                         // compute-side tile / K step
-    for (int step = 0; step < total; ++step) {
-        const int issued = (step + STAGES - 1 < total) ? step + STAGES - 1 : total;
-        wait_ahead(issued - 1 - step);
-        __builtin_amdgcn_s_barrier();
-        if (step + STAGES - 1 < total) issue_stage((step + STAGES - 1) % STAGES);
-        if (ck == 0) {
-#pragma unroll
-            for (int i = 0; i < TCO; ++i)
-#pragma unroll
-                for (int j = 0; j < TPX; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
-        }
-        const char* base = lds + (step % STAGES) * TILE;
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-            v4i wf[TCO], xf[TPX];
-#pragma unroll
-            for (int i = 0; i < TCO; ++i) wf[i] = *(const v4i*)(base + wfrag0 + i * 32 * BK + coff[kk]);
-#pragma unroll
-            for (int j = 0; j < TPX; ++j) xf[j] = *(const v4i*)(base + xfrag0 + j * 32 * BK + coff[kk]);
-#pragma unroll
-            for (int i = 0; i < TCO; ++i)
-#pragma unroll
-                for (int j = 0; j < TPX; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xf[j], acc[i][j], 0, 0, 0);
-        }
-        if (++ck == nk) {
-            const int t = first + cj * Gx;
-            const int tile_m = t / tilesN, tile_n = t - tile_m * tilesN;
-            conv_epilogue<BM, BN, WPX, WCO, false, TCO, TPX>(a, acc, rv, tile_m * BM, tile_n * BN, wpx, wco, l31, lh);
-            ck = 0; ++cj;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Depthwise 3x3 (VALU).  One thread = one output pixel x 4 channels (one dword of NHWC int8).
 // Unsigned inputs are multiplied as unsigned bytes directly: no offset trick needed here.
 // ---------------------------------------------------------------------------------------------
@@ -1096,20 +911,6 @@ static hipError_t launch_conv_t(const ConvArgs& a, int grid, hipStream_t s) {
     constexpr int TILE = (BM + BN) * BK;
     static_assert(ST * TILE <= 65536, "static LDS");
     const bool pad = a.pad > 0, res = a.res != nullptr;
-    static const int persist_mode = [] { const char* e = getenv("F8_PERSIST"); return e ? atoi(e) : 0; }();
-    if (!res && persist_mode) {
-        // persistent variant: fixed grid (multiple of 8 XCDs), deeper ring
-        constexpr int PST = (4 * TILE <= 65536) ? 4 : ((3 * TILE <= 65536) ? 3 : 2);
-        static const int wpc_env = [] { const char* e = getenv("F8_PERSIST_WPC"); return e ? atoi(e) : 0; }();
-        const int lds_wpc = 163840 / (PST * TILE);
-        int wpc = wpc_env > 0 ? wpc_env : (lds_wpc < 3 ? lds_wpc : 3);
-        if (wpc < 1) wpc = 1;
-        int g = num_cus() * wpc;
-        if (g > grid) g = (grid + 7) / 8 * 8;
-        if (pad) hipLaunchKernelGGL((conv_igemm_persist_kernel<BM, BN, BK, WPX, WCO, true, PST>), dim3(g), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((conv_igemm_persist_kernel<BM, BN, BK, WPX, WCO, false, PST>), dim3(g), dim3(256), 0, s, a);
-        return hipGetLastError();
-    }
     // long K loops (3x3 of the late stages: 36-72 steps of ~64-256 MFMA cycles against an ~800-cycle DMA round
     // trip) want a deeper ring; short ones want the smaller LDS footprint
     const int deep_nk = conv_deep_nk();

@@ -81,7 +81,6 @@ struct Node {
     int fbd_a = -1, fbd_b = -1;          // shortcut conv hosting a fused stage-opening block (DS): body.0 / body.2 (body.4 = `dual`)
     int dual = -1;                     // 1x1 conv hosting a join whose other operand is ANOTHER 1x1 conv (node id): one dual-GEMM launch
     int dual_host = -1;                // ... and that other conv: the node that carries it
-    int c1_bn = 0;                     // 1x1 conv on the 8-wave block kernel (cout tile 64 / 128), 0 = implicit-GEMM kernel
     int p3_R = 0, p3_imgs = 0, p3_bn = 0;   // 3x3 conv on the LDS-patch kernel (p3_R > 0): rows / images per tile, cout tile
     bool no_classes = false;           // pack a single bias class (the consumer kernel pads with real zeros itself)
     size_t w_off = 0, b_off = 0; int coutP = 0, ck = 0, ktot = 0;
@@ -558,14 +557,10 @@ static void label_conv_step(f8_net* net, Step& st, const Node& nd) {
     else snprintf(buf, sizeof buf, "conv%dx%ds%d_t%dx%dx%d%s%s:%s", d.kernel, d.kernel, d.stride, nd.tile.bm, nd.tile.bn,
                   nd.tile.bk, nd.stem ? "_stem" : "", st.res_t >= 0 ? "_res" : (nd.dual >= 0 ? "_dual" : ""),
                   (nd.dual >= 0 ? tname(net, ND[nd.dual].out) + "+" + tname(net, nd.out) : tname(net, nd.out)).c_str());
-    if (nd.c1_bn > 0) snprintf(buf, sizeof buf, "conv1x1s%d_blk128x%d%s:%s", d.stride, nd.c1_bn, st.res_t >= 0 ? "_res" : (nd.dual >= 0 ? "_dual" : ""),
-                               (nd.dual >= 0 ? tname(net, ND[nd.dual].out) + "+" + tname(net, nd.out) : tname(net, nd.out)).c_str());
     if (nd.p3_R > 0) snprintf(buf, sizeof buf, "conv3x3s1_patch_R%dx%d_bn%d%s:%s", nd.p3_R, nd.p3_imgs, nd.p3_bn, st.res_t >= 0 ? "_res" : "",
                               tname(net, nd.out).c_str());
     st.name = buf;
     if (nd.depthwise) snprintf(buf, sizeof buf, "f8::dwconv3x3_dot4_kernel<%d, 2>", d.stride);
-    else if (nd.c1_bn > 0) snprintf(buf, sizeof buf, "f8::conv1x1_block_kernel<%d, %s, %s>", nd.c1_bn, (st.res_t >= 0 || nd.dual >= 0) ? "true" : "false",
-                                    nd.dual >= 0 ? "true" : "false");
     else if (nd.p3_R > 0) snprintf(buf, sizeof buf, "f8::conv3x3_patch_kernel<%d, %d, %d, %d, %d, %d, %s>", d.cin, s.W, nd.p3_R, nd.p3_imgs, nd.p3_bn,
                                    d.cin == 64 ? 64 : (nd.p3_bn == 128 ? 128 : 256), st.res_t >= 0 ? "true" : "false");   // keep in sync with launch_conv3x3_patch
     else {
@@ -903,13 +898,6 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                         nd.tile.bk = 64;
                         if (nd.coutP >= wide && nd.tile.bm == 128) nd.tile.bn = 128; else nd.tile.bn = 64;
                     }
-                    if (!nd.stem && nd.cd.groups == 1 && nd.cd.kernel == 1 && nd.cd.pad == 0 && nd.ck == nd.cd.cin) {
-                        static const int split = [] { const char* e = getenv("F8_SPLIT"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
-                        const int launch_px = M1 * std::max(1, max_batch / split);
-                        int k2 = 0;
-                        if (nd.dual >= 0) { const Node& g = ND[nd.dual]; k2 = g.cd.cin; }
-                        nd.c1_bn = conv1x1_block_config(launch_px, nd.coutP, nd.ktot, k2, nd.dual >= 0 ? 2 : (nd.fused_add >= 0 ? 1 : 0));
-                    }
                     if (!nd.stem && nd.cd.groups == 1 && nd.cd.kernel == 3 && nd.cd.stride == 1 && nd.cd.pad == 1 && nd.ck == nd.cd.cin &&
                         !conv3x3_patch_config(nd.cd.cin, s.H, s.W, nd.coutP, &nd.p3_R, &nd.p3_imgs, &nd.p3_bn)) nd.p3_R = 0;
                 }
@@ -1223,7 +1211,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
                 a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1;
             }
             fill_out(&a.out32, a.q);
-            e = nd.c1_bn > 0 ? launch_conv1x1_block(a, nd.c1_bn, s) : (nd.p3_R > 0 ? launch_conv3x3_patch(a, d.cin, s) : launch_conv(a, nd.tile, s));
+            e = nd.p3_R > 0 ? launch_conv3x3_patch(a, d.cin, s) : launch_conv(a, nd.tile, s);
             break;
         }
         case S_STEMPOOL: {
@@ -1367,7 +1355,7 @@ int f8_net_autotune(f8_net* net, int N, void* stream) {
     for (auto& st : net->steps) {
         if (st.kind != S_CONV) continue;
         Node& nd = net->nodes[st.node];
-        if (nd.c1_bn > 0 || nd.p3_R > 0) continue;
+        if (nd.p3_R > 0) continue;
         const ConvTile keep = nd.tile;
         ConvTile best = keep; float best_ms = 1e30f;
         for (int c = 0; c < 4; ++c) {

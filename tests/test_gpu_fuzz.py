@@ -1,6 +1,8 @@
 """Randomised topologies through the planner (GPU) vs the CPU oracle: mixes of bottleneck / basic / inverted-residual /
 depthwise-separable blocks with random widths, strides, signed inputs and fraction lengths, at the spatial sizes where the
 special kernels kick in (56 / 28 / 14 / 7 wide: fused blocks, dual-GEMM joins, LDS-patch 3x3, fused head).  Bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -107,7 +109,8 @@ def test_resnet_like_random_fraclens(seed):
     x, x_fl = synth.make_input(spec, params, n, 224, seed=seed + 7)
     net = build_net(spec, params, max_batch=n, hw=224)
     plan = net.describe()
-    assert 'fused_bottleneck_R' in plan and 'stem7x7s2+maxpool3x3s2' in plan
+    if not any(k.startswith('F8_') for k in os.environ):     # default planner (tuning switches change the plan, not the results)
+        assert 'fused_bottleneck_R' in plan and 'stem7x7s2+maxpool3x3s2' in plan
     got = net.run(torch.from_numpy(x).to(dev)).cpu().numpy()
     try:
         want = oracle.net_forward(spec, params, x, x_fl)
