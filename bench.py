@@ -97,8 +97,10 @@ def main():
     # the all-gather of step i overlaps the compute of step i+1 (double-buffered logits); fence() completes every
     # outstanding collective before the clock stops
     # consecutive steps overlap inside the library as well (f8_net_set_pipelined: static input, double-buffered outputs)
-    pipelined = os.environ.get('F8_BENCH_PIPELINED', '1') != '0'
-    net.set_pipelined(pipelined)
+    # F8_BENCH_PIPELINED: 0 = runs back to back, 1 = lagged sub-batches, 2 = whole batches alternating between two streams
+    pipe_mode = int(os.environ.get('F8_BENCH_PIPELINED', '2'))
+    pipelined = pipe_mode != 0
+    net.set_pipelined(pipe_mode)
     sharded = f8dist.PipelinedShardedForward(lambda t, out: net.run(t, out=out), spec.num_classes, BS, dev, lagged=pipelined)
     logits = sharded.local[0]
 
@@ -129,8 +131,8 @@ def main():
     if rank == 0:
         imgs = BS * world * args.steps
         value = imgs / dt
-        net.set_pipelined(False)
-        # ---- roofline of the dominant kernel, measured live (HIP events on the launch stream)
+        # ---- roofline of the dominant kernel, measured live (HIP events on the launch stream); the pipelining mode stays
+        #      set so that the profiled pass issues the launches the timed region issued (whole batch vs sub-batches)
         n_l = net.num_launches
         reps = 7
         samples = []

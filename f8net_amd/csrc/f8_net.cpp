@@ -122,6 +122,7 @@ struct f8_net {
     const float* in_f32 = nullptr; float in_scale = 0.f; int in_lo = 0, in_hi = 0;   // set by f8_net_run_f32 for the duration of the call
     // pipelined submission (f8_net_set_pipelined): fork dependency = the event recorded at the PREVIOUS run's entry
     int pipelined = 0; hipEvent_t start_ev[2] = {nullptr, nullptr}; int start_idx = 0; bool have_prev_start = false; hipStream_t prev_stream = nullptr;
+    int alt_idx = 0;                   // pipelined == 2: internal stream / arena copy of the next run
     // hipGraph of one whole run (both sub-batch streams), replayed while (input, output, N, stream) stay the same
     hipGraphExec_t g_exec = nullptr; const void* g_in = nullptr; void* g_out = nullptr; int g_N = 0; hipStream_t g_stream = nullptr; int g_warm = 0;
 };
@@ -396,7 +397,7 @@ int f8_net_output(f8_net* net, int src, int as_float) {
 
 int f8_net_set_pipelined(f8_net* net, int on) {
     if (!net) return fail(F8_ERR_INVALID, "f8_net_set_pipelined: null net");
-    net->pipelined = on ? 1 : 0;
+    net->pipelined = on == 2 ? 2 : (on ? 1 : 0);
     net->have_prev_start = false;
     return F8_OK;
 }
@@ -1410,7 +1411,8 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
     hipStream_t s = (hipStream_t)stream;
     const int ns = (int)net->steps.size();
     int cut[5];
-    const int parts = split_batch(net, N, cut);
+    int parts = split_batch(net, N, cut);
+    if (ms && net->pipelined == 2) { parts = 1; cut[0] = 0; cut[1] = N; }   // time the launches the alternating mode issues
     if (ms) {
         // profiled: the sub-batches back to back on the caller's stream, one event pair per launch
         if (cap < ns) return fail(F8_ERR_INVALID, "f8_net_run_profiled: ms capacity %d < %d launches", cap, ns);
@@ -1441,6 +1443,49 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
         }
         return F8_OK;
     }
+    auto ensure_aux = [&]() -> int {
+        if (net->aux[0]) return F8_OK;
+        for (int k = 0; k < 4; ++k) {
+            hipError_t e = hipStreamCreateWithFlags(&net->aux[k], hipStreamNonBlocking);
+            if (e != hipSuccess) return hip_fail(e, "hipStreamCreate");
+        }
+        for (int k = 0; k < 5; ++k) {
+            hipError_t e = hipEventCreateWithFlags(&net->aux_ev[k], hipEventDisableTiming);
+            if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
+        }
+        return F8_OK;
+    };
+    static const int arena_copies = [] { const char* e = getenv("F8_SPLIT"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+    static const int use_streams = [] { const char* e = getenv("F8_SPLIT_STREAMS"); return e ? atoi(e) : 1; }();
+    if (net->pipelined == 2 && arena_copies >= 2 && !use_streams) {   // rocprofv3 runs: the same launches, alone on the caller's stream
+        for (int i = 0; i < ns; ++i) {
+            rc = run_step(net, net->steps[i], input, output, 0, N, 0, s);
+            if (rc) return rc;
+        }
+        return F8_OK;
+    }
+    if (net->pipelined == 2 && arena_copies >= 2) {
+        // alternating whole batches: run i executes UNSPLIT on internal stream / arena copy i % 2, so that two consecutive
+        // runs are in flight together — the same occupancy as two concurrent sub-batches, but every launch covers the whole
+        // batch (twice the workgroups per launch: at 128 images the latency-bound launches of the late stages fill the chip).
+        // Fork: as in the lagged mode the stream waits for `s` as of the PREVIOUS run's entry (and, by stream order, for
+        // run i-2 on the same arena copy); join: `s` waits for this run.
+        if ((rc = ensure_aux())) return rc;
+        if (!net->start_ev[0])
+            for (int k = 0; k < 2; ++k) (void)hipEventCreateWithFlags(&net->start_ev[k], hipEventDisableTiming);
+        const int cur = net->start_idx, slot = net->alt_idx;
+        (void)hipEventRecord(net->start_ev[cur], s);
+        hipEvent_t dep = (net->have_prev_start && net->prev_stream == s) ? net->start_ev[cur ^ 1] : net->start_ev[cur];
+        (void)hipStreamWaitEvent(net->aux[slot], dep, 0);
+        net->start_idx ^= 1; net->have_prev_start = true; net->prev_stream = s; net->alt_idx ^= 1;
+        for (int i = 0; i < ns; ++i) {
+            rc = run_step(net, net->steps[i], input, output, 0, N, slot, net->aux[slot]);
+            if (rc) return rc;
+        }
+        (void)hipEventRecord(net->aux_ev[1 + slot], net->aux[slot]);
+        (void)hipStreamWaitEvent(s, net->aux_ev[1 + slot], 0);
+        return F8_OK;
+    }
     if (parts == 1) {
         for (int i = 0; i < ns; ++i) {
             rc = run_step(net, net->steps[i], input, output, 0, N, 0, s);
@@ -1450,7 +1495,6 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
     }
     // F8_SPLIT_STREAMS=0: same launches, serialised on the caller's stream (used for rocprofv3 runs so
     // that per-kernel durations are not inflated by the overlap of the two sub-batches)
-    static const int use_streams = [] { const char* e = getenv("F8_SPLIT_STREAMS"); return e ? atoi(e) : 1; }();
     if (!use_streams) {
         for (int p = 0; p < parts; ++p)
             for (int i = 0; i < ns; ++i) {
@@ -1461,16 +1505,7 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
     }
     // independent sub-batches on internal streams: while one is in a layer's tail / epilogue phase the
     // others keep the CUs busy.  Fork from and join to the caller's stream with events (no host sync).
-    if (!net->aux[0]) {
-        for (int k = 0; k < 4; ++k) {
-            hipError_t e = hipStreamCreateWithFlags(&net->aux[k], hipStreamNonBlocking);
-            if (e != hipSuccess) return hip_fail(e, "hipStreamCreate");
-        }
-        for (int k = 0; k < 5; ++k) {
-            hipError_t e = hipEventCreateWithFlags(&net->aux_ev[k], hipEventDisableTiming);
-            if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
-        }
-    }
+    if ((rc = ensure_aux())) return rc;
     // F8_GRAPH=1: the second call with the same (input, output, N, stream) captures the launches below into a hipGraph
     // (the aux streams join the capture through the fork event); later calls replay it with one hipGraphLaunch.
     // The legacy null stream cannot be captured: the graph then lives on an internal stream fenced by events.
@@ -1551,7 +1586,8 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
 int f8_net_num_parts(const f8_net* net, int N) {
     if (!net || !net->finalized) return fail(F8_ERR_STATE, "f8_net_num_parts: not finalized");
     int cut[5];
-    return split_batch(net, N, cut);
+    const int parts = split_batch(net, N, cut);
+    return (net->pipelined == 2 && parts >= 2) ? 1 : parts;     // alternating whole batches: one launch set per run
 }
 
 int f8_net_run(f8_net* net, const int32_t* input, void* output, int N, void* stream) {

@@ -172,8 +172,10 @@ class F8Net:
 
     def set_pipelined(self, on=True):
         """Let consecutive runs overlap (f8_net_set_pipelined): the caller keeps inputs / outputs of consecutive runs in
-        buffers that were ready one call earlier (static input, double-buffered outputs)."""
-        check(self._L.f8_net_set_pipelined(self._h, int(bool(on))))
+        buffers that were ready one call earlier (static input, double-buffered outputs).  on=2 / 'alternate': whole
+        batches of consecutive runs alternate between two internal streams instead of splitting every run in two."""
+        mode = 2 if on in (2, 'alternate') else int(bool(on))
+        check(self._L.f8_net_set_pipelined(self._h, mode))
 
     def run_f32(self, images, normalize, out=None):
         """images: float32 CUDA tensor [N,C,H,W] as forward_loss receives them (fix_train.py:676-692); the input

@@ -189,7 +189,11 @@ int f8_net_autotune(f8_net* net, int N, void* stream);
  * by the time run i-1 was submitted (static or double-buffered buffers) — and the sub-batches of run i then start as
  * soon as the sub-batches of run i-1 that use the same arena have finished: the tail of one run overlaps the head of
  * the next (its memory-bound early stages with the previous run's compute-bound late stages).  Results still become
- * visible in `stream` order (every run joins `stream`).  Same `stream` for consecutive pipelined runs. */
+ * visible in `stream` order (every run joins `stream`).  Same `stream` for consecutive pipelined runs.
+ * on == 2: same contract, different schedule — every run executes UNSPLIT on one of two internal streams / arena copies,
+ * alternating, so that two consecutive runs are in flight together: each launch covers the whole batch (twice the
+ * workgroups of a sub-batch launch), which is what the latency-bound launches of the late stages need at 128 images;
+ * the latency of one run roughly doubles, the throughput of a stream of runs rises. */
 int f8_net_set_pipelined(f8_net* net, int on);
 
 /* f8_net_run cuts a batch of N into this many independent sub-batches (1..4) that it runs on

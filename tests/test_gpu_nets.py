@@ -110,9 +110,11 @@ def test_full_size_batch_properties(dev, arch, n):
     assert np.count_nonzero(full) > 0.9 * full.size
 
 
-def test_pipelined_runs_overlap_safely(dev):
-    """f8_net_set_pipelined: consecutive runs may overlap when the caller double-buffers; every run's result still equals
-    the strictly ordered one (different inputs per run, two alternating output buffers, many runs in flight)."""
+@pytest.mark.parametrize('mode', [1, 2])
+def test_pipelined_runs_overlap_safely(dev, mode):
+    """f8_net_set_pipelined (1: lagged sub-batches, 2: whole batches alternating between two streams / arena copies):
+    consecutive runs may overlap when the caller double-buffers; every run's result still equals the strictly ordered one
+    (different inputs per run, two alternating output buffers, many runs in flight)."""
     from f8net_amd.net import build_net
     spec = topology.get('resnet50', normalize=True)
     params = synth.make_params(spec, seed=1234, fraclens=topology.R50_NVIDIA_FRACLENS)
@@ -121,7 +123,9 @@ def test_pipelined_runs_overlap_safely(dev):
     xs = [torch.from_numpy(synth.make_input(spec, params, n, 224, seed=100 + i)[0]).to(dev) for i in range(3)]
     want = [net.run(x).cpu().numpy() for x in xs]
     assert not np.array_equal(want[0], want[1])
-    net.set_pipelined(True)
+    net.set_pipelined(mode)
+    if 'F8_SPLIT' not in os.environ:
+        assert net.num_parts(n) == (2 if mode == 1 else 1)
     outs = [torch.empty((n, spec.num_classes), dtype=torch.float32, device=dev) for _ in range(2)]
     hist = []
     for rep in range(12):
@@ -132,6 +136,12 @@ def test_pipelined_runs_overlap_safely(dev):
     net.set_pipelined(False)
     for rep, y in enumerate(hist):
         np.testing.assert_array_equal(y.cpu().numpy(), want[rep % 3])
+    # the profiled pass times the launches this mode issues, and is as exact
+    net.set_pipelined(mode)
+    y, ms = net.run_profiled(xs[1])
+    net.set_pipelined(False)
+    assert len(ms) == net.num_launches and all(t > 0 for t in ms)
+    np.testing.assert_array_equal(y.cpu().numpy(), want[1])
 
 
 def test_autotuned_plan_is_bit_identical(dev, golden_dir):
