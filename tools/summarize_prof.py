@@ -32,7 +32,7 @@ def main():
     rows = list(c.execute('select name, total_calls, total_duration, average, percentage from top_kernels'))
     with open(os.path.join(out, f'rocprof_{tag}_kernel_stats.md'), 'w') as f:
         f.write(f'# rocprofv3 --kernel-trace --stats — `python bench.py --steps 5 --warmup 2 --no-cpu-baseline` ({tag})\n\n')
-        f.write('Durations in microseconds (7 steps + 7 profiled passes = 14 forward passes of ResNet-50, bs 128; every launch covers one 64-image sub-batch).\n\n')
+        f.write('Durations in microseconds (7 steps + 7 profiled passes = 14 forward passes of ResNet-50, bs 128; every launch covers the whole batch — pipelining mode 2, F8_SPLIT_STREAMS=0 so that no two runs overlap).\n\n')
         f.write('| kernel | calls | total us | avg us | % |\n|---|---:|---:|---:|---:|\n')
         for name, calls, tot, avg, pct in rows:
             f.write(f'| `{short(name)}` | {calls} | {tot:.1f} | {avg:.2f} | {pct:.2f} |\n')
