@@ -1,0 +1,55 @@
+"""Every tuning switch of DESIGN.md §9 changes the plan or the schedule, never the integers.  The switches are read once
+per process, so each setting runs in its own interpreter: ResNet-50 (real fraclen table) and MobileNet-V2 at 64x64, bs 3,
+against the golden-pinned CPU oracle.  (Two opt-in paths that had bit-rotted were found this way and removed.)"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import sys
+import numpy as np
+import torch
+from f8net_amd import synth, topology
+from f8net_amd.net import build_net
+from oracle import oracle
+oracle.build()
+for arch in ('resnet50', 'mobilenet_v2'):
+    spec = topology.get(arch, normalize=(arch == 'resnet50'))
+    fr = topology.R50_NVIDIA_FRACLENS if arch == 'resnet50' else None
+    params = synth.make_params(spec, seed=321, fraclens=fr)
+    x, x_fl = synth.make_input(spec, params, 3, 64, seed=5)
+    want = oracle.net_forward(spec, params, x, x_fl)
+    net = build_net(spec, params, max_batch=3, hw=64)
+    xd = torch.from_numpy(x).cuda()
+    got = net.run(xd).cpu().numpy()
+    assert np.array_equal(got, want), arch
+    for mode in (1, 2):                      # pipelined schedules: several runs in flight, two output buffers
+        net.set_pipelined(mode)
+        outs = [torch.empty_like(torch.from_numpy(want)).cuda() for _ in range(2)]
+        keep = []
+        for rep in range(4):
+            net.run(xd, out=outs[rep & 1])
+            keep.append(outs[rep & 1].clone())
+        torch.cuda.synchronize()
+        net.set_pipelined(False)
+        assert all(np.array_equal(k.cpu().numpy(), want) for k in keep), (arch, mode)
+print('OK')
+'''
+
+SWITCHES = ['F8_FUSE_BLOCKS=0', 'F8_FUSE_STAGES=0', 'F8_FUSE_STAGES=7', 'F8_FUSE_DS=0', 'F8_FUSE_DUAL=0', 'F8_FUSE_STEM=0',
+            'F8_PATCH3X3=0', 'F8_SPLIT=1', 'F8_SPLIT=3', 'F8_SPLIT_STREAMS=0', 'F8_GRAPH=1', 'F8_BK128=1', 'F8_DEEP_NK=1',
+            'F8_DUAL_WIDE=0', 'F8_BN=32', 'F8_BM=64', 'F8_RES_BN=128', 'F8_DW_DOT4=0', 'F8_STAGGER=0', 'F8_STEM_WPC=1']
+
+
+@pytest.mark.parametrize('switch', SWITCHES)
+def test_switch_keeps_results_bit_exact(switch):
+    k, v = switch.split('=')
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    env[k] = v
+    r = subprocess.run([sys.executable, '-c', CHILD], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith('OK'), f'{switch}: {r.stdout[-500:]}\n{r.stderr[-1500:]}'
