@@ -628,9 +628,42 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
     {
         constexpr int S0 = (NK1 + NK2) & 1;
         const int floor1 = a.relu1 ? 0 : -2147483647 /* the join's clamp_(min=-(2^31-1)) and the ReLU floor are one max */;
+#ifdef F8_ABL_NOSTORE8_ALL
+        const int n_store = (a.out32 ? 4 : 0);           // ablation: int8 stores removed everywhere
+#else
         const int n_store = (a.out32 ? 4 : 0) + (a.q[0].ptr ? 1 : 0) + (a.q[1].ptr ? 1 : 0);   // store instructions per wave per chunk
+#endif
         static_assert((NPO - 1) * 32 < OUT_PX, "every pixel tile has live lanes (store count in the counted wait)");
         v4i xf[KK3];                                     // this wave's mid2 fragments are chunk-invariant: read once
+        // ---- int8 output through LDS (STG): a wave's int8 result of one chunk is 32 bytes per pixel, and 32-byte pieces at a
+        // COUT-byte pitch cost as many write requests as the four contiguous 1 KB int32 stores together (ablation: removing
+        // the int8 stores — a ninth of the bytes — took 19 % off the 56x56 kernel).  Two chunks (128 channels) are collected
+        // in one of two LDS buffers [128 px][128 B] (16-byte columns XOR-swizzled by the row) and written out as full
+        // 128-byte lines, 8 pixels per wave instruction, while the next pair fills the other buffer.
+        // Measured (128-image launches): identity 56x56 block 208.5 -> 200.2 us; the DS instance (no residual stream, write-
+        // bound) 114.6 -> 120.6 us, so it keeps its direct stores.  (Most of the ablation's 19 % turned out to be the bytes
+        // themselves: the int8 copy is a tenth of a block's traffic, all of it writes.)
+        constexpr bool STG = ALLW && D3 == 2 && !DS;     // the W2 region (36 KB) is dead in P3: room for both buffers
+        static_assert(!STG || (W2ALL >= 2 * 16384 && OUT_PX <= 128 && OUT_PX >= 64 && (NC3 % 2) == 0), "staging buffers / pairs of chunks");
+        char* const stg = ring;
+        const bool stage0 = STG && a.q[0].ptr != nullptr;
+        const int n_direct = (a.out32 ? 4 : 0) + ((!STG && a.q[0].ptr) ? 1 : 0) + (a.q[1].ptr ? 1 : 0);   // direct stores per wave per chunk
+        auto stores_of = [&](int x) { return n_direct + ((stage0 && x >= 2 && !(x & 1)) ? 2 : 0); };       // VMEM stores issued during chunk x
+        auto flush_pair = [&](int c0) {                  // chunks c0, c0+1 -> 128-byte lines; exactly two store instructions per wave
+            const char* buf = stg + ((c0 >> 1) & 1) * 16384;
+            const int npx = rows_out * W;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int t = tid + rr * 512;
+                const int row = t >> 3, c16 = t & 7;
+                const bool live = row < npx;
+                const int rw = live ? row : npx - 1;     // dead rows: one lane re-writes the last row (keeps the instruction count uniform)
+                if (live || lane == 0) {
+                    const v4i v = *(const v4i*)(buf + rw * 128 + ((c16 ^ (rw & 7)) << 4));
+                    *(v4i*)(a.q[0].ptr + (size_t)(m_tile + rw) * COUT + c0 * 64 + c16 * 16) = v;
+                }
+            }
+        };
         // one chunk of 64 output channels; `cur` holds this chunk's residual, `nxt` receives the next one's
         auto chunk = [&](int c, v4i (&cur)[4], v4i (&nxt)[4]) {
             // W4 chunk c landed?  VMEM retires in order, so exactly the operations issued AFTER that DMA may stay in
@@ -638,25 +671,8 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
             // stores (4 for the int32 form + 1 per int8 form; every wave has live lanes, so all of them issue).
             // A smaller count would be safe but would drain the residual prefetch on every chunk (measured: P3
             // 30k -> cycles per tile); a larger one would race.
-            if (DS) {                                    // no residual prefetch: only the previous chunk's stores are newer than the DMA
-                if (c == 0) wait_vmcnt<0>();
-                else switch (n_store) {
-                    case 1: wait_vmcnt<1>(); break;
-                    case 2: wait_vmcnt<2>(); break;
-                    case 4: wait_vmcnt<4>(); break;
-                    case 5: wait_vmcnt<5>(); break;
-                    case 6: wait_vmcnt<6>(); break;
-                    default: wait_vmcnt<0>(); break;
-                }
-            } else if (c == 0) wait_vmcnt<4>();
-            else switch (n_store) {
-                case 1: wait_vmcnt<5>(); break;
-                case 2: wait_vmcnt<6>(); break;
-                case 4: wait_vmcnt<8>(); break;
-                case 5: wait_vmcnt<9>(); break;
-                case 6: wait_vmcnt<10>(); break;
-                default: wait_vmcnt<4>(); break;
-            }
+            // (DS: no residual prefetch, only the previous chunk's stores are newer than the DMA)
+            wait_vmcnt_dyn((DS ? 0 : 4) + (c == 0 ? 0 : stores_of(c - 1)));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                // chunk 0: also "mid2 complete"
             const int cot = c * 64 + wb * 32;
@@ -672,6 +688,7 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
             if (c + 1 < NC3) issue_w4(c + 1, ALLW ? ((c + 1) & 1) : ((S0 + c + 1) & 1));
             asm volatile("" ::: "memory");
             if (!DS) load_res(nxt, c + 1 < NC3 ? c + 1 : c);   // always 4 loads per wave: the counted wait relies on it
+            if (stage0 && c >= 2 && !(c & 1)) flush_pair(c - 2);   // the pair before this one is complete since this chunk's barrier
             const char* base = w4ring + (ALLW ? (c & 1) : ((S0 + c) & 1)) * W4STRIDE;
             if (c == 0) {
 #pragma unroll
@@ -724,8 +741,14 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
                                  requant1(y[g][2], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(y[g][3], a.q[k].n, a.q[k].lo, a.q[k].hi)) ^ a.q[k].bias_xor;
                 auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
                 auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
-                if (opix_ok) {
-                    v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
+#ifdef F8_ABL_NOSTORE8_ALL
+                if (s0[0] == 0x12345678 && s1[1] == 0x7654321)
+#endif
+                const v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
+                if (STG && k == 0) {                     // 16 bytes of pixel `opix`, column (c & 1) * 64 + wb * 32 + lh * 16 of its 128-byte row
+                    const int c16 = (c & 1) * 4 + wb * 2 + lh;
+                    *(v4i*)(stg + ((c >> 1) & 1) * 16384 + opix * 128 + ((c16 ^ (opix & 7)) << 4)) = o;
+                } else if (opix_ok) {
                     *(v4i*)(a.q[k].ptr + (size_t)m * COUT + cot + 16 * lh) = o;
                 }
             }
@@ -827,6 +850,11 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
             for (int c = 0; c < NC3; c += 2) {
                 chunk(c, rv, rn);
                 chunk(c + 1, rn, rv);
+            }
+            if (stage0) {                                // the last pair
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                flush_pair(NC3 - 2);
             }
         }
     }
