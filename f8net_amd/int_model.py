@@ -119,6 +119,23 @@ class IntModel(nn.Module):
         assert images.shape[2] == images.shape[3], 'square inputs'
         return self.plan(int(images.shape[2]), int(images.shape[0])).run_f32(images.contiguous(), normalize)
 
+    def forward_integize(self, x):
+        """The reference's float-carried evaluation of the IntModel — the branches taken when `int_op_only` is unset
+        (fix_resnet.py:384-409 with IntBlock :78-118; fix_mobilenet_v2.py / fix_mobilenet_v1.py likewise): `x` is the REAL-
+        valued float batch; it enters as `(x * 2^head.input_fraclen).int()` (`:391`; with FLAGS.normalize through
+        fix_quant: round + clamp to +-127, `:386-389`), every layer works on real values (`conv(int) / 2^fl`), and the
+        classifier returns its raw integer accumulators (`:408`).  Here the integers are never left: the input is
+        quantised the same way and the planned integer network runs; the result equals the reference's integize output
+        wherever float32 carries the reference's accumulators exactly (all golden nets: tests/test_oracle_golden.py)."""
+        head = self.head[0]
+        fl = int(head.input_fraclen.item())
+        if self.spec.normalize:
+            xi = torch.clamp(torch.round(x * float(2 ** fl)), -127, 127).to(torch.int32)
+        else:
+            xi = (x * float(2 ** fl)).to(torch.int32)          # `.int()`: truncation toward zero, as the reference
+        setattr(xi, 'output_fraclen', fl)
+        return self.forward(xi)
+
     def _load_from_state_dict(self, *a, **k):
         super()._load_from_state_dict(*a, **k)
         self._plans = {}

@@ -183,6 +183,25 @@ def child_model(arch):
                 h.remove()
             tag = f's{seed}_hw{hw}_n{n}'
             out[f'{tag}/logits'] = logits.numpy().astype(np.float32)
+            if hw == 64:
+                # the reference's float-carried "integize" evaluation of the same IntModel (the non-int_op_only
+                # branches: fix_resnet.py:78-118,384-409, fix_mobilenet_v2.py / _v1.py likewise): real-valued float tensors,
+                # requantised with fix_quant, convs in float32.  Fed the real value of the same integers.
+                # (the integize export keeps the integer weights in float tensors, fix_quant_ops.py:700-707: same values)
+                int_model.apply(lambda m: setattr(m, 'int_op_only', False))
+                layers = [mods[key] for key in spec.layer_keys()]
+                for m in layers:
+                    m.weight.data = m.weight.data.float()
+                    m.bias.data = m.bias.data.float()
+                xr = torch.from_numpy(x_np).float() / float(2 ** x_fl)
+                with torch.no_grad():
+                    lg = int_model(xr)
+                for m in layers:
+                    m.weight.data = m.weight.data.int()
+                    m.bias.data = m.bias.data.int()
+                int_model.apply(lambda m: setattr(m, 'int_op_only', True))
+                out[f'{tag}/integize_logits'] = lg.numpy().astype(np.float32)
+                out[f'{tag}/integize_equal'] = np.array(bool(np.array_equal(lg.numpy(), logits.numpy())))
             assert np.count_nonzero(out[f'{tag}/logits']) > 0.9 * logits.numel(), 'degenerate logits'
             names = sorted(caps)
             out[f'{tag}/cap_names'] = np.array(names)

@@ -71,6 +71,19 @@ def test_op_level_path_equals_fused_path(arch, dev):
     np.testing.assert_array_equal(oplevel, want)
 
 
+@pytest.mark.parametrize('arch', ARCHS)
+def test_integize_mode_matches_reference_float_carried_evaluation(arch, golden_dir, dev):
+    """`IntModel.forward_integize` takes the REAL-valued float batch the reference's float-carried branches
+    take (fix_resnet.py:384-409) and returns what they return — captured from the reference IntModel in that mode."""
+    from f8net_amd import int_model
+    g, spec, params = _golden_setup(arch, golden_dir)
+    m = int_model.from_params(spec, params).to(dev)
+    x, x_fl = synth.make_input(spec, params, 2, 64, seed=7)
+    xr = (torch.from_numpy(x).float() / float(2 ** x_fl)).to(dev)
+    got = m.forward_integize(xr).cpu().numpy()
+    np.testing.assert_array_equal(got, g['s1234_hw64_n2/integize_logits'])
+
+
 def test_state_dict_keys_match_reference_export():
     """84 / 216 / 112 / 212 keys, 4 per layer."""
     from f8net_amd import int_model

@@ -98,6 +98,11 @@ def test_whole_net_vs_reference(arch, golden_dir):
         for name, want in zip(names, sums):
             np.testing.assert_array_equal(caps[name], want, err_msg=f'{arch} {tag} layer {name}')
         np.testing.assert_array_equal(logits, g[f'{tag}/logits'])
+        if f'{tag}/integize_logits' in g.files:
+            # the reference's float-carried "integize" evaluation of the same IntModel, fed the real value of
+            # the same input integers — float32 carries these accumulators exactly, so it returns the very same logits
+            assert bool(g[f'{tag}/integize_equal'])
+            np.testing.assert_array_equal(logits, g[f'{tag}/integize_logits'])
 
 
 def test_topk_scoring_matches_reference(ops):
