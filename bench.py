@@ -147,12 +147,12 @@ def main():
             name, nbytes, nops = net.launch_info(i, BS)
             k = net.launch_kernel(i)
             e = by_kernel.setdefault(k, {'ms': 0.0, 'bytes': 0.0, 'ops': 0.0, 'launches': 0})
-            e['ms'] += ms[i]; e['bytes'] += nbytes; e['ops'] += nops; e['launches'] += 1
+            e['ms'] += ms[i]; e['bytes'] += nbytes; e['ops'] += nops; e['launches'] += net.step_launches(i, BS)
             rows.append((i, name, ms[i], nbytes, nops))
         parts = net.num_parts(BS)       # each planned launch is issued once per sub-batch
         dom = max(by_kernel, key=lambda k: by_kernel[k]['ms'])
         d = by_kernel[dom]
-        d_launches = d['launches'] * parts
+        d_launches = d['launches']       # kernel launches per step (sub-batches / chunks included)
         achieved = d['bytes'] / (d['ms'] * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
@@ -177,7 +177,7 @@ def main():
             'config': {'workload': f'{spec.arch} fix_quant INT8 int_op_only forward, bs={BS} per GPU, 224x224, '
                                    f'NVIDIA-pretrained fraclens (normalize: True), int32 NCHW input resident in HBM',
                        'global_batch': BS * world, 'parallelism': f'dp{world} (batch shards + RCCL all-gather of logits)',
-                       'launches_per_step': n_l * parts, 'sub_batches': parts, 'autotuned_launches': retiled},
+                       'launches_per_step': sum(net.step_launches(i, BS) for i in range(n_l)), 'sub_batches': parts, 'autotuned_launches': retiled},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'launches_per_step': d_launches,
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,

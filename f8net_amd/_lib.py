@@ -61,6 +61,7 @@ SYMBOLS = [
     ('f8_net_output_elems', _sz, [_vp]),
     ('f8_net_upload', _i, [_vp]),
     ('f8_net_num_parts', _i, [_vp, _i]),
+    ('f8_net_step_launches', _i, [_vp, _i, _i]),
     ('f8_net_run', _i, [_vp, _vp, _vp, _i, _vp]),
     ('f8_net_run_f32', _i, [_vp, _vp, _i, _vp, _i, _vp]),
     ('f8_net_run_profiled', _i, [_vp, _vp, _vp, _i, _vp, ctypes.POINTER(ctypes.c_float), _i]),

@@ -129,6 +129,10 @@ class F8Net:
     def num_parts(self, N):
         return check(self._L.f8_net_num_parts(self._h, int(N)))
 
+    def step_launches(self, i, N):
+        """Kernel launches planned launch i issues per run of N images (sub-batches / chunks), f8_net_step_launches."""
+        return check(self._L.f8_net_step_launches(self._h, i, int(N)))
+
     def launch_kernel(self, i):
         buf = ctypes.create_string_buffer(256)
         check(self._L.f8_net_launch_kernel(self._h, i, buf, 256))
