@@ -1403,30 +1403,33 @@ static int split_batch(const f8_net* net, int N, int cut[5]) {
     return parts;
 }
 
-// Chunked execution.  The 56x56 fused bottleneck blocks of a stage run in chunks of F8_CHUNK images (default 32), block after
-// block per chunk: a chunk's int32 stream (103 MB at 32 images) is still in the memory-side cache when the next block reads
-// it.  Measured, identity blocks alone: 3.12 us per image in one 128-image launch, 2.66 us in 32-image launches; whole
-// net at bs 128: chunks of 16 / 24 / 32 / 40 / 48 images = +1.0 / +2.1 / +1.4 / -1.4 / -0.7 %.  Applies wherever one stream
-// executes a whole run (pipelining mode 2, a single part, serialised sub-batches); the interleaved sub-batch schedule
-// launches 64 images at a time anyway.
-static int chunk_images() {
-    static const int chunk = [] { const char* e = getenv("F8_CHUNK"); return e ? atoi(e) : 32; }();
-    return chunk;
+// Chunked execution.  The fused bottleneck blocks of a stage run in chunks of images, block after block per chunk: a chunk's
+// int32 stream (78 MB for 24 images at 56x56, 103 MB for 64 images at 28x28) is still in the memory-side cache when the next
+// block reads it.  Measured, 56x56 identity blocks alone: 3.12 us per image in one 128-image launch, 2.66 us in 32-image
+// launches.  Whole net at bs 128, same box: 56x56 chunks of 16 / 24 / 32 / 40 / 48 images = +1.0 / +2.1 / +1.4 / -1.4 / -0.7 %;
+// then 28x28 chunks of 32 / 48 / 64 / 80 / 96 = +1.7 / +2.5 / +2.9 / +2.8 / +1.1 %; the 14x14 tensors (103 MB per batch) need
+// none.  Applies wherever one stream executes a whole run (pipelining mode 2, a single part, serialised sub-batches); the
+// interleaved sub-batch schedule launches 64 images at a time anyway.
+static int chunk_images(int W) {                         // images per chunk for a fused block on W x W maps (0 = whole batch)
+    static const int c56 = [] { const char* e = getenv("F8_CHUNK"); return e ? atoi(e) : 24; }();
+    static const int c28 = [] { const char* e = getenv("F8_CHUNK28"); return e ? atoi(e) : 64; }();
+    return W == 56 ? c56 : (W == 28 ? c28 / 2 * 2 : 0);  // 28 x 28 = 784 pixels: even image offsets are I32T-block aligned
 }
-static bool step_is_chunked(const f8_net* net, int i) {
+static int step_chunk(const f8_net* net, int i) {
     const Step& st = net->steps[i];
-    if (st.kind != S_FUSED) return false;
+    if (st.kind != S_FUSED) return 0;
     const Tensor& x = net->tensors[st.src_t];
-    return x.W == 56 && x.H == 56;                       // 3136 pixels per image: any image offset is I32T-block aligned
+    return x.W == x.H ? chunk_images(x.W) : 0;
 }
 // f(step index, first image of the chunk, images) for every kernel launch of a run over N images, in launch order
 extern "C++" template <class F>
 static int for_each_launch(const f8_net* net, int N, F&& f) {
-    const int ns = (int)net->steps.size(), chunk = chunk_images();
+    const int ns = (int)net->steps.size();
     for (int i = 0; i < ns;) {
-        if (chunk > 0 && N > chunk && step_is_chunked(net, i)) {
+        const int chunk = step_chunk(net, i);
+        if (chunk > 0 && N > chunk) {
             int j = i;
-            while (j < ns && step_is_chunked(net, j)) ++j;
+            while (j < ns && step_chunk(net, j) == chunk && net->tensors[net->steps[j].src_t].W == net->tensors[net->steps[i].src_t].W) ++j;
             for (int c0 = 0; c0 < N; c0 += chunk)
                 for (int k = i; k < j; ++k) { const int rc = f(k, c0, std::min(chunk, N - c0)); if (rc) return rc; }
             i = j;
