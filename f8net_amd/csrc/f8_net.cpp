@@ -1417,7 +1417,7 @@ static int chunk_images(int W) {                         // images per chunk for
 }
 static int step_chunk(const f8_net* net, int i) {
     const Step& st = net->steps[i];
-    if (st.kind != S_FUSED) return 0;
+    if (st.kind != S_FUSED) return 0;                    // (chunking the stage-opening convs as well: -3 %, more launches than locality)
     static const int chunk_ds = [] { const char* e = getenv("F8_CHUNK_DS"); return e ? atoi(e) : 1; }();
     if (!chunk_ds && net->nodes[st.node].fbd_a >= 0) return 0;
     const Tensor& x = net->tensors[st.src_t];
