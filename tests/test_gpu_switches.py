@@ -53,3 +53,42 @@ def test_switch_keeps_results_bit_exact(switch):
     env[k] = v
     r = subprocess.run([sys.executable, '-c', CHILD], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith('OK'), f'{switch}: {r.stdout[-500:]}\n{r.stderr[-1500:]}'
+
+
+CHUNK_CHILD = r'''
+import numpy as np
+import torch
+from f8net_amd import synth, topology
+from f8net_amd.net import build_net
+from oracle import oracle
+oracle.build()
+spec = topology.get('resnet50', normalize=True)
+params = synth.make_params(spec, seed=77, fraclens=topology.R50_NVIDIA_FRACLENS)
+x, x_fl = synth.make_input(spec, params, 5, 224, seed=3)
+want = oracle.net_forward(spec, params, x, x_fl)
+net = build_net(spec, params, max_batch=5, hw=224)
+assert 'fused_bottleneck' in net.describe()
+xd = torch.from_numpy(x).cuda()
+launches = sum(net.step_launches(i, 5) for i in range(net.num_launches))
+for mode in (0, 2):                          # one stream per run: chunks of 2 + 2 + 1 images through the fused blocks
+    net.set_pipelined(mode)
+    outs = [torch.empty((5, 1000), dtype=torch.float32, device='cuda') for _ in range(2)]
+    for rep in range(3):
+        net.run(xd, out=outs[rep & 1])
+    torch.cuda.synchronize()
+    assert np.array_equal(outs[0].cpu().numpy(), want) and np.array_equal(outs[1].cpu().numpy(), want), mode
+    y, ms = net.run_profiled(xd)
+    assert np.array_equal(y.cpu().numpy(), want)
+net.set_pipelined(2)
+print('OK', launches, sum(net.step_launches(i, 5) for i in range(net.num_launches)), net.num_launches)
+'''
+
+
+def test_chunked_execution_is_bit_exact_with_ragged_chunks():
+    """F8_CHUNK / F8_CHUNK28 = 2 on a 5-image batch at 224x224: every fused block runs as 2 + 2 + 1 images (pipelining mode 2 and
+    the profiled pass; in the default mode the two sub-batches of 2 / 3 images chunk as well when serialised)."""
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''), F8_CHUNK='2', F8_CHUNK28='2')
+    r = subprocess.run([sys.executable, '-c', CHUNK_CHILD], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().startswith('OK'), f'{r.stdout[-500:]}\n{r.stderr[-1500:]}'
+    _, split_launches, alt_launches, planned = r.stdout.split()
+    assert int(alt_launches) > int(planned)          # chunks add launches where one stream runs the whole batch
