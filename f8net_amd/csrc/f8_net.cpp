@@ -1413,7 +1413,9 @@ static int split_batch(const f8_net* net, int N, int cut[5]) {
 static int chunk_images(int W) {                         // images per chunk for a fused block on W x W maps (0 = whole batch)
     static const int c56 = [] { const char* e = getenv("F8_CHUNK"); return e ? atoi(e) : 24; }();
     static const int c28 = [] { const char* e = getenv("F8_CHUNK28"); return e ? atoi(e) : 64; }();
-    return W == 56 ? c56 : (W == 28 ? c28 / 2 * 2 : 0);  // 28 x 28 = 784 pixels: even image offsets are I32T-block aligned
+    static const int c14 = [] { const char* e = getenv("F8_CHUNK14"); return e ? atoi(e) : 128; }();   // only batches > 128 chunk here
+    // 28 x 28 = 784 pixels: even image offsets are I32T-block aligned; 14 x 14 = 196 pixels: multiples of 8
+    return W == 56 ? c56 : (W == 28 ? c28 / 2 * 2 : (W == 14 ? c14 / 8 * 8 : 0));
 }
 static int step_chunk(const f8_net* net, int i) {
     const Step& st = net->steps[i];

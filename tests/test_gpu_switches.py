@@ -64,15 +64,15 @@ from oracle import oracle
 oracle.build()
 spec = topology.get('resnet50', normalize=True)
 params = synth.make_params(spec, seed=77, fraclens=topology.R50_NVIDIA_FRACLENS)
-x, x_fl = synth.make_input(spec, params, 5, 224, seed=3)
+x, x_fl = synth.make_input(spec, params, 9, 224, seed=3)
 want = oracle.net_forward(spec, params, x, x_fl)
-net = build_net(spec, params, max_batch=5, hw=224)
+net = build_net(spec, params, max_batch=9, hw=224)
 assert 'fused_bottleneck' in net.describe()
 xd = torch.from_numpy(x).cuda()
-launches = sum(net.step_launches(i, 5) for i in range(net.num_launches))
-for mode in (0, 2):                          # one stream per run: chunks of 2 + 2 + 1 images through the fused blocks
+launches = sum(net.step_launches(i, 9) for i in range(net.num_launches))
+for mode in (0, 2):                          # one stream per run: chunks of 2 (8 at 14x14) images through the fused blocks
     net.set_pipelined(mode)
-    outs = [torch.empty((5, 1000), dtype=torch.float32, device='cuda') for _ in range(2)]
+    outs = [torch.empty((9, 1000), dtype=torch.float32, device='cuda') for _ in range(2)]
     for rep in range(3):
         net.run(xd, out=outs[rep & 1])
     torch.cuda.synchronize()
@@ -80,14 +80,15 @@ for mode in (0, 2):                          # one stream per run: chunks of 2 +
     y, ms = net.run_profiled(xd)
     assert np.array_equal(y.cpu().numpy(), want)
 net.set_pipelined(2)
-print('OK', launches, sum(net.step_launches(i, 5) for i in range(net.num_launches)), net.num_launches)
+print('OK', launches, sum(net.step_launches(i, 9) for i in range(net.num_launches)), net.num_launches)
 '''
 
 
 def test_chunked_execution_is_bit_exact_with_ragged_chunks():
-    """F8_CHUNK / F8_CHUNK28 = 2 on a 5-image batch at 224x224: every fused block runs as 2 + 2 + 1 images (pipelining mode 2 and
-    the profiled pass; in the default mode the two sub-batches of 2 / 3 images chunk as well when serialised)."""
-    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''), F8_CHUNK='2', F8_CHUNK28='2')
+    """F8_CHUNK / F8_CHUNK28 = 2, F8_CHUNK14 = 8 on a 9-image batch at 224x224: the 56x56 / 28x28 fused blocks run as 2+2+2+2+1
+    images, the 14x14 ones as 8+1 (pipelining mode 2 and the profiled pass)."""
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''), F8_CHUNK='2', F8_CHUNK28='2',
+               F8_CHUNK14='8', F8_FUSE_STAGES='7')
     r = subprocess.run([sys.executable, '-c', CHUNK_CHILD], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().startswith('OK'), f'{r.stdout[-500:]}\n{r.stderr[-1500:]}'
     _, split_launches, alt_launches, planned = r.stdout.split()
