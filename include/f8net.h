@@ -201,9 +201,9 @@ int f8_net_set_pipelined(f8_net* net, int on);
  * is therefore issued this many times per run, each over N / parts images. */
 int f8_net_num_parts(const f8_net* net, int N);
 
-/* Kernel launches planned launch `i` issues in a run of N images under the current schedule: one per sub-batch, or — where
- * one stream executes the whole run — one per chunk of F8_CHUNK images for the launches that run chunked (the 56x56 fused
- * blocks).  f8_net_run_profiled reports the SUM over these launches for launch i. */
+/* Kernel launches planned launch `i` issues in a run of N images under the current schedule: one per sub-batch, times the
+ * chunks of images the launches that run chunked (the fused bottleneck blocks; F8_CHUNK*) are cut into.
+ * f8_net_run_profiled reports the SUM over these launches for launch i. */
 int f8_net_step_launches(const f8_net* net, int i, int N);
 
 /* Same, bracketing every launch with HIP events on `stream`; ms[i] = duration of launch i summed over
