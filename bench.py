@@ -177,7 +177,11 @@ def main():
             'config': {'workload': f'{spec.arch} fix_quant INT8 int_op_only forward, bs={BS} per GPU, 224x224, '
                                    f'NVIDIA-pretrained fraclens (normalize: True), int32 NCHW input resident in HBM',
                        'global_batch': BS * world, 'parallelism': f'dp{world} (batch shards + RCCL all-gather of logits)',
-                       'launches_per_step': sum(net.step_launches(i, BS) for i in range(n_l)), 'sub_batches': parts, 'autotuned_launches': retiled},
+                       'launches_per_step': sum(net.step_launches(i, BS) for i in range(n_l)), 'sub_batches': parts, 'autotuned_launches': retiled,
+                       'schedule': {0: 'runs back to back (two concurrent sub-batches per run)',
+                                    1: 'pipelined: sub-batches of consecutive runs overlap (f8_net_set_pipelined(1))',
+                                    2: 'pipelined: two consecutive batches in flight, each launch covers a whole batch '
+                                       '(f8_net_set_pipelined(2)); every timed step completes inside the timed region'}[pipe_mode]},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'launches_per_step': d_launches,
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
