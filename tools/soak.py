@@ -1,0 +1,32 @@
+"""Soak test of the pipelined schedules: thousands of overlapping runs on varying inputs, every result compared on the GPU
+with the strictly ordered result of the same input.  `python tools/soak.py [runs]`"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from f8net_amd import synth, topology
+from f8net_amd.net import build_net
+
+runs = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+spec = topology.get('resnet50', normalize=True)
+params = synth.make_params(spec, seed=1234, fraclens=topology.R50_NVIDIA_FRACLENS)
+n = 128
+net = build_net(spec, params, max_batch=n, hw=224)
+xs = [torch.from_numpy(synth.make_input(spec, params, n, 224, seed=50 + i)[0]).cuda() for i in range(3)]
+want = [net.run(x).clone() for x in xs]
+torch.cuda.synchronize()
+for mode in (2, 1):
+    net.set_pipelined(mode)
+    outs = [torch.empty((n, 1000), dtype=torch.float32, device='cuda') for _ in range(2)]
+    bad = torch.zeros((), dtype=torch.int64, device='cuda')
+    for r in range(runs):
+        o = outs[r & 1]
+        net.run(xs[r % 3], out=o)
+        bad += (o != want[r % 3]).any().to(torch.int64)        # consumer enqueued right after its run
+    torch.cuda.synchronize()
+    net.set_pipelined(False)
+    print(f'mode {mode}: {runs} overlapping runs, {int(bad.item())} with a wrong result')
+    assert int(bad.item()) == 0
+print('OK')
