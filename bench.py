@@ -60,8 +60,8 @@ def main():
     global BS
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--arch', default='resnet50', help='other nets are parity-test cases, not bench lines')
     ap.add_argument('--bs', type=int, default=BS, help='images per GPU (the headline metric is quoted at 128)')
