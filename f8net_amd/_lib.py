@@ -71,6 +71,9 @@ SYMBOLS = [
     ('f8_net_set_label', _i, [_vp, _i, ctypes.c_char_p]),
     ('f8_net_set_pipelined', _i, [_vp, _i]),
     ('f8_net_autotune', _i, [_vp, _i, _vp]),
+    ('f8_net_set_option', _i, [_vp, ctypes.c_char_p, _i]),
+    ('f8_net_get_option', _i, [_vp, ctypes.c_char_p, ctypes.POINTER(_i)]),
+    ('f8_net_set_input_ready', _i, [_vp, _vp]),
 ]
 
 

@@ -326,8 +326,7 @@ static hipError_t launch_patch_t(const ConvArgs& a, hipStream_t s) {
 
 // Shapes with an instance: (cin, input width) -> rows per tile / images per tile / cout tile.
 bool conv3x3_patch_config(int cin, int H, int W, int coutP, int* R, int* IMGS, int* BN) {
-    static const int on = [] { const char* e = getenv("F8_PATCH3X3"); return e ? atoi(e) : 1; }();
-    if (!on || coutP < 64) return false;
+    if (coutP < 64) return false;
     if (cin == 128 && W == 28 && H % 4 == 0) { *R = 4; *IMGS = 1; *BN = 128; return true; }
     if (cin == 256 && W == 14 && H % 7 == 0) { *R = 7; *IMGS = 1; *BN = 128; return true; }
     if (cin == 512 && W == 7 && H == 7) { *R = 7; *IMGS = 2; *BN = 64; return true; }

@@ -920,14 +920,12 @@ hipError_t launch_fused_bottleneck(const FusedArgs& a, hipStream_t s) {
 
 // stage-opening bottleneck at unchanged resolution (1x1 -> 3x3 -> [1x1 + 1x1 shortcut]): the ResNet-50 stage-0 shape
 bool fused_ds_supported(int C, int MID, int COUT, int H, int W, int* R) {
-    static const int on = [] { const char* e = getenv("F8_FUSE_DS"); return e ? atoi(e) : 1; }();
-    if (on && C == 64 && MID == 64 && COUT == 256 && W == 56 && H % 2 == 0) { *R = 2; return true; }
+    if (C == 64 && MID == 64 && COUT == 256 && W == 56 && H % 2 == 0) { *R = 2; return true; }
     return false;
 }
 
-bool fused_bottleneck_supported(int C, int MID, int H, int W, int imgs_per_launch, int* R) {
-    // bit s = stage s.  Unset: stages 0 and 1 always, stage 2 when one launch fills at least half the chip.
-    static const int mask = [] { const char* e = getenv("F8_FUSE_STAGES"); return e ? atoi(e) : -1; }();
+bool fused_bottleneck_supported(int C, int MID, int H, int W, int imgs_per_launch, int mask, int* R) {
+    // mask (Options::fuse_stages): bit s = stage s.  -1: stages 0 and 1 always, stage 2 when one launch fills at least half the chip.
     if ((mask & 1) && C == 256 && MID == 64 && W == 56 && H % 2 == 0) { *R = 2; return true; }
     if ((mask & 2) && C == 512 && MID == 128 && W == 28 && H % 4 == 0) { *R = 4; return true; }
     if (C == 1024 && MID == 256 && W == 14 && H % 7 == 0) {

@@ -7,6 +7,35 @@
 
 namespace f8 {
 
+// Per-handle tuning options (f8_net_set_option; include/f8net.h lists the keys).  Defaults are the measured best; the
+// environment (F8_<KEY>) only seeds the defaults of a new handle, so two nets in one process can differ.
+struct Options {
+    int split = 2;               // concurrent sub-batches per run = arena copies (1..4)
+    int fuse_blocks = 1;         // whole-bottleneck fusion
+    int fuse_stages = -1;        // bit mask of stages for the identity-block fusion (-1: stages 0+1, stage 2 when a launch fills half the chip)
+    int fuse_dual = 1;           // dual-GEMM downsample join
+    int fuse_ds = 1;             // stage-opening block at unchanged resolution in one launch
+    int fuse_opener = 1;         // stage-opening block with a stride-2 3x3 in one launch
+    int fuse_stem = 1;           // stem conv + max-pool in one launch
+    int fuse_ir = 1;             // MobileNet-V2 inverted residual (expand -> depthwise -> project) in one launch
+    int patch3x3 = 1;            // LDS-patch 3x3 kernel
+    int dual_wide = 2048;        // dual-GEMM joins with at least this many couts use the 128x128 tile
+    int deep_nk = 7;             // K loops of at least this many steps use the deepest DMA ring
+    int bk128 = 0;               // 128-byte K steps in conv_igemm_kernel
+    int dw_dot4 = 1;             // v_dot4 depthwise kernel
+    int stem_wpc = 2;            // resident stem workgroups per CU
+    int opener_stg = 1;          // stride-2 opener: int8 output staged through LDS into 128-byte lines
+    int chunk56 = -1, chunk28 = -1, chunk14 = -1;   // images per chunk of the fused blocks (-1: derived from chunk_budget_mb, 0: whole batch)
+    int chunk_budget_mb = 96;    // a chunk's int32 stream must fit this much memory-side cache (3/8 of the 256 MiB Infinity Cache)
+    int chunk_ds = 1, chunk_opener = 1;             // chunk the stage-opening blocks with their neighbours
+    int split_streams = 1;       // 0: same launches serialised on the caller's stream (profiling)
+    int graph = 0;               // hipGraph capture / replay of a run
+    int stagger = -1, stagger_pipelined = 2;
+    int check_device = 1;        // f8_net_run fails if the current device is not the one the handle was uploaded to
+};
+void options_from_env(Options* o);                       // f8_net.cpp
+int* option_slot(Options* o, const char* key);            // nullptr: unknown key
+
 // One requantised int8 output of an epilogue: int_op_only_fix_quant with n = src_fl - dst_fl.
 struct QuantOut {
     int8_t* ptr;      // NHWC int8, row stride ld (bytes); nullptr = absent
@@ -48,6 +77,7 @@ struct ConvArgs {
     const int32_t* bias2;                  // [coutP]
     int32_t sN2, sP2, sQ2, ktot2;          // input byte strides of x2 (per image / output row / output col), its K
     void* trace;                           // tuning builds (F8_TRACE) only; nullptr otherwise
+    int32_t deep_nk;                       // Options::deep_nk (ring depth rule of launch_conv_t)
 };
 
 // Depthwise 3x3 (groups == C), NHWC int8 in, VALU.
@@ -60,6 +90,7 @@ struct DwArgs {
     int32_t relu0;
     int32_t* out32;
     QuantOut q[2];
+    int32_t use_dot4;                      // Options::dw_dot4
 };
 
 struct PoolArgs {                          // max-pool, NHWC
@@ -111,6 +142,8 @@ struct FusedArgs {
     int32_t acc_shl, res_shl, relu1;       // residual join
     int32_t* out32; QuantOut q[2];
     void* trace;                           // tuning builds (F8_TRACE) only
+    int32_t stride2;                       // stage-opening block with a stride-2 3x3 (f8_opener.hip): H, W are the INPUT map
+    int32_t stg;                           // Options::opener_stg
 };
 
 // ResNet head in one launch: 7x7/2 conv + ReLU + requant (unsigned 8-bit) + 3x3/2 max-pool (f8_stem.hip).
@@ -123,19 +156,22 @@ struct StemPoolArgs {
     int32_t relu0;
     int32_t* out32;                        // pooled int32 (I32T, 64 channels) or nullptr
     QuantOut q[2];                         // pooled int8 NHWC (64 channels) in up to two formats
+    int32_t wpc;                           // Options::stem_wpc
 };
 
 struct ConvTile { int bm, bn, bk; };
 
 // Tile choice for a conv; returns false if no kernel instance fits (ck % bk).
-bool pick_conv_tile(int M, int coutP, int ck, bool has_res, ConvTile* t);
+bool pick_conv_tile(int M, int coutP, int ck, bool has_res, bool bk128, ConvTile* t);
 int  conv_grid(const ConvTile& t, int M, int coutP);
-int  conv_deep_nk();
 
 hipError_t launch_conv(const ConvArgs& a, const ConvTile& t, hipStream_t s);
 hipError_t launch_fused_bottleneck(const FusedArgs& a, hipStream_t s);
-bool fused_bottleneck_supported(int C, int MID, int H, int W, int imgs_per_launch, int* R);
+bool fused_bottleneck_supported(int C, int MID, int H, int W, int imgs_per_launch, int stage_mask, int* R);
 bool fused_ds_supported(int C, int MID, int COUT, int H, int W, int* R);
+// stage-opening block with a stride-2 3x3 (f8_opener.hip); H, W = input map
+bool fused_opener_supported(int C, int MID, int COUT, int H, int W, int* R);
+hipError_t launch_fused_opener(const FusedArgs& a, hipStream_t s);
 // 3x3 / stride 1 / pad 1 with the input patch resident in LDS (f8_conv3x3.hip); config = false: no instance
 bool conv3x3_patch_config(int cin, int H, int W, int coutP, int* R, int* IMGS, int* BN);
 hipError_t launch_conv3x3_patch(const ConvArgs& a, int cin, hipStream_t s);
@@ -148,7 +184,8 @@ hipError_t launch_add(const AddArgs& a, hipStream_t s);
 hipError_t launch_input(const InArgs& a, hipStream_t s);
 hipError_t launch_output(const OutArgs& a, hipStream_t s);
 hipError_t launch_quantize_input(const float* x, int32_t* y, size_t n, float scale, int lo, int hi, hipStream_t s);
-hipError_t launch_topk_correct(const float* logits, const int64_t* target, int N, int C, const int* ks_dev, int nk, float* correct, hipStream_t s);
+struct TopkKs { int k[8]; };                // the k list travels by value in the kernel arguments
+hipError_t launch_topk_correct(const float* logits, const int64_t* target, int N, int C, TopkKs ks, int nk, float* correct, hipStream_t s);
 hipError_t launch_requant_i32(const int32_t* src, int32_t* dst, size_t n, int sh, int lo, int hi, hipStream_t s);
 hipError_t launch_relu_i32(int32_t* x, size_t n, hipStream_t s);
 hipError_t launch_add_align_i32(int32_t* res, const int32_t* x, size_t n, int res_shl, int x_shl, hipStream_t s);

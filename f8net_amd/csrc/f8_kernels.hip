@@ -732,7 +732,7 @@ __global__ void __launch_bounds__(256) quantize_input_kernel(const float* x, int
 // ImageNet scoring of forward_loss (fix_train.py:697-704): correct[k][n] = 1 if target n is among the k largest logits.
 // Rank of the target = #{logit > logit[target]} + #{logit == logit[target], index < target} (ties by lower index, the
 // order a stable descending sort gives); one wave per image.
-__global__ void __launch_bounds__(256) topk_correct_kernel(const float* logits, const int64_t* target, int N, int C, const int* ks, int nk, float* correct) {
+__global__ void __launch_bounds__(256) topk_correct_kernel(const float* logits, const int64_t* target, int N, int C, const TopkKs ks, int nk, float* correct) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
@@ -747,7 +747,7 @@ __global__ void __launch_bounds__(256) topk_correct_kernel(const float* logits, 
     }
     for (int off = 32; off > 0; off >>= 1) rank += __shfl_down(rank, off, 64);
     if (lane == 0)
-        for (int k = 0; k < nk; ++k) correct[(size_t)k * N + n] = (valid && rank < ks[k]) ? 1.f : 0.f;
+        for (int k = 0; k < nk; ++k) correct[(size_t)k * N + n] = (valid && rank < ks.k[k]) ? 1.f : 0.f;
 }
 
 // Stem form only, W % 4 == 0: one thread = 4 consecutive pixels (3 dwordx4 plane reads, one dwordx4 write).
@@ -855,10 +855,9 @@ static inline int grid_for(size_t work, int block = 256, int cap = 256 * 8 * 4) 
     return (int)g;
 }
 
-bool pick_conv_tile(int M, int coutP, int ck, bool has_res, ConvTile* t) {
+bool pick_conv_tile(int M, int coutP, int ck, bool has_res, bool bk128, ConvTile* t) {
     if (ck % 32 != 0 || coutP % 32 != 0) return false;
     t->bk = (ck % 64 == 0) ? 64 : 32;
-    static const int bk128 = [] { const char* e = getenv("F8_BK128"); return e ? atoi(e) : 0; }();
     if (bk128 && ck % 128 == 0 && coutP > 32) t->bk = 128;
     t->bn = coutP >= 96 ? 128 : (coutP > 32 ? 64 : 32);
     t->bm = 128;
@@ -869,21 +868,13 @@ bool pick_conv_tile(int M, int coutP, int ck, bool has_res, ConvTile* t) {
     auto tiles = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((coutP + bn - 1) / bn); };
     if (tiles(t->bm, t->bn) < 512 && t->bn >= 64) t->bm = 64;
     if (tiles(t->bm, t->bn) < 512 && t->bn == 128) t->bn = 64;
-    // experiment hooks (tuning only)
-    if (const char* e = getenv(has_res ? "F8_RES_BN" : "F8_BN")) { const int v = atoi(e); if (v == 32 || v == 64 || v == 128) t->bn = v; }
-    if (const char* e = getenv(has_res ? "F8_RES_BM" : "F8_BM")) { const int v = atoi(e); if (v == 64 || v == 128) t->bm = v; }
     if (t->bm == 64 && t->bn == 32) t->bn = 64;
     return true;
 }
 
-// K loops of at least this many steps get the deepest ring that fits 64 KB of static LDS (else 2 slots).
-// Measured (ResNet-50, bs 128, A/B/A/B): threshold 16 -> 64.0-64.5 k, 7 -> 64.7-64.9 k, 5 -> 65.2 k img/s; 7 takes in the
+// K loops of at least ConvArgs::deep_nk (Options::deep_nk, default 7) steps get the deepest ring that fits 64 KB of static LDS (else 2
+// slots).  Measured (ResNet-50, bs 128, A/B/A/B): threshold 16 -> 64.0-64.5 k, 7 -> 64.7-64.9 k, 5 -> 65.2 k img/s; 7 takes in the
 // 7-step stem (80 -> 75 us) and the 9-step 3x3s without touching the 4-step residual-carrying 1x1s.
-int conv_deep_nk() {
-    static const int v = [] { const char* e = getenv("F8_DEEP_NK"); return e ? atoi(e) : 7; }();
-    return v;
-}
-
 int conv_grid(const ConvTile& t, int M, int coutP) {
     return ((M + t.bm - 1) / t.bm) * ((coutP + t.bn - 1) / t.bn);
 }
@@ -913,7 +904,7 @@ static hipError_t launch_conv_t(const ConvArgs& a, int grid, hipStream_t s) {
     const bool pad = a.pad > 0, res = a.res != nullptr;
     // long K loops (3x3 of the late stages: 36-72 steps of ~64-256 MFMA cycles against an ~800-cycle DMA round
     // trip) want a deeper ring; short ones want the smaller LDS footprint
-    const int deep_nk = conv_deep_nk();
+    const int deep_nk = a.deep_nk > 0 ? a.deep_nk : 7;
     constexpr int DST = (4 * TILE <= 65536) ? 4 : ((3 * TILE <= 65536) ? 3 : 2);
     const bool deep = (DST > ST) && ((a.ktot + a.ktot2) / BK >= deep_nk);
     if (a.x2) {   // dual GEMM (downsample join): 1x1 / no padding; 64-wide cout tiles, or 128x128 for the wide late stages
@@ -990,8 +981,7 @@ hipError_t launch_conv(const ConvArgs& a0, const ConvTile& t, hipStream_t s) {
 
 hipError_t launch_dwconv(const DwArgs& a, hipStream_t s) {
     // dot4 kernel: int8 outputs only, stride 1 / 2, pad 1, channel stride a multiple of 16 (always: Cs % 32 == 0)
-    static const int use_dot4 = [] { const char* e = getenv("F8_DW_DOT4"); return e ? atoi(e) : 1; }();
-    if (use_dot4 && !a.out32 && a.w4 && a.pad == 1 && (a.stride == 1 || a.stride == 2)) {
+    if (a.use_dot4 && !a.out32 && a.w4 && a.pad == 1 && (a.stride == 1 || a.stride == 2)) {
         const size_t work = (size_t)a.N * a.P * ((a.Q + 1) / 2) * (a.Cs >> 4);
         const unsigned grid = (unsigned)((work + 255) / 256);
         DwArgs b = a; b.w = a.w4; b.bias = a.bias4;
@@ -1034,8 +1024,8 @@ hipError_t launch_quantize_input(const float* x, int32_t* y, size_t n, float sca
     hipLaunchKernelGGL(quantize_input_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, n, scale, lo, hi);
     return hipGetLastError();
 }
-hipError_t launch_topk_correct(const float* logits, const int64_t* target, int N, int C, const int* ks_dev, int nk, float* correct, hipStream_t s) {
-    hipLaunchKernelGGL(topk_correct_kernel, dim3((N + 3) / 4), dim3(256), 0, s, logits, target, N, C, ks_dev, nk, correct);
+hipError_t launch_topk_correct(const float* logits, const int64_t* target, int N, int C, TopkKs ks, int nk, float* correct, hipStream_t s) {
+    hipLaunchKernelGGL(topk_correct_kernel, dim3((N + 3) / 4), dim3(256), 0, s, logits, target, N, C, ks, nk, correct);
     return hipGetLastError();
 }
 hipError_t launch_output(const OutArgs& a, hipStream_t s) {

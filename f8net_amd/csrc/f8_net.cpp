@@ -79,6 +79,7 @@ struct Node {
     int fb_a = -1, fb_b = -1, fb_R = 0;  // last conv of a fused bottleneck: its first two convs, rows per tile
     int sp_pool = -1, sp_conv = -1;      // stem conv <-> max-pool fused into one launch (f8_stem.hip)
     int fbd_a = -1, fbd_b = -1;          // shortcut conv hosting a fused stage-opening block (DS): body.0 / body.2 (body.4 = `dual`)
+    bool fbd_s2 = false;                 // ... whose 3x3 and shortcut have stride 2 (f8_opener.hip)
     int dual = -1;                     // 1x1 conv hosting a join whose other operand is ANOTHER 1x1 conv (node id): one dual-GEMM launch
     int dual_host = -1;                // ... and that other conv: the node that carries it
     int p3_R = 0, p3_imgs = 0, p3_bn = 0;   // 3x3 conv on the LDS-patch kernel (p3_R > 0): rows / images per tile, cout tile
@@ -109,6 +110,10 @@ struct f8_net {
     int out_t = -1, out_float = 0;
     bool finalized = false;
     int max_batch = 0;
+    Options opt;                       // per-handle tuning (f8_net_set_option); seeded from the environment at create
+    int device = -1;                   // HIP device the arena / weights live on (set by f8_net_upload)
+    int n_copies = 0;                  // arena copies allocated at upload (= opt.split then)
+    hipEvent_t input_ready = nullptr;  // one-shot: the next run's first launch also waits for it (f8_net_set_input_ready)
     std::vector<Step> steps;
     std::vector<uint8_t> wblob;
     size_t arena_bytes = 0;
@@ -176,6 +181,8 @@ void make_magic(uint32_t d, uint32_t* magic, int32_t* sh1, int32_t* sh2) {
     *sh2 = l > 1 ? l - 1 : 0;
 }
 
+int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
 void set_q(QuantOut& q, char* ptr, const Form& f) {
     q.ptr = (int8_t*)ptr; q.n = f.n;
     q.lo = f.sgn ? -127 : 0; q.hi = f.sgn ? 127 : 255;
@@ -183,6 +190,50 @@ void set_q(QuantOut& q, char* ptr, const Form& f) {
 }
 
 }  // namespace
+
+namespace f8 {
+struct OptKey { const char* key; const char* env; int Options::*slot; int lo, hi; bool planning; };
+static const OptKey kOptKeys[] = {
+    {"split", "F8_SPLIT", &Options::split, 1, 4, true},
+    {"fuse_blocks", "F8_FUSE_BLOCKS", &Options::fuse_blocks, 0, 1, true},
+    {"fuse_stages", "F8_FUSE_STAGES", &Options::fuse_stages, -1, 7, true},
+    {"fuse_dual", "F8_FUSE_DUAL", &Options::fuse_dual, 0, 1, true},
+    {"fuse_ds", "F8_FUSE_DS", &Options::fuse_ds, 0, 1, true},
+    {"fuse_opener", "F8_FUSE_OPENER", &Options::fuse_opener, 0, 1, true},
+    {"fuse_stem", "F8_FUSE_STEM", &Options::fuse_stem, 0, 1, true},
+    {"fuse_ir", "F8_FUSE_IR", &Options::fuse_ir, 0, 1, true},
+    {"patch3x3", "F8_PATCH3X3", &Options::patch3x3, 0, 1, true},
+    {"dual_wide", "F8_DUAL_WIDE", &Options::dual_wide, 0, 1 << 30, true},
+    {"deep_nk", "F8_DEEP_NK", &Options::deep_nk, 1, 1 << 20, true},
+    {"bk128", "F8_BK128", &Options::bk128, 0, 1, true},
+    {"dw_dot4", "F8_DW_DOT4", &Options::dw_dot4, 0, 1, true},
+    {"stem_wpc", "F8_STEM_WPC", &Options::stem_wpc, 1, 8, false},
+    {"opener_stg", "F8_OPENER_STG", &Options::opener_stg, 0, 1, true},
+    {"chunk56", "F8_CHUNK", &Options::chunk56, -1, 1 << 20, false},
+    {"chunk28", "F8_CHUNK28", &Options::chunk28, -1, 1 << 20, false},
+    {"chunk14", "F8_CHUNK14", &Options::chunk14, -1, 1 << 20, false},
+    {"chunk_budget_mb", "F8_CHUNK_BUDGET_MB", &Options::chunk_budget_mb, 1, 1 << 20, false},
+    {"chunk_ds", "F8_CHUNK_DS", &Options::chunk_ds, 0, 1, false},
+    {"chunk_opener", "F8_CHUNK_OPENER", &Options::chunk_opener, 0, 1, false},
+    {"split_streams", "F8_SPLIT_STREAMS", &Options::split_streams, 0, 1, false},
+    {"graph", "F8_GRAPH", &Options::graph, 0, 1, false},
+    {"stagger", "F8_STAGGER", &Options::stagger, -1, 1 << 20, false},
+    {"stagger_pipelined", "F8_STAGGER_PIPELINED", &Options::stagger_pipelined, 0, 1 << 20, false},
+    {"check_device", "F8_CHECK_DEVICE", &Options::check_device, 0, 1, false},
+};
+static const OptKey* find_opt(const char* key) {
+    if (!key) return nullptr;
+    for (const auto& k : kOptKeys) if (!strcmp(k.key, key)) return &k;
+    return nullptr;
+}
+void options_from_env(Options* o) {
+    for (const auto& k : kOptKeys) {
+        const int v = env_int(k.env, o->*(k.slot));
+        o->*(k.slot) = v < k.lo ? k.lo : (v > k.hi ? k.hi : v);
+    }
+}
+int* option_slot(Options* o, const char* key) { const OptKey* k = find_opt(key); return k ? &(o->*(k->slot)) : nullptr; }
+}  // namespace f8
 
 extern "C" {
 
@@ -230,12 +281,10 @@ int f8_topk_correct_f32(const float* logits, const int64_t* target, int N, int c
     for (int k = 0; k < nk; ++k) if (ks[k] < 1 || ks[k] > classes) return fail(F8_ERR_INVALID, "f8_topk_correct_f32: k=%d outside [1,%d]", ks[k], classes);
     if (N == 0) return F8_OK;
     if (!logits || !target || !correct) return fail(F8_ERR_INVALID, "f8_topk_correct_f32: null pointer");
-    // the k list is tiny and call-specific: it travels through a per-thread device scratch (8 ints)
-    static thread_local int* ks_dev = nullptr;
-    hipError_t e = hipSuccess;
-    if (!ks_dev && (e = hipMalloc((void**)&ks_dev, 8 * sizeof(int))) != hipSuccess) return hip_fail(e, "f8_topk_correct_f32: hipMalloc");
-    if ((e = hipMemcpyAsync(ks_dev, ks, nk * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream)) != hipSuccess) return hip_fail(e, "f8_topk_correct_f32: copy");
-    e = launch_topk_correct(logits, target, N, classes, ks_dev, nk, correct, (hipStream_t)stream);
+    // the k list is tiny and call-specific: it travels by value in the kernel arguments (no device scratch, no copy)
+    TopkKs kv{};
+    for (int k = 0; k < nk; ++k) kv.k[k] = ks[k];
+    const hipError_t e = launch_topk_correct(logits, target, N, classes, kv, nk, correct, (hipStream_t)stream);
     return e == hipSuccess ? F8_OK : hip_fail(e, "f8_topk_correct_f32");
 }
 int f8_relu_i32(int32_t* x, size_t n, void* stream) {
@@ -255,7 +304,33 @@ int f8_add_align_i32(int32_t* res, const int32_t* x, size_t n, int res_fl, int x
 }
 
 // ------------------------------------------------------------------------------ builder
-f8_net* f8_net_create(void) { return new (std::nothrow) f8_net(); }
+f8_net* f8_net_create(void) {
+    f8_net* net = new (std::nothrow) f8_net();
+    if (net) options_from_env(&net->opt);
+    return net;
+}
+
+int f8_net_set_option(f8_net* net, const char* key, int value) {
+    if (!net) return fail(F8_ERR_INVALID, "f8_net_set_option: null net");
+    const OptKey* k = find_opt(key);
+    if (!k) return fail(F8_ERR_INVALID, "f8_net_set_option: unknown key '%s'", key ? key : "(null)");
+    if (value < k->lo || value > k->hi) return fail(F8_ERR_INVALID, "f8_net_set_option: %s = %d outside [%d,%d]", key, value, k->lo, k->hi);
+    if (k->planning && net->finalized) return fail(F8_ERR_STATE, "f8_net_set_option: '%s' decides the plan; set it before f8_net_finalize", key);
+    net->opt.*(k->slot) = value;
+    return F8_OK;
+}
+int f8_net_get_option(const f8_net* net, const char* key, int* value) {
+    if (!net || !value) return fail(F8_ERR_INVALID, "f8_net_get_option: null argument");
+    const OptKey* k = find_opt(key);
+    if (!k) return fail(F8_ERR_INVALID, "f8_net_get_option: unknown key '%s'", key ? key : "(null)");
+    *value = net->opt.*(k->slot);
+    return F8_OK;
+}
+int f8_net_set_input_ready(f8_net* net, void* event) {
+    if (!net) return fail(F8_ERR_INVALID, "f8_net_set_input_ready: null net");
+    net->input_ready = (hipEvent_t)event;
+    return F8_OK;
+}
 
 void f8_net_destroy(f8_net* net) {
     if (!net) return;
@@ -571,7 +646,7 @@ static void label_conv_step(f8_net* net, Step& st, const Node& nd) {
         const int tile_b = (nd.tile.bm + nd.tile.bn) * nd.tile.bk;
         const int dst = (4 * tile_b <= 65536) ? 4 : ((3 * tile_b <= 65536) ? 3 : 2);
         const int ksteps = (nd.ktot + (nd.dual >= 0 ? ND[nd.dual].ktot : 0)) / nd.tile.bk;
-        const int stages = (dst > 2 && ksteps >= conv_deep_nk()) ? dst : 2;     // ring depth rule of launch_conv_t
+        const int stages = (dst > 2 && ksteps >= net->opt.deep_nk) ? dst : 2;    // ring depth rule of launch_conv_t
         snprintf(buf, sizeof buf, "f8::conv_igemm_kernel<%d, %d, %d, %d, %d, %s, %s, %d, %s>", nd.tile.bm, nd.tile.bn, nd.tile.bk, wpx, wco,
                  (d.pad > 0 && !nd.stem) ? "true" : "false", (st.res_t >= 0 || nd.dual >= 0) ? "true" : "false", stages,
                  nd.dual >= 0 ? "true" : "false");
@@ -607,7 +682,8 @@ int f8_net_finalize(f8_net* net, int max_batch) {
 
     // ---- 1b. whole-block fusion: 1x1(ReLU) -> 3x3 pad 1 (ReLU) -> 1x1 + residual with the block input,
     //          all stride 1, intermediates read by nobody else  ->  one launch (f8_fused.hip)
-    static const int fuse_blocks = [] { const char* e = getenv("F8_FUSE_BLOCKS"); return e ? atoi(e) : 1; }();
+    const Options& opt = net->opt;
+    const int fuse_blocks = opt.fuse_blocks;
     for (int i = 0; fuse_blocks && i < nn; ++i) {
         Node& c = ND[i];
         if (c.kind != N_CONV || c.fused_add < 0 || c.cd.groups != 1 || c.cd.kernel != 1 || c.cd.stride != 1 || c.cd.pad != 0 || c.cd.relu) continue;
@@ -626,15 +702,14 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         const int C = a0.cd.cin, MID = a0.cd.cout;
         if (c.cd.cout != C || b.cd.cin != MID || b.cd.cout != MID || c.cd.cin != MID) continue;
         int R = 0;
-        static const int split_env = [] { const char* e = getenv("F8_SPLIT"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
-        if (!fused_bottleneck_supported(C, MID, x.H, x.W, std::max(1, max_batch / split_env), &R)) continue;
+        if (!fused_bottleneck_supported(C, MID, x.H, x.W, std::max(1, max_batch / opt.split), opt.fuse_stages, &R)) continue;
         a0.absorbed_by = i; b.absorbed_by = i; b.no_classes = true;
         c.fb_a = ta.prod; c.fb_b = tb.prod; c.fb_R = R;
     }
 
     // ---- 1c. downsample join: the add's two operands are both 1x1 / pad 0 convs (body.4 and the shortcut) and the
     //          earlier one feeds nothing else  ->  one dual-GEMM launch, its int32 result never touches HBM
-    static const int fuse_dual = [] { const char* e = getenv("F8_FUSE_DUAL"); return e ? atoi(e) : 1; }();
+    const int fuse_dual = opt.fuse_dual;
     for (int i = 0; fuse_dual && i < nn; ++i) {
         Node& h = ND[i];
         if (h.kind != N_CONV || h.fused_add < 0 || h.fb_a >= 0 || h.cd.groups != 1 || h.cd.kernel != 1 || h.cd.pad != 0) continue;
@@ -652,19 +727,20 @@ int f8_net_finalize(f8_net* net, int max_batch) {
     // ---- 1d. stage-opening bottleneck at unchanged resolution: body.0 -> body.2 -> [body.4 + shortcut] in ONE launch
     for (int i = 0; fuse_blocks && i < nn; ++i) {
         Node& h = ND[i];
-        if (h.kind != N_CONV || h.dual < 0 || h.cd.stride != 1 || h.cd.relu || !h.cd.quant_input) continue;
+        if (h.kind != N_CONV || h.dual < 0 || (h.cd.stride != 1 && h.cd.stride != 2) || h.cd.relu || !h.cd.quant_input) continue;
+        const int bs = h.cd.stride;                            // stride of the shortcut = stride of the block's 3x3
         Node& g = ND[h.dual];
         if (g.cd.stride != 1 || !g.cd.quant_input) continue;
         const Tensor& tb = T[g.a];
         if (tb.consumers.size() != 1 || g.a == net->out_t) continue;
         Node& b = ND[tb.prod];
-        if (b.kind != N_CONV || b.fused_add >= 0 || b.absorbed_by >= 0 || b.cd.groups != 1 || b.cd.kernel != 3 || b.cd.stride != 1 || b.cd.pad != 1 ||
+        if (b.kind != N_CONV || b.fused_add >= 0 || b.absorbed_by >= 0 || b.cd.groups != 1 || b.cd.kernel != 3 || b.cd.stride != bs || b.cd.pad != 1 ||
             !b.cd.quant_input) continue;
         const Tensor& ta = T[b.a];
         if (ta.consumers.size() != 1 || b.a == net->out_t) continue;
         Node& a0 = ND[ta.prod];
         if (a0.kind != N_CONV || a0.fused_add >= 0 || a0.absorbed_by >= 0 || a0.cd.groups != 1 || a0.cd.kernel != 1 || a0.cd.stride != 1 ||
-            a0.cd.pad != 0 || !a0.cd.quant_input || a0.a != h.a) continue;
+            a0.cd.pad != 0 || !a0.cd.quant_input || a0.a != h.a || a0.dual_host >= 0 || a0.dual >= 0) continue;
         const Tensor& x = T[h.a];
         int na = 0, nh = 0;
         if (consumer_format(x, a0.cd, &na, "finalize") || consumer_format(x, h.cd, &nh, "finalize")) continue;
@@ -672,9 +748,10 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         const int C = a0.cd.cin, MID = a0.cd.cout;
         if (b.cd.cin != MID || b.cd.cout != MID || g.cd.cin != MID || g.cd.cout != h.cd.cout || h.cd.cin != C) continue;
         int R = 0;
-        if (!fused_ds_supported(C, MID, h.cd.cout, x.H, x.W, &R)) continue;
+        if (bs == 1 ? !(opt.fuse_ds && fused_ds_supported(C, MID, h.cd.cout, x.H, x.W, &R))
+                    : !(opt.fuse_opener && fused_opener_supported(C, MID, h.cd.cout, x.H, x.W, &R))) continue;
         a0.absorbed_by = i; b.absorbed_by = i; b.no_classes = true;
-        h.fbd_a = ta.prod; h.fbd_b = tb.prod; h.fb_R = R;
+        h.fbd_a = ta.prod; h.fbd_b = tb.prod; h.fb_R = R; h.fbd_s2 = bs == 2;
     }
 
     // ---- 2. which forms does each tensor need?  (reverse order: consumers before producers)
@@ -733,7 +810,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     // ResNet head: 7x7/2 stem conv + this pool in one launch (the conv output never leaves LDS)
                     Node& c = ND[T[nd.a].prod];
                     if (c.kind == N_CONV && c.cd.groups == 1 && c.fused_add < 0 && ND[T[c.a].prod].kind == N_INPUT && T[c.a].consumers.size() == 1 &&
-                        c.a != net->out_t && (!c.cd.quant_input || T[c.a].fl == c.cd.input_fl) &&
+                        c.a != net->out_t && (!c.cd.quant_input || T[c.a].fl == c.cd.input_fl) && opt.fuse_stem &&
                         stem_pool_supported(c.cd.cin, c.cd.cout, c.cd.kernel, c.cd.stride, c.cd.pad, nd.pk, nd.pstride, nd.ppad, o.H, o.W)) {
                         c.sp_pool = i; nd.sp_conv = T[nd.a].prod;
                         break;                                   // no HBM form of the conv output
@@ -835,19 +912,21 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     out_t = ad.out;
                     select_outputs(net, out_t, &st.out, &extra);
                     Tensor& o = T[out_t];
-                    const double px = (double)x.H * x.W;
-                    st.ops_per_img = 2.0 * px * ((double)na.cd.cin * na.cd.cout + 9.0 * nb.cd.cin * nb.cd.cout + (double)ng.cd.cin * ng.cd.cout +
-                                                 (double)nd.cd.cin * nd.cd.cout);
+                    const double px = (double)x.H * x.W, pxo = (double)o.H * o.W;   // stride-2 opener: body.0 runs on the input map
+                    st.ops_per_img = 2.0 * (px * (double)na.cd.cin * na.cd.cout + pxo * (9.0 * nb.cd.cin * nb.cd.cout + (double)ng.cd.cin * ng.cd.cout +
+                                                                                         (double)nd.cd.cin * nd.cd.cout));
                     double b = px * x.Cs;                                           // int8 input once
-                    if (st.out.f32 >= 0) b += px * o.Cs * 4;
-                    for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += px * o.Cs;
+                    if (st.out.f32 >= 0) b += pxo * o.Cs * 4;
+                    for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += pxo * o.Cs;
                     st.bytes_per_img = b;
                     st.bytes_const = (double)na.coutP * (na.ktot + 4) + (double)nb.coutP * (nb.ktot + 4) + (double)ng.coutP * (ng.ktot + 4) +
                                      (double)nd.coutP * (nd.ktot + 4);
-                    st.name = "fused_bottleneck_ds_R" + std::to_string(nd.fb_R) + ":" + tname(net, na.out) + "+" + tname(net, nb.out) + "+" + tname(net, ng.out) + "+" +
-                              tname(net, nd.out);
+                    st.name = std::string(nd.fbd_s2 ? "fused_opener_s2_R" : "fused_bottleneck_ds_R") + std::to_string(nd.fb_R) + ":" + tname(net, na.out) + "+" +
+                              tname(net, nb.out) + "+" + tname(net, ng.out) + "+" + tname(net, nd.out);
                     char kb[160];
-                    snprintf(kb, sizeof kb, "f8::fused_bottleneck_kernel<%d, %d, %d, %d, %d, true>", na.cd.cin, na.cd.cout, x.W, nd.fb_R, nd.cd.cout);
+                    if (nd.fbd_s2) snprintf(kb, sizeof kb, "f8::fused_opener_kernel<%d, %d, %d, %d, %d, %s>", na.cd.cin, na.cd.cout, x.W, nd.fb_R, nd.cd.cout,
+                                            (opt.opener_stg && st.out.f8[0] >= 0) ? "true" : "false");
+                    else snprintf(kb, sizeof kb, "f8::fused_bottleneck_kernel<%d, %d, %d, %d, %d, true>", na.cd.cin, na.cd.cout, x.W, nd.fb_R, nd.cd.cout);
                     st.kernel = kb;
                     break;
                 }
@@ -893,14 +972,14 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 else {
                     pack_conv_weights(net, nd, s, T[nd.out]);
                     const int M1 = T[nd.out].H * T[nd.out].W;
-                    if (!pick_conv_tile(M1 * max_batch, nd.coutP, nd.ck, nd.fused_add >= 0, &nd.tile))
+                    if (!pick_conv_tile(M1 * max_batch, nd.coutP, nd.ck, nd.fused_add >= 0, opt.bk128 != 0, &nd.tile))
                         return fail(F8_ERR_UNSUPPORTED, "finalize: no conv kernel instance for ck=%d coutP=%d", nd.ck, nd.coutP);
                     if (nd.dual >= 0) {       // the dual-GEMM instances: 128x64 / 64x64, or 128x128 where many cout tiles re-read X
-                        static const int wide = [] { const char* e = getenv("F8_DUAL_WIDE"); return e ? atoi(e) : 2048; }();   // measured: 7x7x2048 join 67 -> 52 us; 14x14x1024 and 28x28x512 are slower with the wide tile
+                        const int wide = opt.dual_wide;   // measured: 7x7x2048 join 67 -> 52 us; 14x14x1024 and 28x28x512 are slower with the wide tile
                         nd.tile.bk = 64;
                         if (nd.coutP >= wide && nd.tile.bm == 128) nd.tile.bn = 128; else nd.tile.bn = 64;
                     }
-                    if (!nd.stem && nd.cd.groups == 1 && nd.cd.kernel == 3 && nd.cd.stride == 1 && nd.cd.pad == 1 && nd.ck == nd.cd.cin &&
+                    if (!nd.stem && nd.cd.groups == 1 && nd.cd.kernel == 3 && nd.cd.stride == 1 && nd.cd.pad == 1 && nd.ck == nd.cd.cin && opt.patch3x3 &&
                         !conv3x3_patch_config(nd.cd.cin, s.H, s.W, nd.coutP, &nd.p3_R, &nd.p3_imgs, &nd.p3_bn)) nd.p3_R = 0;
                 }
                 if (nd.fused_add >= 0) {
@@ -1050,29 +1129,54 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 net->stem_zero_off = F.off; net->stem_zero_bytes = F.bytes_per_img * max_batch;
                 net->stem_zero_val = F.sgn ? 0 : 0x80;
             }
-    for (size_t si = 0; si < net->steps.size(); ++si) {
-        Step& st = net->steps[si];
-        // forms born at this step
-        for (size_t ti = 0; ti < T.size(); ++ti)
-            for (size_t f = 0; f < T[ti].forms.size(); ++f) {
-                Form& F = T[ti].forms[f];
-                if (F.kind == FORM_STEM || F.first != (int)si) continue;
-                // in-place residual: out32 of a conv/add step may overwrite a residual operand that dies here
-                // (each thread reads its element before writing it; same NHWC geometry)
-                if (F.kind == FORM_I32 && (int)ti == st.out.t && (int)f == st.out.f32 && st.res_t >= 0 &&
-                    (st.kind == S_CONV || st.kind == S_ADD || st.kind == S_FUSED)) {
-                    Form& R = T[st.res_t].forms[st.res_f];
-                    if (R.last == (int)si && R.bytes_per_img == F.bytes_per_img && R.kind == FORM_I32) {
-                        F.off = R.off; R.last = -2;   // ownership moves to F
-                        continue;
+    // Chunked execution (for_each_launch) interleaves the steps of a chunk group: chunk c runs steps i..j-1 before chunk c+1
+    // does.  A form that dies inside the group is therefore still needed by later chunks while forms born later in the group
+    // are already being written by earlier chunks: for the allocator the whole group is ONE step (forms born in it live from
+    // its first step, forms dying in it until its last).  Groups are taken as large as any option setting can make them.
+    const int ns_all = (int)net->steps.size();
+    std::vector<int> gstart(ns_all), gend(ns_all);
+    {
+        auto chunkable_w = [&](int k) -> int {
+            const Step& st = net->steps[k];
+            if (st.kind != S_FUSED) return 0;
+            const Tensor& x = T[st.src_t];
+            return (x.W == x.H && (x.W == 56 || x.W == 28 || x.W == 14)) ? x.W : 0;
+        };
+        for (int i = 0; i < ns_all;) {
+            int j = i + 1;
+            const int w = chunkable_w(i);
+            if (w) while (j < ns_all && chunkable_w(j) == w) ++j;
+            for (int k = i; k < j; ++k) { gstart[k] = i; gend[k] = j - 1; }
+            i = j;
+        }
+    }
+    for (int si = 0; si < ns_all; ++si) {
+        // forms born at this (super) step, in the order of their producing steps
+        if (gstart[si] == si)
+            for (int sj = si; sj <= gend[si]; ++sj) {
+                Step& st = net->steps[sj];
+                for (size_t ti = 0; ti < T.size(); ++ti)
+                    for (size_t f = 0; f < T[ti].forms.size(); ++f) {
+                        Form& F = T[ti].forms[f];
+                        if (F.kind == FORM_STEM || F.first != sj) continue;
+                        // in-place residual: out32 of a conv/add step may overwrite a residual operand that dies here
+                        // (each thread reads its element before writing it; same geometry, so it also holds per chunk)
+                        if (F.kind == FORM_I32 && (int)ti == st.out.t && (int)f == st.out.f32 && st.res_t >= 0 &&
+                            (st.kind == S_CONV || st.kind == S_ADD || st.kind == S_FUSED)) {
+                            Form& R = T[st.res_t].forms[st.res_f];
+                            if (R.last == sj && R.bytes_per_img == F.bytes_per_img && R.kind == FORM_I32) {
+                                F.off = R.off; R.last = -2;   // ownership moves to F
+                                continue;
+                            }
+                        }
+                        F.off = alloc(F.bytes_per_img * max_batch + F.slack);
                     }
-                }
-                F.off = alloc(F.bytes_per_img * max_batch + F.slack);
             }
-        // forms dying at this step
-        for (size_t ti = 0; ti < T.size(); ++ti)
-            for (auto& F : T[ti].forms)
-                if (F.kind != FORM_STEM && F.last == (int)si && F.first >= 0) release(F.off, F.bytes_per_img * max_batch + F.slack);
+        // forms dying at this (super) step
+        if (gend[si] == si)
+            for (size_t ti = 0; ti < T.size(); ++ti)
+                for (auto& F : T[ti].forms)
+                    if (F.kind != FORM_STEM && F.first >= 0 && F.last >= gstart[si] && F.last <= si) release(F.off, F.bytes_per_img * max_batch + F.slack);
     }
     net->arena_bytes = top;
     for (auto& t : T)
@@ -1134,7 +1238,9 @@ int f8_net_upload(f8_net* net) {
     if (!net || !net->finalized) return fail(F8_ERR_STATE, "f8_net_upload: not finalized");
     if (net->uploaded) return F8_OK;
     hipError_t e;
-    static const int parts_cap = [] { const char* e = getenv("F8_SPLIT"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+    const int parts_cap = net->opt.split;
+    if ((e = hipGetDevice(&net->device)) != hipSuccess) return hip_fail(e, "hipGetDevice");
+    net->n_copies = parts_cap;
     net->arena_stride = round_up_z(std::max<size_t>(net->arena_bytes, 256), 4096);
     if ((e = hipMalloc((void**)&net->d_arena, net->arena_stride * parts_cap)) != hipSuccess) return hip_fail(e, "hipMalloc(arena)");
     if ((e = hipMalloc((void**)&net->d_w, std::max<size_t>(net->wblob.size(), 256))) != hipSuccess) return hip_fail(e, "hipMalloc(weights)");
@@ -1201,7 +1307,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
                 a.origin = -(d.pad * sT.W + d.pad) * sT.Cs; a.H = sT.H; a.W = sT.W; a.pad = d.pad; a.kw = d.kernel;
                 a.tapH = sT.W * sT.Cs; a.tapW = sT.Cs;
             }
-            a.relu0 = st.relu0;
+            a.relu0 = st.relu0; a.deep_nk = net->opt.deep_nk;
             if (st.res_t >= 0) { a.res = (const int32_t*)fp(T[st.res_t].forms[st.res_f]); a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1; }
             if (nd.dual >= 0) {
                 const Node& g = net->nodes[nd.dual];
@@ -1226,7 +1332,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             a.bias = (const int32_t*)(net->d_w + nd.b_off);
             a.N = N; a.Hp = sF.Hp; a.Wp = sF.Wp; a.org = sF.pad - nd.cd.pad;
             a.Pc = cT.H; a.Qc = cT.W; a.P = oT.H; a.Q = oT.W;
-            a.relu0 = st.relu0;
+            a.relu0 = st.relu0; a.wpc = net->opt.stem_wpc;
             fill_out(&a.out32, a.q);
             e = launch_stem_pool(a, s);
             break;
@@ -1244,7 +1350,8 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
                 a.b0 = (const int32_t*)(net->d_w + na.b_off); a.b2 = (const int32_t*)(net->d_w + nb.b_off);
                 a.b4 = (const int32_t*)(net->d_w + ng.b_off); a.bsc = (const int32_t*)(net->d_w + nd.b_off);
                 a.N = N; a.H = x.H; a.W = x.W; a.C = na.cd.cin; a.MID = na.cd.cout; a.COUT = nd.cd.cout; a.R = nd.fb_R;
-                a.tiles_per_img = (x.H + nd.fb_R - 1) / nd.fb_R;
+                a.tiles_per_img = nd.fbd_s2 ? (x.H / 2) / nd.fb_R : (x.H + nd.fb_R - 1) / nd.fb_R;
+                a.stride2 = nd.fbd_s2 ? 1 : 0; a.stg = net->opt.opener_stg;
                 auto fmt = [&](const Node& cons, const Tensor& src, int32_t* n, int32_t* lo, int32_t* hi, uint32_t* x_or) {
                     int nn = 0; consumer_format(src, cons.cd, &nn, "run");
                     *n = nn; *lo = cons.cd.input_signed ? -127 : 0; *hi = cons.cd.input_signed ? 127 : 255;
@@ -1255,7 +1362,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
                 a.relu_a = na.cd.relu; a.relu_b = nb.cd.relu;
                 a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1;
                 fill_out(&a.out32, a.q);
-                e = launch_fused_bottleneck(a, s);
+                e = nd.fbd_s2 ? launch_fused_opener(a, s) : launch_fused_bottleneck(a, s);
                 break;
             }
             const Node& na = net->nodes[nd.fb_a]; const Node& nb = net->nodes[nd.fb_b];
@@ -1289,7 +1396,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             a.x = (const int8_t*)fp(sF); a.w = (const int8_t*)(net->d_w + nd.w_off); a.bias = (const int32_t*)(net->d_w + nd.b_off);
             a.w4 = (const int8_t*)(net->d_w + nd.rc_off); a.bias4 = (const int32_t*)(net->d_w + nd.cc_off);
             a.N = N; a.H = sT.H; a.W = sT.W; a.P = oT.H; a.Q = oT.W; a.Cs = sT.Cs; a.stride = nd.cd.stride; a.pad = nd.cd.pad;
-            a.in_signed = nd.cd.input_signed; a.relu0 = st.relu0;
+            a.in_signed = nd.cd.input_signed; a.relu0 = st.relu0; a.use_dot4 = net->opt.dw_dot4;
             fill_out(&a.out32, a.q);
             e = launch_dwconv(a, s);
             break;
@@ -1389,11 +1496,10 @@ int f8_net_autotune(f8_net* net, int N, void* stream) {
 // Cuts the batch into up to F8_SPLIT (default 2, max 4) sub-batches; every I32T form needs each cut at a
 // multiple of 32 pixels.  Returns the number of parts and their starts in cut[0..parts].
 static int split_batch(const f8_net* net, int N, int cut[5]) {
-    static const int want = [] { const char* e = getenv("F8_SPLIT"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+    const int want = std::min(net->opt.split, net->n_copies > 0 ? net->n_copies : net->opt.split);   // never more parts than arena copies
     cut[0] = 0; cut[1] = N;
     if (want < 2 || N < 2) return 1;
     const int gran = 1;
-    (void)net;
     int parts = want;
     while (parts > 1 && (N / parts) / gran * gran == 0) --parts;
     if (parts < 2) return 1;
@@ -1410,32 +1516,48 @@ static int split_batch(const f8_net* net, int N, int cut[5]) {
 // then 28x28 chunks of 32 / 48 / 64 / 80 / 96 = +1.7 / +2.5 / +2.9 / +2.8 / +1.1 %; the 14x14 tensors (103 MB per batch) need
 // none.  Applies in every schedule (a sub-batch of 64 images still runs its 56x56 blocks in chunks: non-pipelined run
 // 73.4k -> 75.1k img/s).
-static int chunk_images(int W) {                         // images per chunk for a fused block on W x W maps (0 = whole batch)
-    static const int c56 = [] { const char* e = getenv("F8_CHUNK"); return e ? atoi(e) : 24; }();
-    static const int c28 = [] { const char* e = getenv("F8_CHUNK28"); return e ? atoi(e) : 64; }();
-    static const int c14 = [] { const char* e = getenv("F8_CHUNK14"); return e ? atoi(e) : 128; }();   // only batches > 128 chunk here
-    // 28 x 28 = 784 pixels: even image offsets are I32T-block aligned; 14 x 14 = 196 pixels: multiples of 8
-    return W == 56 ? c56 : (W == 28 ? c28 / 2 * 2 : (W == 14 ? c14 / 8 * 8 : 0));
-}
-static int step_chunk(const f8_net* net, int i) {
+// Defaults are DERIVED: the int32 stream of a chunk (bytes per image of the wider of the block's int32-sized input and
+// output maps: 3.2 MB at 56x56x256, 1.6 MB at 28x28x512, 0.8 MB at 14x14x1024) has to fit Options::chunk_budget_mb
+// (96 MiB = 3/8 of the 256 MiB memory-side cache: 24 / 56 / 96 images); chunk56 / chunk28 / chunk14 override (0 = whole
+// batch).  Every chunk offset must keep the I32T blocks of the group's tensors aligned (chunk * H*W a multiple of 32 pixels,
+// for the source map AND a stage-opening block's half-resolution output): chunks are multiples of 2 / 8 / 32 images.
+static int chunk_gran(int W) { return W == 56 ? 2 : (W == 28 ? 8 : 32); }
+static int step_chunk(const f8_net* net, int i) {        // nominal images per chunk of step i (0 = not chunked)
     const Step& st = net->steps[i];
     if (st.kind != S_FUSED) return 0;                    // (chunking the stage-opening convs as well: -3 %, more launches than locality)
-    static const int chunk_ds = [] { const char* e = getenv("F8_CHUNK_DS"); return e ? atoi(e) : 1; }();
-    if (!chunk_ds && net->nodes[st.node].fbd_a >= 0) return 0;
+    const Node& nd = net->nodes[st.node];
+    const Options& o = net->opt;
+    if (nd.fbd_a >= 0 && !(nd.fbd_s2 ? o.chunk_opener : o.chunk_ds)) return 0;
     const Tensor& x = net->tensors[st.src_t];
-    return x.W == x.H ? chunk_images(x.W) : 0;
+    if (x.W != x.H || !(x.W == 56 || x.W == 28 || x.W == 14)) return 0;
+    int chunk = x.W == 56 ? o.chunk56 : (x.W == 28 ? o.chunk28 : o.chunk14);
+    if (chunk < 0) {
+        size_t per_img = (size_t)x.H * x.W * x.Cs * 4;
+        if (st.out.t >= 0) { const Tensor& y = net->tensors[st.out.t]; per_img = std::max(per_img, (size_t)y.H * y.W * y.Cs * 4); }
+        chunk = (int)std::min<size_t>(((size_t)o.chunk_budget_mb << 20) / std::max<size_t>(per_img, 1), 1 << 20);
+    }
+    const int gran = chunk_gran(x.W);
+    chunk = chunk / gran * gran;
+    return chunk;
 }
-// f(step index, first image of the chunk, images) for every kernel launch of a run over N images, in launch order
+// f(step index, first image of the chunk, images) for every kernel launch of a run over N images, in launch order.
+// A group = consecutive chunkable steps at one resolution with the same nominal chunk; the batch is cut into equal chunks
+// (no tiny tail), and not at all when it exceeds the nominal chunk by less than a quarter.
 extern "C++" template <class F>
 static int for_each_launch(const f8_net* net, int N, F&& f) {
     const int ns = (int)net->steps.size();
     for (int i = 0; i < ns;) {
-        const int chunk = step_chunk(net, i);
-        if (chunk > 0 && N > chunk) {
+        const int nominal = step_chunk(net, i);
+        const int W = nominal > 0 ? net->tensors[net->steps[i].src_t].W : 0;
+        int k = nominal > 0 ? (N + nominal - 1) / nominal : 1;
+        if (nominal > 0 && (long)N * 4 <= (long)nominal * 5) k = 1;
+        if (k > 1) {
+            const int gran = chunk_gran(W);
+            const int chunk = ((N + k - 1) / k + gran - 1) / gran * gran;
             int j = i;
-            while (j < ns && step_chunk(net, j) == chunk && net->tensors[net->steps[j].src_t].W == net->tensors[net->steps[i].src_t].W) ++j;
+            while (j < ns && step_chunk(net, j) == nominal && net->tensors[net->steps[j].src_t].W == W) ++j;
             for (int c0 = 0; c0 < N; c0 += chunk)
-                for (int k = i; k < j; ++k) { const int rc = f(k, c0, std::min(chunk, N - c0)); if (rc) return rc; }
+                for (int kk = i; kk < j; ++kk) { const int rc = f(kk, c0, std::min(chunk, N - c0)); if (rc) return rc; }
             i = j;
         } else {
             const int rc = f(i, 0, N);
@@ -1461,7 +1583,16 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
     if (!input || !output) return fail(F8_ERR_INVALID, "f8_net_run: null pointer");
     int rc = f8_net_upload(net);
     if (rc) return rc;
+    if (net->opt.check_device) {       // the arena, the weights and the internal streams belong to the device of the upload
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev != net->device)
+            return fail(F8_ERR_STATE, "f8_net_run: current device %d, but this net lives on device %d (hipSetDevice before the call; one handle per device)", dev, net->device);
+    }
     hipStream_t s = (hipStream_t)stream;
+    if (net->input_ready) {            // one-shot: the producer of this run's input (f8_net_set_input_ready); every schedule forks from / runs on `s`
+        (void)hipStreamWaitEvent(s, net->input_ready, 0);
+    }
+    hipEvent_t in_ready = net->input_ready; net->input_ready = nullptr;
     const int ns = (int)net->steps.size();
     int cut[5];
     int parts = split_batch(net, N, cut);
@@ -1516,8 +1647,8 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
         }
         return F8_OK;
     };
-    static const int arena_copies = [] { const char* e = getenv("F8_SPLIT"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
-    static const int use_streams = [] { const char* e = getenv("F8_SPLIT_STREAMS"); return e ? atoi(e) : 1; }();
+    const int arena_copies = net->n_copies;
+    const int use_streams = net->opt.split_streams;
     if (net->pipelined == 2 && arena_copies >= 2 && !use_streams)     // rocprofv3 runs: the same launches, alone on the caller's stream
         return run_steps(net, input, output, 0, N, 0, s);
     if (net->pipelined == 2 && arena_copies >= 2) {
@@ -1533,6 +1664,7 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
         (void)hipEventRecord(net->start_ev[cur], s);
         hipEvent_t dep = (net->have_prev_start && net->prev_stream == s) ? net->start_ev[cur ^ 1] : net->start_ev[cur];
         (void)hipStreamWaitEvent(net->aux[slot], dep, 0);
+        if (in_ready) (void)hipStreamWaitEvent(net->aux[slot], in_ready, 0);   // the lagged dependency does not cover this run's input
         net->start_idx ^= 1; net->have_prev_start = true; net->prev_stream = s; net->alt_idx ^= 1;
         if ((rc = run_steps(net, input, output, 0, N, slot, net->aux[slot]))) return rc;
         (void)hipEventRecord(net->aux_ev[1 + slot], net->aux[slot]);
@@ -1553,7 +1685,7 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
     // F8_GRAPH=1: the second call with the same (input, output, N, stream) captures the launches below into a hipGraph
     // (the aux streams join the capture through the fork event); later calls replay it with one hipGraphLaunch.
     // The legacy null stream cannot be captured: the graph then lives on an internal stream fenced by events.
-    static const int use_graph = [] { const char* e = getenv("F8_GRAPH"); return e ? atoi(e) : 0; }();
+    const int use_graph = net->opt.graph;
     bool capturing = false;
     hipStream_t user_s = s;
     auto graph_replay = [&]() -> int {
@@ -1586,7 +1718,7 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
         const int cur = net->start_idx;
         (void)hipEventRecord(net->start_ev[cur], s);
         hipEvent_t dep = (net->have_prev_start && net->prev_stream == s) ? net->start_ev[cur ^ 1] : net->start_ev[cur];
-        for (int k = 0; k < parts; ++k) (void)hipStreamWaitEvent(net->aux[k], dep, 0);
+        for (int k = 0; k < parts; ++k) { (void)hipStreamWaitEvent(net->aux[k], dep, 0); if (in_ready) (void)hipStreamWaitEvent(net->aux[k], in_ready, 0); }
         net->start_idx ^= 1; net->have_prev_start = true; net->prev_stream = s;
     } else {
         (void)hipEventRecord(net->aux_ev[0], s);
@@ -1595,8 +1727,7 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
     }
     // optional stagger: sub-batch p starts only after sub-batch p-1 has finished its first `lag` launches, so that the
     // streams do not march through the memory-bound and the latency-bound layers in lock step
-    static const int lag_env = [] { const char* e = getenv("F8_STAGGER"); return e ? atoi(e) : -1; }();
-    static const int lag_pipe = [] { const char* e = getenv("F8_STAGGER_PIPELINED"); return e ? atoi(e) : 2; }();
+    const int lag_env = net->opt.stagger, lag_pipe = net->opt.stagger_pipelined;
     const int lag = lag_env >= 0 ? lag_env : (net->pipelined ? lag_pipe : 2);   // measured: lag 0/1/2/4/8 = 56.06/56.37/56.65/56.34/55.1 k img/s
     // the launches of every part (chunked where a part is larger than a chunk), submitted round-robin so that no stream's
     // queue starts late

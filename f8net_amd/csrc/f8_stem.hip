@@ -164,14 +164,13 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemPoolArgs a) {
 }
 
 bool stem_pool_supported(int cin, int cout, int k, int stride, int pad, int pool_k, int pool_s, int pool_p, int P, int Q) {
-    static const int on = [] { const char* e = getenv("F8_FUSE_STEM"); return e ? atoi(e) : 1; }();
-    return on && cin <= 4 && cout == 64 && k == 7 && stride == 2 && pad == 3 && pool_k == 3 && pool_s == 2 && pool_p == 1 && P > 0 && Q > 0 &&
+    return cin <= 4 && cout == 64 && k == 7 && stride == 2 && pad == 3 && pool_k == 3 && pool_s == 2 && pool_p == 1 && P > 0 && Q > 0 &&
            P % TP == 0 && Q % TQ == 0;
 }
 
 hipError_t launch_stem_pool(const StemPoolArgs& a, hipStream_t s) {
     const int ntiles = a.N * (a.P / TP) * (a.Q / TQ);
-    static const int wpc = [] { const char* e = getenv("F8_STEM_WPC"); return e ? atoi(e) : 2; }();     // resident workgroups per CU (63 KB LDS each)
+    const int wpc = a.wpc > 0 ? a.wpc : 2;               // resident workgroups per CU (63 KB LDS each), Options::stem_wpc
     static int ncu = 0;
     if (!ncu) { int dev = 0; hipDeviceProp_t p; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
     const int grid = ntiles < ncu * wpc ? ntiles : ncu * wpc;

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define F8NET_VERSION 100
+#define F8NET_VERSION 200
 
 typedef enum f8_status {
     F8_OK = 0,
@@ -162,7 +162,8 @@ int f8_net_output_fraclen(const f8_net* net);
 size_t f8_net_output_elems(const f8_net* net);
 
 /* Allocates device memory on the current device and uploads packed weights.  Implicit in the
- * first f8_net_run; explicit so that callers can keep allocation out of timed regions. */
+ * first f8_net_run; explicit so that callers can keep allocation out of timed regions.  The handle is bound to that
+ * device: a run with another device current fails with F8_ERR_STATE (option check_device). */
 int f8_net_upload(f8_net* net);
 
 /* Runs the net on `N` images (1 <= N <= max_batch).  input_dev: int32 NCHW [N,C,H,W];
@@ -195,6 +196,25 @@ int f8_net_autotune(f8_net* net, int N, void* stream);
  * workgroups of a sub-batch launch), which is what the latency-bound launches of the late stages need at 128 images;
  * the latency of one run roughly doubles, the throughput of a stream of runs rises. */
 int f8_net_set_pipelined(f8_net* net, int on);
+
+/* Orders the NEXT run (any f8_net_run* entry) behind `event` (a hipEvent_t passed as void*; NULL clears): the run's first
+ * launch waits for it in addition to its stream dependencies.  This is how a pipelined caller hands over an input that is
+ * produced on another stream (an H2D copy, a decoder): record the event behind the producer, call this, then run.  Needed
+ * because under f8_net_set_pipelined the run does NOT wait for work queued on `stream` after the previous run's entry.
+ * One-shot: consumed by the next run. */
+int f8_net_set_input_ready(f8_net* net, void* event);
+
+/* Per-handle tuning options.  A new handle takes its defaults from the environment (F8_<KEY IN CAPITALS>; F8_CHUNK for
+ * chunk56) and otherwise the measured best; two handles in one process may differ.  Keys that decide the plan must be set
+ * before f8_net_finalize (F8_ERR_STATE afterwards); scheduling keys may change between runs.
+ *   planning  : split (1..4 concurrent sub-batches = arena copies), fuse_blocks, fuse_stages (bit mask, -1 = auto), fuse_dual,
+ *               fuse_ds, fuse_opener, fuse_stem, fuse_ir, patch3x3, dual_wide, deep_nk, bk128, dw_dot4, opener_stg
+ *   scheduling: chunk56 / chunk28 / chunk14 (images per chunk of the fused blocks; -1 = derived from chunk_budget_mb, 0 = whole
+ *               batch), chunk_budget_mb (memory-side cache a chunk's int32 stream may occupy), chunk_ds, chunk_opener,
+ *               split_streams, graph, stagger, stagger_pipelined, stem_wpc, check_device
+ * F8_ERR_INVALID for an unknown key or a value outside the key's range. */
+int f8_net_set_option(f8_net* net, const char* key, int value);
+int f8_net_get_option(const f8_net* net, const char* key, int* value);
 
 /* f8_net_run cuts a batch of N into this many independent sub-batches (1..4) that it runs on
  * internal streams forked from / joined to `stream` (no host synchronisation); every planned launch

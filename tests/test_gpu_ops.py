@@ -298,6 +298,69 @@ def test_stage_opening_block_fused_matches_oracle(dev, variant):
     assert (np.abs(want.astype(np.int64)) > 2**30).any()
 
 
+@pytest.mark.parametrize('H,N', [(56, 2), (16, 3)])
+@pytest.mark.parametrize('variant', ['body_shifts_left', 'shortcut_shifts_left_signed_mid', 'different_input_formats'])
+@pytest.mark.parametrize('tail', ['i32', 'i8', 'both'])
+def test_stage1_opening_block_stride2_fused_matches_oracle(dev, H, N, variant, tail):
+    """ResNet-50's stage-1 opening block (256 -> 128 -> 3x3 / 2 -> 512 + strided 1x1 shortcut, 56 wide; fix_resnet.py:26-77) as
+    a net of its own: ONE launch (f8_opener.hip) when body.0 and the shortcut read the same int8 form of the block input,
+    separate launches otherwise.  `tail` decides which forms the block output needs: the int32 stream, an int8 copy (staged
+    through LDS into 128-byte lines), or both.  Top image border (tile 0), several row tiles, wrap / clamp in the join."""
+    from f8net_amd import topology
+    from f8net_amd.net import F8Net
+    Cin, MID, Cout, W = 256, 128, 512, 56
+    if H == 56 and (tail != 'both' or variant == 'different_input_formats'):
+        pytest.skip('the full-height map runs once per fused variant')
+    body = [topology.ConvSpec('blk.body.0', Cin, MID, 1, 1, 0, relu=True),
+            topology.ConvSpec('blk.body.2', MID, MID, 3, 2, 1, relu=True),
+            topology.ConvSpec('blk.body.4', MID, Cout, 1, 1, 0)]
+    sc = topology.ConvSpec('blk.shortcut.0', Cin, Cout, 1, 2, 0)
+    b = topology.BlockSpec('blk', body, sc, residual=True, post_relu=True)
+    fls = {'blk.body.0': (4, 7), 'blk.body.2': (3, 6), 'blk.body.4': (3, 5), 'blk.shortcut.0': (4, 7)}       # 8 vs 11
+    if variant == 'shortcut_shifts_left_signed_mid':
+        fls.update({'blk.body.4': (6, 7), 'blk.shortcut.0': (4, 6)})                                             # 13 vs 10
+        body[1].signed_in = True          # plain (unbiased) LDS patch and its zero border
+    if variant == 'different_input_formats':
+        fls['blk.shortcut.0'] = (5, 7)
+    x_fl = 9
+    params = {}
+    for c in body + [sc]:
+        in_fl, w_fl = fls[c.key]
+        params[c.key + '.weight'] = np.clip(synth.rand_normal_int(45, c.key + 'w' + variant, (c.cout, c.cin, c.k, c.k), 50.0), -127, 127).astype(np.int32)
+        params[c.key + '.bias'] = synth.rand_normal_int(46, c.key + 'b', (c.cout,), 2.0 ** 27).astype(np.int32)   # joins wrap / clamp
+        params[c.key + '.weight_fraclen'] = np.array(w_fl, np.int32)
+        params[c.key + '.input_fraclen'] = np.array([in_fl], np.int32)
+    x = synth.rand_normal_int(47, 'op2' + variant, (N, Cin, H, W), 2.0e3).astype(np.int32)
+    net = F8Net()
+    t = net.input(Cin, H, W, x_fl)
+    r = t
+    for c in body:
+        r = net.conv(r, params[c.key + '.weight'], params[c.key + '.bias'], stride=c.stride, pad=c.pad, groups=1,
+                     weight_fl=fls[c.key][1], input_fl=fls[c.key][0], input_signed=c.signed_in, quant_input=True, relu=c.relu)
+    s = net.conv(t, params[sc.key + '.weight'], params[sc.key + '.bias'], stride=2, pad=0, groups=1,
+                 weight_fl=fls[sc.key][1], input_fl=fls[sc.key][0], input_signed=False, quant_input=True, relu=False)
+    r = net.add(r, s, relu=True)
+    want, want_fl = oracle.block_forward(b, params, x, x_fl)
+    assert (np.abs(want.astype(np.int64)) > 2**30).any()       # the join ran at full int32 width
+    P, Q = H // 2, W // 2
+    if tail != 'i32':                                          # a consumer that needs the int8 copy of the block output
+        wt = np.clip(synth.rand_normal_int(48, 'tailw', (Cout if tail == 'both' else 32, Cout, 1, 1), 40.0), -127, 127).astype(np.int32)
+        bt = synth.rand_normal_int(49, 'tailb', (wt.shape[0],), 1.0e4).astype(np.int32)
+        in_fl_t, w_fl_t = 2, 6
+        c2 = net.conv(r, wt, bt, stride=1, pad=0, groups=1, weight_fl=w_fl_t, input_fl=in_fl_t, input_signed=False, quant_input=True, relu=False)
+        y = oracle.conv2d(oracle.requant(want, in_fl_t, want_fl, False), wt, bt, 1, 0)
+        if tail == 'both':                                     # ... and the int32 stream as a residual operand
+            c2 = net.add(c2, r, relu=False)
+            y, _ = oracle.add_align(y, want, in_fl_t + w_fl_t, want_fl)
+        r, want = c2, y
+    net.output(r, as_float=False)
+    net.finalize(N)
+    plan = net.describe()
+    assert ('fused_opener_s2' in plan) == (variant != 'different_input_formats'), plan
+    got = net.run(_t(x, dev)).cpu().numpy().reshape(N, -1, P, Q)
+    np.testing.assert_array_equal(got, want)
+
+
 @pytest.mark.parametrize('case', [(3, 112, 224, True), (2, 224, 224, False), (1, 56, 64, False)], ids=lambda c: 'x'.join(map(str, c)))
 def test_fused_head_stem_conv_maxpool(dev, case):
     """ResNet head as ONE launch (f8_stem.hip): 7x7/2 conv + ReLU + [requant] + 3x3/2 max-pool, followed by a 1x1 conv that
