@@ -101,7 +101,8 @@ def main():
     pipe_mode = int(os.environ.get('F8_BENCH_PIPELINED', '2'))
     pipelined = pipe_mode != 0
     net.set_pipelined(pipe_mode)
-    sharded = f8dist.PipelinedShardedForward(lambda t, out: net.run(t, out=out), spec.num_classes, BS, dev, lagged=pipelined)
+    depth = int(os.environ.get('F8_PIPELINE_DEPTH', '2')) if pipe_mode == 2 else 2
+    sharded = f8dist.PipelinedShardedForward(lambda t, out: net.run(t, out=out), spec.num_classes, BS, dev, lagged=pipelined, depth=depth)
     logits = sharded.local[0]
 
     def step():

@@ -27,7 +27,9 @@ struct Options {
     int opener_stg = 1;          // stride-2 opener: int8 output staged through LDS into 128-byte lines
     int chunk56 = -1, chunk28 = -1, chunk14 = -1;   // images per chunk of the fused blocks (-1: derived from chunk_budget_mb, 0: whole batch)
     int chunk_budget_mb = 96;    // a chunk's int32 stream must fit this much memory-side cache (3/8 of the 256 MiB Infinity Cache)
-    int chunk_ds = 1, chunk_opener = 1;             // chunk the stage-opening blocks with their neighbours
+    int chunk_ds = 1, chunk_opener = 0;             // chunk the stage-opening blocks too (the stride-2 opener runs one workgroup per
+                                                    // CU, 7 per image: measured 139 us in one 128-image launch, 161 us in 4 chunks)
+    int pipeline_depth = 2;      // f8_net_set_pipelined(2): runs in flight (2..4, at most `split` arena copies)
     int split_streams = 1;       // 0: same launches serialised on the caller's stream (profiling)
     int graph = 0;               // hipGraph capture / replay of a run
     int stagger = -1, stagger_pipelined = 2;

@@ -112,6 +112,7 @@ struct f8_net {
     int max_batch = 0;
     Options opt;                       // per-handle tuning (f8_net_set_option); seeded from the environment at create
     int device = -1;                   // HIP device the arena / weights live on (set by f8_net_upload)
+    int num_cu = 0;                    // its compute units (0 before upload: 256 assumed)
     int n_copies = 0;                  // arena copies allocated at upload (= opt.split then)
     hipEvent_t input_ready = nullptr;  // one-shot: the next run's first launch also waits for it (f8_net_set_input_ready)
     std::vector<Step> steps;
@@ -126,7 +127,7 @@ struct f8_net {
     hipEvent_t lag_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     const float* in_f32 = nullptr; float in_scale = 0.f; int in_lo = 0, in_hi = 0;   // set by f8_net_run_f32 for the duration of the call
     // pipelined submission (f8_net_set_pipelined): fork dependency = the event recorded at the PREVIOUS run's entry
-    int pipelined = 0; hipEvent_t start_ev[2] = {nullptr, nullptr}; int start_idx = 0; bool have_prev_start = false; hipStream_t prev_stream = nullptr;
+    int pipelined = 0; hipEvent_t start_ev[4] = {nullptr, nullptr, nullptr, nullptr}; int start_idx = 0; int pipe_count = 0; hipStream_t prev_stream = nullptr;
     int alt_idx = 0;                   // pipelined == 2: internal stream / arena copy of the next run
     int chunk_off = 0;                 // image offset inside the arena while a chunk group runs (run_steps)
     // hipGraph of one whole run (both sub-batch streams), replayed while (input, output, N, stream) stay the same
@@ -220,6 +221,7 @@ static const OptKey kOptKeys[] = {
     {"stagger", "F8_STAGGER", &Options::stagger, -1, 1 << 20, false},
     {"stagger_pipelined", "F8_STAGGER_PIPELINED", &Options::stagger_pipelined, 0, 1 << 20, false},
     {"check_device", "F8_CHECK_DEVICE", &Options::check_device, 0, 1, false},
+    {"pipeline_depth", "F8_PIPELINE_DEPTH", &Options::pipeline_depth, 2, 4, false},
 };
 static const OptKey* find_opt(const char* key) {
     if (!key) return nullptr;
@@ -344,7 +346,7 @@ void f8_net_destroy(f8_net* net) {
     for (int k = 0; k < 5; ++k) if (net->aux_ev[k]) (void)hipEventDestroy(net->aux_ev[k]);
     for (int k = 0; k < 4; ++k) if (net->lag_ev[k]) (void)hipEventDestroy(net->lag_ev[k]);
     if (net->g_exec) (void)hipGraphExecDestroy(net->g_exec);
-    for (int k = 0; k < 2; ++k) if (net->start_ev[k]) (void)hipEventDestroy(net->start_ev[k]);
+    for (int k = 0; k < 4; ++k) if (net->start_ev[k]) (void)hipEventDestroy(net->start_ev[k]);
     delete net;
 }
 
@@ -474,7 +476,7 @@ int f8_net_output(f8_net* net, int src, int as_float) {
 int f8_net_set_pipelined(f8_net* net, int on) {
     if (!net) return fail(F8_ERR_INVALID, "f8_net_set_pipelined: null net");
     net->pipelined = on == 2 ? 2 : (on ? 1 : 0);
-    net->have_prev_start = false;
+    net->pipe_count = 0;
     return F8_OK;
 }
 
@@ -1241,6 +1243,7 @@ int f8_net_upload(f8_net* net) {
     const int parts_cap = net->opt.split;
     if ((e = hipGetDevice(&net->device)) != hipSuccess) return hip_fail(e, "hipGetDevice");
     net->n_copies = parts_cap;
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, net->device) == hipSuccess && pr.multiProcessorCount > 0) net->num_cu = pr.multiProcessorCount; }
     net->arena_stride = round_up_z(std::max<size_t>(net->arena_bytes, 256), 4096);
     if ((e = hipMalloc((void**)&net->d_arena, net->arena_stride * parts_cap)) != hipSuccess) return hip_fail(e, "hipMalloc(arena)");
     if ((e = hipMalloc((void**)&net->d_w, std::max<size_t>(net->wblob.size(), 256))) != hipSuccess) return hip_fail(e, "hipMalloc(weights)");
@@ -1516,11 +1519,16 @@ static int split_batch(const f8_net* net, int N, int cut[5]) {
 // then 28x28 chunks of 32 / 48 / 64 / 80 / 96 = +1.7 / +2.5 / +2.9 / +2.8 / +1.1 %; the 14x14 tensors (103 MB per batch) need
 // none.  Applies in every schedule (a sub-batch of 64 images still runs its 56x56 blocks in chunks: non-pipelined run
 // 73.4k -> 75.1k img/s).
-// Defaults are DERIVED: the int32 stream of a chunk (bytes per image of the wider of the block's int32-sized input and
-// output maps: 3.2 MB at 56x56x256, 1.6 MB at 28x28x512, 0.8 MB at 14x14x1024) has to fit Options::chunk_budget_mb
-// (96 MiB = 3/8 of the 256 MiB memory-side cache: 24 / 56 / 96 images); chunk56 / chunk28 / chunk14 override (0 = whole
-// batch).  Every chunk offset must keep the I32T blocks of the group's tensors aligned (chunk * H*W a multiple of 32 pixels,
-// for the source map AND a stage-opening block's half-resolution output): chunks are multiples of 2 / 8 / 32 images.
+// Defaults are DERIVED from two numbers, not hand-fitted per net:
+//   cache : the int32 stream of a chunk (bytes per image of the wider of the block's int32-sized input and output maps: 3.2 MB
+//           at 56x56x256, 1.6 MB at 28x28x512, 0.8 MB at 14x14x1024) should fit Options::chunk_budget_mb (96 MiB = 3/8 of the
+//           256 MiB memory-side cache);
+//   fill  : a chunk launch must still fill the chip: >= 85 % of (CUs x resident workgroups per CU) workgroups.
+// chunk = max(cache, fill): 56x56 -> 30 images (cache), 28x28 -> 64 (fill: 7 tiles per image, 2 workgroups per CU),
+// 14x14 -> 128 (fill: 2 tiles per image, 1 per CU), which is what sweeps over explicit sizes had found (24-32 / 64 / 128).
+// chunk56 / chunk28 / chunk14 override (0 = whole batch).  Every chunk offset must keep the I32T blocks of the group's tensors
+// aligned (chunk * H*W a multiple of 32 pixels, for the source map AND a stage-opening block's half-resolution output):
+// chunks are multiples of 2 / 8 / 32 images.
 static int chunk_gran(int W) { return W == 56 ? 2 : (W == 28 ? 8 : 32); }
 static int step_chunk(const f8_net* net, int i) {        // nominal images per chunk of step i (0 = not chunked)
     const Step& st = net->steps[i];
@@ -1531,12 +1539,17 @@ static int step_chunk(const f8_net* net, int i) {        // nominal images per c
     const Tensor& x = net->tensors[st.src_t];
     if (x.W != x.H || !(x.W == 56 || x.W == 28 || x.W == 14)) return 0;
     int chunk = x.W == 56 ? o.chunk56 : (x.W == 28 ? o.chunk28 : o.chunk14);
+    const int gran = chunk_gran(x.W);
     if (chunk < 0) {
         size_t per_img = (size_t)x.H * x.W * x.Cs * 4;
         if (st.out.t >= 0) { const Tensor& y = net->tensors[st.out.t]; per_img = std::max(per_img, (size_t)y.H * y.W * y.Cs * 4); }
-        chunk = (int)std::min<size_t>(((size_t)o.chunk_budget_mb << 20) / std::max<size_t>(per_img, 1), 1 << 20);
+        const int cache = (int)std::min<size_t>(((size_t)o.chunk_budget_mb << 20) / std::max<size_t>(per_img, 1), 1 << 20) / gran * gran;
+        const int mid = net->nodes[nd.fbd_a >= 0 ? nd.fbd_a : nd.fb_a].cd.cout;
+        const int tiles = std::max(1, (nd.fbd_s2 ? x.H / 2 : x.H) / std::max(1, nd.fb_R));        // workgroups per image
+        const int slots = (net->num_cu > 0 ? net->num_cu : 256) * ((nd.fbd_s2 || mid > 128) ? 1 : 2);
+        const int fill = ((slots * 85 / 100 + tiles - 1) / tiles + gran - 1) / gran * gran;
+        chunk = std::max(cache, fill);
     }
-    const int gran = chunk_gran(x.W);
     chunk = chunk / gran * gran;
     return chunk;
 }
@@ -1657,15 +1670,19 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
         // batch (twice the workgroups per launch: at 128 images the latency-bound launches of the late stages fill the chip).
         // Fork: as in the lagged mode the stream waits for `s` as of the PREVIOUS run's entry (and, by stream order, for
         // run i-2 on the same arena copy); join: `s` waits for this run.
+        // Options::pipeline_depth D (2..4, at most the arena copies): D runs in flight; the fork then lags D-1 entries.
         if ((rc = ensure_aux())) return rc;
         if (!net->start_ev[0])
-            for (int k = 0; k < 2; ++k) (void)hipEventCreateWithFlags(&net->start_ev[k], hipEventDisableTiming);
-        const int cur = net->start_idx, slot = net->alt_idx;
+            for (int k = 0; k < 4; ++k) (void)hipEventCreateWithFlags(&net->start_ev[k], hipEventDisableTiming);
+        const int D = std::max(2, std::min(net->opt.pipeline_depth, arena_copies));
+        if (net->prev_stream != s) net->pipe_count = 0;
+        const int cur = net->start_idx, slot = net->alt_idx % D;
         (void)hipEventRecord(net->start_ev[cur], s);
-        hipEvent_t dep = (net->have_prev_start && net->prev_stream == s) ? net->start_ev[cur ^ 1] : net->start_ev[cur];
+        const int lagn = std::min(net->pipe_count, D - 1);
+        hipEvent_t dep = net->start_ev[(cur - lagn + 4) & 3];
         (void)hipStreamWaitEvent(net->aux[slot], dep, 0);
         if (in_ready) (void)hipStreamWaitEvent(net->aux[slot], in_ready, 0);   // the lagged dependency does not cover this run's input
-        net->start_idx ^= 1; net->have_prev_start = true; net->prev_stream = s; net->alt_idx ^= 1;
+        net->start_idx = (cur + 1) & 3; ++net->pipe_count; net->prev_stream = s; net->alt_idx = (slot + 1) % D;
         if ((rc = run_steps(net, input, output, 0, N, slot, net->aux[slot]))) return rc;
         (void)hipEventRecord(net->aux_ev[1 + slot], net->aux[slot]);
         (void)hipStreamWaitEvent(s, net->aux_ev[1 + slot], 0);
@@ -1714,16 +1731,17 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
         // lagged fork: the sub-batch streams order themselves behind the previous run on the same arena copy by stream
         // order; towards the caller they only wait for the state of `s` at the previous run's entry (header contract)
         if (!net->start_ev[0])
-            for (int k = 0; k < 2; ++k) (void)hipEventCreateWithFlags(&net->start_ev[k], hipEventDisableTiming);
+            for (int k = 0; k < 4; ++k) (void)hipEventCreateWithFlags(&net->start_ev[k], hipEventDisableTiming);
+        if (net->prev_stream != s) net->pipe_count = 0;
         const int cur = net->start_idx;
         (void)hipEventRecord(net->start_ev[cur], s);
-        hipEvent_t dep = (net->have_prev_start && net->prev_stream == s) ? net->start_ev[cur ^ 1] : net->start_ev[cur];
+        hipEvent_t dep = net->start_ev[(cur - std::min(net->pipe_count, 1) + 4) & 3];
         for (int k = 0; k < parts; ++k) { (void)hipStreamWaitEvent(net->aux[k], dep, 0); if (in_ready) (void)hipStreamWaitEvent(net->aux[k], in_ready, 0); }
-        net->start_idx ^= 1; net->have_prev_start = true; net->prev_stream = s;
+        net->start_idx = (cur + 1) & 3; ++net->pipe_count; net->prev_stream = s;
     } else {
         (void)hipEventRecord(net->aux_ev[0], s);
         for (int k = 0; k < parts; ++k) (void)hipStreamWaitEvent(net->aux[k], net->aux_ev[0], 0);
-        net->have_prev_start = false;
+        net->pipe_count = 0;
     }
     // optional stagger: sub-batch p starts only after sub-batch p-1 has finished its first `lag` launches, so that the
     // streams do not march through the memory-bound and the latency-bound layers in lock step

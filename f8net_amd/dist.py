@@ -83,24 +83,26 @@ class PipelinedShardedForward(ShardedForward):
     buffer pairs alternate, and a pair is only reused after its collective has been waited for.  The tensor returned by
     `__call__` is complete after `finish()` (or after the pair comes round again).  Equal shards only."""
 
-    def __init__(self, forward_local, num_classes: int, n_local: int, device, group=None, lagged=False):
+    def __init__(self, forward_local, num_classes: int, n_local: int, device, group=None, lagged=False, depth=2):
         super().__init__(forward_local, num_classes, group)
         self.n_local = n_local
+        self.depth = depth = max(2, int(depth))     # buffer pairs = runs the net keeps in flight (option pipeline_depth)
         # lagged: the net runs with f8_net_set_pipelined(1), whose contract wants a buffer free ONE CALL before the run that
         # writes it: the collective of the previous batch is then waited for at the top of this call (the wait lands on the
         # caller's stream, which the net's sub-batch streams only follow with one call of lag: it stalls no compute)
         self.lagged = lagged
-        self.local = [torch.empty((n_local, num_classes), dtype=torch.float32, device=device) for _ in range(2)]
+        self.local = [torch.empty((n_local, num_classes), dtype=torch.float32, device=device) for _ in range(depth)]
         world = self.world
-        self.full = [torch.empty((n_local * world, num_classes), dtype=torch.float32, device=device) for _ in range(2)] \
+        self.full = [torch.empty((n_local * world, num_classes), dtype=torch.float32, device=device) for _ in range(depth)] \
             if world > 1 else self.local
-        self.work = [None, None]
+        self.work = [None] * depth
         self.i = 0
 
     def __call__(self, x_local, n_total=None):
-        k = self.i & 1
+        k = self.i % self.depth
         self.i += 1
-        for j in ((k, k ^ 1) if self.lagged else (k,)):
+        # lagged: the buffer of the run `depth - 1` calls ahead (pair k - 1) has to be free by the time THIS run is submitted
+        for j in ((k, (k - 1) % self.depth) if self.lagged else (k,)):
             if self.work[j] is not None:
                 self.work[j].wait()        # a pair's previous collective is done before its buffers are rewritten
                 self.work[j] = None
@@ -110,7 +112,7 @@ class PipelinedShardedForward(ShardedForward):
         return self.full[k]
 
     def finish(self):
-        for k in range(2):
+        for k in range(self.depth):
             if self.work[k] is not None:
                 self.work[k].wait()
                 self.work[k] = None
