@@ -6,20 +6,29 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the whole hot path over one synthetic batch already resident in HBM:
-int32 NCHW images (the reference's input format, fix_train.py:683-692) -> 57 fused HIP launches
+int32 NCHW images (the reference's input format, fix_train.py:683-692) -> fused HIP launches
 (libf8net.so) -> fp32 logits; with N > 1 every rank runs its own 128 images (weak scaling) and the
 logits are all-gathered over RCCL (the path's one exchange step).  Rank 0 prints ONE JSON line.
 
-Parameters: the reference's real learned fraction lengths for the NVIDIA-pretrained ResNet-50
-(fraclen_visual/res50_fix_quant_nvidia_pretrained.out:492-1138; `normalize: True`, signed head
-input) with seeded synthetic int8 weights — Model-Zoo checkpoints are unreachable (no network).
+Parameters: the reference's real learned fraction lengths (ResNet-50: NVIDIA-pretrained run,
+fraclen_visual/res50_fix_quant_nvidia_pretrained.out:492-1138, `normalize: True`, signed head input;
+MobileNet-V2: fraclen_visual/mbv2_fix_quant.out:1267-1901) with seeded synthetic int8 weights —
+Model-Zoo checkpoints are unreachable (no network).
 
-roofline  : dominant kernel symbol by time; achieved = sum(algorithmic bytes of its launches) /
-            sum(their durations), durations from HIP events on the launch stream (f8_net_run_profiled).
-cpu_baseline: the CPU oracle (oracle/, a port of the reference's int32 CPU forward) timed on the host
-            cores for a bounded sample of the same workload, rank 0 at N = 1 only.
+Other BASELINE.json configurations:  --arch resnet18 --bs 128 (C2), --arch mobilenet_v2 --bs 128 (C3),
+--arch resnet50 --bs 256 (C4), --gpus 8 --bs 256 (C5: 2048 images over 8 GPUs).
+
+value            : the timed region is EXACTLY --steps steps with two batches in flight (f8_net_set_pipelined(2)).
+value_unpipelined: the same steps, one batch in flight (runs back to back; each run = two concurrent sub-batches).
+roofline         : dominant kernel symbol by time; achieved = sum(algorithmic bytes of its launches) / sum(their
+                   durations), durations from HIP events on the launch stream (f8_net_run_profiled).  `traffic` (HBM bytes per
+                   launch, separate rocprofv3 --pmc passes) and `mfma` (INT8-MFMA busy fraction, rocprofv3 --pmc) are taken from
+                   profiles/pmc_*.json ONLY when those files were produced from the same kernel sources (sha256 stamp).
+cpu_baseline     : the CPU oracle (oracle/, a port of the reference's int32 CPU forward) timed on the host cores for a bounded
+                   sample of the same workload, rank 0 at N = 1 only; `c1` = BASELINE config 1 (ResNet-18, bs 1) timed the same way.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -28,16 +37,42 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BS = 128
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 MFMA_I8_PEAK_TOPS = 5033.0     # 256 CU x 4 SIMD x 2048 op/clk x 2.4 GHz
 # per image: integer ops (2 * MACs) and the structural byte model of SURVEY.md §8d
 OPS_PER_IMG = {'resnet50': 8.178368512e9, 'resnet18': 3.628146688e9, 'mobilenet_v2': 0.601548544e9, 'mobilenet_v1': 1.137480704e9}
 STRUCT_BYTES_PER_IMG = {'resnet50': 93444000.0, 'resnet18': 20830112.0, 'mobilenet_v2': 20602656.0, 'mobilenet_v1': 28911520.0}
+PRETTY = {'resnet50': 'ResNet-50', 'resnet18': 'ResNet-18', 'mobilenet_v2': 'MobileNet-V2', 'mobilenet_v1': 'MobileNet-V1'}
+MIN_TIMED_S = 0.2              # below this the two-deep pipeline's fill / drain is a visible share of the timed region
 
 
-def cpu_baseline(spec, params, x_np, x_fl, ref_logits):
-    """Time the oracle on a bounded sample (~10-30 s of CPU work) and check it against the GPU."""
+def csrc_sha256():
+    """Stamp of the kernel sources the in-tree library is built from (profiles/pmc_*.json carry the stamp of the build they measured)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'f8net_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h', '.cpp')):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()
+
+
+def stamped_json(name, stamp):
+    """profiles/<name> if it was measured on this build, else (None, reason)."""
+    path = os.path.join(ROOT, 'profiles', name)
+    if not os.path.exists(path):
+        return None, f'profiles/{name} missing'
+    try:
+        d = json.load(open(path))
+    except Exception as e:                                          # noqa: BLE001
+        return None, f'profiles/{name} unreadable ({e})'
+    if d.get('csrc_sha256') != stamp:
+        return None, f'profiles/{name} was measured on other kernel sources (stamp mismatch): dropped'
+    return d, None
+
+
+def cpu_baseline(spec, params, x_np, x_fl, ref_logits, budget_s=12.0):
+    """Time the oracle on a bounded sample (~10-15 s of CPU work) and check it against the GPU."""
     import numpy as np
     from oracle import oracle
     oracle.build()
@@ -45,26 +80,43 @@ def cpu_baseline(spec, params, x_np, x_fl, ref_logits):
     t0 = time.time()
     oracle.net_forward(spec, params, x_np[:4], x_fl)
     t4 = (time.time() - t0) / 4                                     # seconds per image at a small batch
-    n = int(max(1, min(x_np.shape[0], 12.0 / max(t4, 1e-3))))      # ~10-15 s of CPU work
+    n = int(max(1, min(x_np.shape[0], budget_s / max(t4, 1e-3))))
     t0 = time.time()
     y = oracle.net_forward(spec, params, x_np[:n], x_fl)
     dt = time.time() - t0
     ok = bool(np.array_equal(y, ref_logits[:n]) and np.array_equal(y1, ref_logits[:1]))
     return {'value': round(n / dt, 3), 'unit': 'img/s', 'cores': oracle.num_threads(), 'kind': 'port',
-            'sample': f'{n} images of the same batch (ResNet-50, 224x224), one forward, {dt:.1f} s; '
+            'sample': f'{n} images of the same batch ({PRETTY.get(spec.arch, spec.arch)}, {x_np.shape[2]}x{x_np.shape[3]}), one forward, {dt:.1f} s; '
                       f'host has {os.cpu_count()} logical cpus',
             'matches_gpu_bit_exact': ok}
 
 
+def cpu_config1():
+    """BASELINE.json configs[0]: ResNet-18 fix_quant int_op_only, bs = 1, CPU forward (the reference's own CPU-runnable case,
+    BASELINE.md §3: 0.287 s per forward on 8 Xeon vCPUs with the reference's ATen path) — the oracle, timed per forward."""
+    from f8net_amd import synth, topology
+    from oracle import oracle
+    spec = topology.get('resnet18')
+    params = synth.make_params(spec, seed=1234)
+    x, fl = synth.make_input(spec, params, 1, 224, seed=1)
+    oracle.net_forward(spec, params, x, fl)
+    reps, t0 = 0, time.time()
+    while reps < 5 or time.time() - t0 < 2.0:
+        oracle.net_forward(spec, params, x, fl)
+        reps += 1
+    dt = (time.time() - t0) / reps
+    return {'config': 'ResNet-18 fix_quant int_op_only, bs=1, 224x224, CPU forward', 'sec_per_forward': round(dt, 5), 'value': round(1.0 / dt, 2), 'unit': 'img/s',
+            'cores': oracle.num_threads(), 'kind': 'port', 'sample': f'{reps} forwards of one image'}
+
+
 def main():
-    global BS
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--arch', default='resnet50', help='other nets are parity-test cases, not bench lines')
-    ap.add_argument('--bs', type=int, default=BS, help='images per GPU (the headline metric is quoted at 128)')
+    ap.add_argument('--arch', default='resnet50', help='resnet50 (headline) | resnet18 | mobilenet_v2 | mobilenet_v1')
+    ap.add_argument('--bs', type=int, default=128, help='images per GPU (the headline metric is quoted at 128)')
     ap.add_argument('--per-layer', action='store_true', help='also print the per-launch table to stderr')
     ap.add_argument('--autotune', action='store_true', help='measured tile selection (f8_net_autotune) instead of the planner heuristics; '
                     'measured: re-tiles ~12 launches, gain within run-to-run noise, so off by default')
@@ -87,8 +139,9 @@ def main():
 
     normalize = args.arch == 'resnet50'
     spec = topology.get(args.arch, normalize=normalize)
-    fr = topology.R50_NVIDIA_FRACLENS if args.arch == 'resnet50' else None
-    params = synth.make_params(spec, seed=1234, fraclens=fr)
+    params = synth.reference_params(spec, seed=1234)
+    fr_name = {'resnet50': 'NVIDIA-pretrained fraclens (normalize: True)', 'mobilenet_v2': "the reference log's learned fraclens (mbv2_fix_quant.out)"}.get(
+        args.arch, 'seeded fraclens (weight_format [8,7]-style)')
     x_np, x_fl = synth.make_input(spec, params, BS, 224, seed=1 + rank)
     net = build_net(spec, params, max_batch=BS, hw=224)
     net.upload()
@@ -99,34 +152,47 @@ def main():
     # consecutive steps overlap inside the library as well (f8_net_set_pipelined: static input, double-buffered outputs)
     # F8_BENCH_PIPELINED: 0 = runs back to back, 1 = lagged sub-batches, 2 = whole batches alternating between two streams
     pipe_mode = int(os.environ.get('F8_BENCH_PIPELINED', '2'))
-    pipelined = pipe_mode != 0
-    net.set_pipelined(pipe_mode)
     depth = int(os.environ.get('F8_PIPELINE_DEPTH', '2')) if pipe_mode == 2 else 2
-    sharded = f8dist.PipelinedShardedForward(lambda t, out: net.run(t, out=out), spec.num_classes, BS, dev, lagged=pipelined, depth=depth)
-    logits = sharded.local[0]
 
-    def step():
-        return sharded(x)
+    def timed(mode, steps, warmup):
+        net.set_pipelined(mode)
+        sharded = f8dist.PipelinedShardedForward(lambda t, out: net.run(t, out=out), spec.num_classes, BS, dev, lagged=mode != 0, depth=depth)
 
-    def fence():
-        sharded.finish()
+        def fence():
+            sharded.finish()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+
+        out = None
+        for _ in range(warmup):
+            sharded(x)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = sharded(x)
+        fence()
+        dt = time.perf_counter() - t0
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        assert out.shape == (BS * world, spec.num_classes)
+        return dt, sharded.local[0]
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    assert out.shape == (BS * world, spec.num_classes)
+    dt, logits = timed(pipe_mode, args.steps, args.warmup)
+    # the same K steps with ONE batch in flight (every rank takes part: the loop holds collectives)
+    dt0, _ = timed(0, args.steps, min(args.warmup, 5)) if pipe_mode != 0 else (dt, None)
+    # a timed region under MIN_TIMED_S is dominated by pipeline fill / drain and launch jitter: report a longer one beside it
+    ext = None
+    if dt < MIN_TIMED_S:
+        k2 = int(max(args.steps * 2, min(20000, args.steps * (1.25 * MIN_TIMED_S / max(dt, 1e-6)))))
+        dte, _ = timed(pipe_mode, k2, 2)
+        ext = (k2, dte)
+        if rank == 0:
+            print(f'bench.py: the timed region of {args.steps} steps lasted {dt * 1e3:.1f} ms (< {MIN_TIMED_S} s); also timed {k2} steps '
+                  f'({dte * 1e3:.1f} ms) -> value_extended', file=sys.stderr)
+    net.set_pipelined(pipe_mode)
 
     result = None
     if rank == 0:
@@ -155,13 +221,23 @@ def main():
         d = by_kernel[dom]
         d_launches = d['launches']       # kernel launches per step (sub-batches / chunks included)
         achieved = d['bytes'] / (d['ms'] * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(tpath):     # HBM bytes per launch from separate rocprofv3 --pmc passes
-            try:
-                traffic = json.load(open(tpath)).get(dom, {}).get('hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
+        stamp = csrc_sha256()
+        notes = []
+        traffic = mfma = None
+        tj, why = stamped_json('pmc_traffic.json', stamp)    # HBM bytes per launch from separate rocprofv3 --pmc passes
+        if tj is not None and tj.get('workload') == f'{args.arch}/bs{BS}':
+            traffic = tj.get('kernels', {}).get(dom, {}).get('hbm_bytes_per_launch')
+        elif why:
+            notes.append(why)
+        mj, why = stamped_json('pmc_mfma.json', stamp)       # INT8-MFMA busy cycles per kernel (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES)
+        if mj is not None and mj.get('workload') == f'{args.arch}/bs{BS}':
+            mk = mj.get('kernels', {}).get(dom)
+            mfma = {'counter': 'SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 256 CU x 4 SIMD), rocprofv3 --pmc',
+                    'dominant_kernel_busy_frac': mk.get('mfma_busy_frac') if mk else None,
+                    'whole_net_busy_frac': mj.get('whole_net_mfma_busy_frac'),
+                    'whole_net_mfma_i8_insts_per_img': mj.get('whole_net_mfma_insts_per_img')}
+        elif why:
+            notes.append(why)
         total_ms = sum(ms)
         if args.per_layer:
             for i, name, m, b, o in rows:
@@ -170,32 +246,44 @@ def main():
             for k, e in sorted(by_kernel.items(), key=lambda kv: -kv[1]['ms']):
                 print(f'  {e["ms"]*1e3:8.1f} us {100*e["ms"]/total_ms:5.1f}% x{e["launches"]:2d}  '
                       f'{e["bytes"]/e["ms"]/1e6:7.0f} GB/s  {k}', file=sys.stderr)
+        headline = args.arch == 'resnet50' and BS == 128
         result = {
-            'metric': 'images/sec at bs=128 (ResNet-50 INT8)', 'value': round(value, 1), 'unit': 'img/s',
+            'metric': f'images/sec at bs={BS} ({PRETTY.get(args.arch, args.arch)} INT8)', 'value': round(value, 1), 'unit': 'img/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * dt / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'int8 x int8 -> int32 (exact integer)', 'data': 'synthetic',
-            'config': {'workload': f'{spec.arch} fix_quant INT8 int_op_only forward, bs={BS} per GPU, 224x224, '
-                                   f'NVIDIA-pretrained fraclens (normalize: True), int32 NCHW input resident in HBM',
+            'value_unpipelined': round(imgs / dt0, 1),
+            'config': {'workload': f'{spec.arch} fix_quant INT8 int_op_only forward, bs={BS} per GPU, 224x224, {fr_name}, '
+                                   f'int32 NCHW input resident in HBM' + ('' if headline else ' [not the headline configuration]'),
                        'global_batch': BS * world, 'parallelism': f'dp{world} (batch shards + RCCL all-gather of logits)',
                        'launches_per_step': sum(net.step_launches(i, BS) for i in range(n_l)), 'sub_batches': parts, 'autotuned_launches': retiled,
                        'schedule': {0: 'runs back to back (two concurrent sub-batches per run)',
                                     1: 'pipelined: sub-batches of consecutive runs overlap (f8_net_set_pipelined(1))',
                                     2: 'pipelined: two consecutive batches in flight, each launch covers a whole batch '
-                                       '(f8_net_set_pipelined(2)); every timed step completes inside the timed region'}[pipe_mode]},
+                                       '(f8_net_set_pipelined(2)); every timed step completes inside the timed region; '
+                                       'value_unpipelined = the same steps with one batch in flight'}[pipe_mode]},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'launches_per_step': d_launches,
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                          'avg_launch_us': round(1e3 * d['ms'] / d_launches, 2),
                          'alg_bytes_per_launch': round(d['bytes'] / d_launches, 0),
-                         'kernel_share_of_step': round(d['ms'] / total_ms, 3)},
+                         'kernel_share_of_step': round(d['ms'] / total_ms, 3),
+                         'mfma': mfma},
             'whole_net': {'sum_kernel_ms': round(total_ms, 4),
                           'mfma_int8_frac_of_peak': round(value / world * OPS_PER_IMG.get(args.arch, 0.0) / 1e12 / MFMA_I8_PEAK_TOPS, 4),
                           'hbm_frac_structural_bytes': round(value / world * STRUCT_BYTES_PER_IMG.get(args.arch, 0.0) / 1e9 / HBM_PEAK_GBS, 4),
+                          'hbm_frac_algorithmic_bytes': round(value / world * sum(r[3] for r in rows) / BS / 1e9 / HBM_PEAK_GBS, 4),
                           'alg_bytes_per_img': round(sum(r[3] for r in rows) / BS, 0)},
+            'build': {'csrc_sha256': stamp[:16]},
         }
-        if world == 1 and not args.no_cpu_baseline and args.arch == 'resnet50':
+        if ext is not None:
+            result['value_extended'] = round(BS * world * ext[0] / ext[1], 1)
+            result['steps_extended'] = ext[0]
+        if notes:
+            result['notes'] = notes
+        if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(spec, params, x_np, x_fl, logits[:BS].cpu().numpy())
+            result['cpu_baseline']['c1'] = cpu_config1()
         elif world == 1:
             result['cpu_baseline'] = None
     if world > 1:

@@ -64,6 +64,7 @@ SYMBOLS = [
     ('f8_net_step_launches', _i, [_vp, _i, _i]),
     ('f8_net_run', _i, [_vp, _vp, _vp, _i, _vp]),
     ('f8_net_run_f32', _i, [_vp, _vp, _i, _vp, _i, _vp]),
+    ('f8_net_run_u8', _i, [_vp, _vp, _i, _i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _vp, _i, _vp]),
     ('f8_net_run_profiled', _i, [_vp, _vp, _vp, _i, _vp, ctypes.POINTER(ctypes.c_float), _i]),
     ('f8_net_launch_info', _i, [_vp, _i, _i, ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_double),
                                 ctypes.POINTER(ctypes.c_double)]),

@@ -118,6 +118,8 @@ struct AddArgs {                           // standalone align-add (when it cann
 struct InArgs {                            // network input: int32 NCHW -> NHWC forms
     const int32_t* x; int32_t N, C, H, W;
     const float* xf; float scale; int32_t qlo, qhi;   // fp32 images quantised on the fly (x unused): rint(xf * scale) clamped
+    const uint8_t* xu8; int32_t u8_nhwc;              // uint8 images (f8_net_run_u8): NCHW planes or NHWC pixels, through `lut`
+    int16_t lut[3 * 256];                             // lut[c * 256 + byte] = the head-format integer of that pixel value
     uint32_t xor8;                         // 0x80808080 when the int8 consumer format is unsigned (biased storage)
     int8_t* out8;  int32_t Cs8;            // NHWC int8 (Cs8-channel rows), or
     int8_t* stem;  int32_t Hp, Wp, pad;    // zero-haloed NHWC4 for the stem conv

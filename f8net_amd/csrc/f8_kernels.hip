@@ -767,7 +767,19 @@ __global__ void __launch_bounds__(256) input_stem4_kernel(const InArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[c][j] = 0;
         for (int c = 0; c < a.C; ++c) {
-            if (a.xf) {
+            if (a.xu8) {
+                // uint8 pixels (1 B / px / channel instead of 4): NCHW = one dword of the plane, NHWC = 4 strided bytes
+                const int16_t* lut = a.lut + (c < 3 ? c : 2) * 256;
+                if (a.u8_nhwc) {
+                    const uint8_t* p = a.xu8 + ((((size_t)n * a.H + h) * a.W) + w) * a.C + c;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[c][j] = lut[p[(size_t)j * a.C]];
+                } else {
+                    const unsigned d = *(const unsigned*)(a.xu8 + pix0 + c * plane);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[c][j] = lut[(d >> (8 * j)) & 0xffu];
+                }
+            } else if (a.xf) {
                 const v4f f = *(const v4f*)(a.xf + pix0 + c * plane);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[c][j] = quant_in(f[j], a.scale, a.qlo, a.qhi);
@@ -797,7 +809,10 @@ __global__ void __launch_bounds__(256) input_kernel(const InArgs a) {
         const size_t pix0 = ((size_t)n * a.C * a.H + h) * a.W + w;
         const size_t plane = (size_t)a.H * a.W;
         // fp32 images are quantised on the fly (f8_net_run_f32): the int32 tensor of the reference never exists
-        auto ld = [&](int c) { return a.xf ? quant_in(a.xf[pix0 + c * plane], a.scale, a.qlo, a.qhi) : a.x[pix0 + c * plane]; };
+        auto ld = [&](int c) -> int {
+            if (a.xu8) return a.lut[(c < 3 ? c : 2) * 256 + (a.u8_nhwc ? a.xu8[((((size_t)n * a.H + h) * a.W) + w) * a.C + c] : a.xu8[pix0 + c * plane])];
+            return a.xf ? quant_in(a.xf[pix0 + c * plane], a.scale, a.qlo, a.qhi) : a.x[pix0 + c * plane];
+        };
         if (a.stem) {
             int v[4] = {0, 0, 0, 0};
             for (int c = 0; c < a.C; ++c) v[c] = ld(c);

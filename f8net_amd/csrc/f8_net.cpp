@@ -126,6 +126,7 @@ struct f8_net {
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t aux_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t lag_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     const float* in_f32 = nullptr; float in_scale = 0.f; int in_lo = 0, in_hi = 0;   // set by f8_net_run_f32 for the duration of the call
+    const uint8_t* in_u8 = nullptr; int in_u8_nhwc = 0; int16_t in_lut[3 * 256];       // set by f8_net_run_u8 for the duration of the call
     // pipelined submission (f8_net_set_pipelined): fork dependency = the event recorded at the PREVIOUS run's entry
     int pipelined = 0; hipEvent_t start_ev[4] = {nullptr, nullptr, nullptr, nullptr}; int start_idx = 0; int pipe_count = 0; hipStream_t prev_stream = nullptr;
     int alt_idx = 0;                   // pipelined == 2: internal stream / arena copy of the next run
@@ -1279,6 +1280,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             const Tensor& o = T[st.out.t];
             InArgs a{}; a.x = input + (size_t)n0 * o.C * o.H * o.W; a.N = N; a.C = o.C; a.H = o.H; a.W = o.W;
             if (net->in_f32) { a.xf = net->in_f32 + (size_t)n0 * o.C * o.H * o.W; a.scale = net->in_scale; a.qlo = net->in_lo; a.qhi = net->in_hi; }
+            if (net->in_u8) { a.xu8 = net->in_u8 + (size_t)n0 * o.C * o.H * o.W; a.u8_nhwc = net->in_u8_nhwc; memcpy(a.lut, net->in_lut, sizeof a.lut); }
             for (auto& F : o.forms) {
                 if (F.kind == FORM_I8) { if (F.n == 0) { a.out8 = (int8_t*)fp(F); a.Cs8 = o.Cs; if (!F.sgn) a.xor8 = 0x80808080u; } }
                 else if (F.kind == FORM_I32) { a.out32 = (int32_t*)fp(F); a.Cs32 = o.Cs; }
@@ -1713,7 +1715,7 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
         if (gs != user_s) { (void)hipEventRecord(net->aux_ev[4], gs); (void)hipStreamWaitEvent(user_s, net->aux_ev[4], 0); }
         return F8_OK;
     };
-    if (use_graph && parts <= 3 && !net->in_f32) {
+    if (use_graph && parts <= 3 && !net->in_f32 && !net->in_u8) {
         const bool same = net->g_in == input && net->g_out == output && net->g_N == N && net->g_stream == user_s;
         if (same && net->g_exec) return graph_replay();
         if (!same) {
@@ -1837,6 +1839,64 @@ int f8_net_run_f32(f8_net* net, const float* images, int normalize, void* output
     net->in_f32 = nullptr;
     return rc;
 }
+// sign of the network input's consumers (0 unsigned, 1 signed, < 0 status)
+static int input_sign(const f8_net* net, const char* who) {
+    const Tensor& in = net->tensors[net->nodes[0].out];
+    int sgn = -1;
+    for (int c : in.consumers) {
+        const Node& nd = net->nodes[c];
+        if (nd.kind != N_CONV && nd.kind != N_LINEAR) return fail(F8_ERR_UNSUPPORTED, "%s: the input must feed convolutions", who);
+        if (sgn >= 0 && sgn != (nd.cd.input_signed ? 1 : 0)) return fail(F8_ERR_UNSUPPORTED, "%s: consumers disagree on signedness", who);
+        sgn = nd.cd.input_signed ? 1 : 0;
+    }
+    if (sgn < 0) return fail(F8_ERR_UNSUPPORTED, "%s: the input has no consumer", who);
+    return sgn;
+}
+
+int f8_net_run_u8(f8_net* net, const uint8_t* images, int nhwc, int normalize, const float* mean, const float* stdv, void* output, int N, void* stream) {
+    if (!net || !net->finalized) return fail(F8_ERR_STATE, "f8_net_run_u8: not finalized");
+    if (!images) return fail(F8_ERR_INVALID, "f8_net_run_u8: null pointer");
+    const Tensor& in = net->tensors[net->nodes[0].out];
+    if (in.C > 3 && normalize) return fail(F8_ERR_UNSUPPORTED, "f8_net_run_u8: mean / std are given for 3 channels");
+    const int sgn = input_sign(net, "f8_net_run_u8");
+    if (sgn < 0) return sgn;
+    // The decoder-side pipeline of the reference, per pixel value k of channel c, in the float32 operations torch executes
+    // (fix_train.py:299-329 transforms.ToTensor / Normalize, then :683-692):
+    //   t = float(k) / 255                        ToTensor
+    //   normalize == 0:  x_int = round_half_even(255 * t)                  (== k; fraclen 8)
+    //   normalize != 0:  t = (t - mean[c]) / std[c];  x_int = clamp(round_half_even(t * 2^fl), +-127 or [0,255])   (fix_quant)
+    // A uint8 has 256 values: the whole pipeline is a 3 x 256 table built here on the host (IEEE single precision, one
+    // rounding per operation as in torch) and looked up inside the input kernel.
+    if (normalize) {
+        if (!mean || !stdv) return fail(F8_ERR_INVALID, "f8_net_run_u8: normalize needs mean and std");
+        if (in.fl < 0 || in.fl > (sgn ? 7 : 8)) return fail(F8_ERR_INVALID, "f8_net_run_u8: input fraclen %d outside [0,%d]", in.fl, sgn ? 7 : 8);
+        for (int c = 0; c < 3; ++c) if (!(stdv[c] != 0.f)) return fail(F8_ERR_INVALID, "f8_net_run_u8: std[%d] is zero", c);
+    } else if (in.fl != 8 || sgn) {
+        return fail(F8_ERR_INVALID, "f8_net_run_u8: normalize == 0 needs an unsigned input at fraclen 8 (fix_train.py:689-692), net has fl %d %s", in.fl, sgn ? "signed" : "unsigned");
+    }
+    const float scale = (float)(1 << (normalize ? in.fl : 0));
+    const float lo = sgn ? -127.f : 0.f, hi = sgn ? 127.f : 255.f;
+    for (int c = 0; c < 3; ++c)
+        for (int k = 0; k < 256; ++k) {
+            volatile float t = (float)k / 255.0f;              // volatile: one rounding per operation, no contraction / excess precision
+            int v;
+            if (!normalize) { volatile float r = 255.0f * t; v = (int)__builtin_rintf(r); }
+            else {
+                volatile float d = t - mean[c];
+                volatile float q = d / stdv[c];
+                volatile float r = q * scale;
+                float rr = __builtin_rintf(r);
+                rr = rr < lo ? lo : (rr > hi ? hi : rr);
+                v = (int)rr;
+            }
+            net->in_lut[c * 256 + k] = (int16_t)v;
+        }
+    net->in_u8 = images; net->in_u8_nhwc = nhwc ? 1 : 0;
+    const int rc = run_common(net, (const int32_t*)images, output, N, stream, nullptr, 0);
+    net->in_u8 = nullptr;
+    return rc;
+}
+
 int f8_net_run_profiled(f8_net* net, const int32_t* input, void* output, int N, void* stream, float* ms, int cap) {
     if (!ms) return fail(F8_ERR_INVALID, "f8_net_run_profiled: null ms");
     return run_common(net, input, output, N, stream, ms, cap);

@@ -94,30 +94,59 @@ class IntModel(nn.Module):
         self.classifier = nn.Sequential(F8Linear(spec.fc_in, spec.num_classes, input_symmetric=spec.fc_signed_in))
         self.int_op_only = True
         self._plans = {}
+        self._pipelined = 0
 
     # -- performance path ------------------------------------------------------------------
-    def plan(self, hw: int, max_batch: int):
-        key = hw
-        net = self._plans.get(key)
-        if net is None or net.max_batch < max_batch:
-            net = build_net(self.spec, self.state_dict(), max_batch, hw)
-            self._plans[key] = net
-        return net
+    def _param_version(self):
+        return tuple((t._version, t.data_ptr()) for t in self.state_dict(keep_vars=True).values())
 
-    def forward(self, x):
+    def plan(self, hw: int, max_batch: int, device=None):
+        """The planned net for hw x hw inputs on `device` (a handle is bound to one device).  Re-planned when the batch
+        capacity grows or any parameter was edited in place since the plan was built."""
+        dev = None if device is None else torch.device(device).index
+        key = (dev, hw)
+        ver = self._param_version()
+        ent = self._plans.get(key)
+        if ent is None or ent[0] != ver or ent[1].max_batch < max_batch:
+            net = build_net(self.spec, self.state_dict(), max_batch, hw)
+            if self._pipelined:
+                net.set_pipelined(self._pipelined)
+            ent = (ver, net)
+            self._plans[key] = ent
+        return ent[1]
+
+    def set_pipelined(self, mode):
+        """Let consecutive forwards overlap inside the library (f8_net_set_pipelined; 2 = two whole batches in flight).
+        CONTRACT (include/f8net.h): a run then no longer waits for work queued on the stream after the PREVIOUS run's entry.
+        `forward` / `forward_f32` therefore refuse to allocate in this mode: pass `out=` (buffers that rotate with at least the
+        pipeline depth) and hand over inputs produced on another stream with `input_ready=` (an event recorded behind the
+        producer); inputs produced on the current stream must have been complete one call earlier."""
+        self._pipelined = 2 if mode in (2, 'alternate') else int(bool(mode))
+        for _, net in self._plans.values():
+            net.set_pipelined(self._pipelined)
+
+    def _check_pipelined(self, out):
+        if self._pipelined and out is None:
+            raise ValueError('IntModel: pipelined mode needs a caller-owned, rotating `out=` buffer (a fresh allocation could recycle a block '
+                             'that an in-flight run still writes); see IntModel.set_pipelined')
+
+    def forward(self, x, out=None, input_ready=None):
         if not hasattr(x, 'output_fraclen'):
             raise ValueError('IntModel.forward: input must carry `output_fraclen` (fix_train.py:687,692)')
         head_fl = int(self.head[0].input_fraclen.item())
         if x.output_fraclen != head_fl:
             raise ValueError(f'input output_fraclen {x.output_fraclen} != head.input_fraclen {head_fl}')
         assert x.shape[2] == x.shape[3], 'square inputs'
-        return self.plan(int(x.shape[2]), int(x.shape[0])).run(x.contiguous())
+        self._check_pipelined(out)
+        return self.plan(int(x.shape[2]), int(x.shape[0]), x.device).run(x.contiguous(), out=out, input_ready=input_ready)
 
-    def forward_f32(self, images, normalize=False):
+    def forward_f32(self, images, normalize=False, out=None, input_ready=None):
         """forward_loss's input quantisation (fix_train.py:683-692) fused into the input kernel: `images` is the
         float32 batch the data loader yields; no int32 copy of it is ever written."""
         assert images.shape[2] == images.shape[3], 'square inputs'
-        return self.plan(int(images.shape[2]), int(images.shape[0])).run_f32(images.contiguous(), normalize)
+        self._check_pipelined(out)
+        return self.plan(int(images.shape[2]), int(images.shape[0]), images.device).run_f32(images.contiguous(), normalize, out=out,
+                                                                                              input_ready=input_ready)
 
     def forward_integize(self, x):
         """The reference's float-carried evaluation of the IntModel — the branches taken when `int_op_only` is unset

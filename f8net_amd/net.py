@@ -153,8 +153,24 @@ class F8Net:
         if not (1 <= x.shape[0] <= self.max_batch):
             raise ValueError(f'F8Net.run: batch {x.shape[0]} outside [1,{self.max_batch}]')
 
-    def run(self, x, out=None):
-        """x: int32 CUDA tensor [N,C,H,W] (reference input format).  Returns [N, out_elems]."""
+    def set_option(self, key, value):
+        """Per-handle tuning option (f8_net_set_option; keys in include/f8net.h).  Planning keys before finalize()."""
+        check(self._L.f8_net_set_option(self._h, key.encode(), int(value)))
+        return self
+
+    def get_option(self, key):
+        v = ctypes.c_int(0)
+        check(self._L.f8_net_get_option(self._h, key.encode(), ctypes.byref(v)))
+        return v.value
+
+    def _input_ready(self, ev):
+        """One-shot: the next run also waits for `ev` (a torch.cuda.Event recorded behind the producer of its input)."""
+        if ev is not None:
+            check(self._L.f8_net_set_input_ready(self._h, ctypes.c_void_p(ev.cuda_event)))
+
+    def run(self, x, out=None, input_ready=None):
+        """x: int32 CUDA tensor [N,C,H,W] (reference input format).  Returns [N, out_elems].
+        input_ready: torch.cuda.Event recorded behind the producer of `x` when that is another stream (pipelined callers)."""
         import torch
         self._check_input(x)
         N = x.shape[0]
@@ -163,6 +179,7 @@ class F8Net:
                               device=x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         with torch.cuda.device(x.device):
+            self._input_ready(input_ready)
             check(self._L.f8_net_run(self._h, x.data_ptr(), out.data_ptr(), N, ctypes.c_void_p(stream)))
         return out
 
@@ -181,7 +198,7 @@ class F8Net:
         mode = 2 if on in (2, 'alternate') else int(bool(on))
         check(self._L.f8_net_set_pipelined(self._h, mode))
 
-    def run_f32(self, images, normalize, out=None):
+    def run_f32(self, images, normalize, out=None, input_ready=None):
         """images: float32 CUDA tensor [N,C,H,W] as forward_loss receives them (fix_train.py:676-692); the input
         quantisation runs inside the input kernel.  normalize: FLAGS.normalize of the reference."""
         import torch
@@ -199,8 +216,35 @@ class F8Net:
                               device=images.device)
         stream = torch.cuda.current_stream(images.device).cuda_stream
         with torch.cuda.device(images.device):
+            self._input_ready(input_ready)
             check(self._L.f8_net_run_f32(self._h, images.data_ptr(), int(bool(normalize)), out.data_ptr(), N,
                                          ctypes.c_void_p(stream)))
+        return out
+
+    def run_u8(self, images, normalize=False, mean=None, std=None, nhwc=False, out=None, input_ready=None):
+        """images: uint8 CUDA tensor, NCHW [N,3,H,W] (or NHWC [N,H,W,3] with nhwc=True) as a decoder yields them; ToTensor /
+        Normalize(mean, std) / the input quantisation of forward_loss are a table lookup inside the input kernel (f8_net_run_u8)."""
+        import torch
+        if not images.is_cuda:
+            raise ValueError('F8Net.run_u8: input must be a CUDA/HIP tensor (there is no CPU path)')
+        if images.dtype != torch.uint8 or not images.is_contiguous():
+            raise ValueError('F8Net.run_u8: input must be contiguous uint8')
+        C, H, W = self.in_shape
+        want = (H, W, C) if nhwc else (C, H, W)
+        if tuple(images.shape[1:]) != want:
+            raise ValueError(f'F8Net.run_u8: input shape {tuple(images.shape)} != [N,{want}]')
+        N = images.shape[0]
+        if not (1 <= N <= self.max_batch):
+            raise ValueError(f'F8Net.run_u8: batch {N} outside [1,{self.max_batch}]')
+        if out is None:
+            out = torch.empty((N, self.out_elems), dtype=torch.float32 if self.out_float else torch.int32, device=images.device)
+        m = (ctypes.c_float * 3)(*[float(v) for v in mean]) if mean is not None else None
+        s = (ctypes.c_float * 3)(*[float(v) for v in std]) if std is not None else None
+        stream = torch.cuda.current_stream(images.device).cuda_stream
+        with torch.cuda.device(images.device):
+            self._input_ready(input_ready)
+            check(self._L.f8_net_run_u8(self._h, images.data_ptr(), int(bool(nhwc)), int(bool(normalize)), m, s, out.data_ptr(), N,
+                                        ctypes.c_void_p(stream)))
         return out
 
     def run_profiled(self, x, out=None):
@@ -225,9 +269,18 @@ def _fl(params, key, name):
 
 
 def build_net(spec: topology.NetSpec, params: dict, max_batch: int, hw: int = 224,
-              input_fraclen=None) -> F8Net:
+              input_fraclen=None, options=None) -> F8Net:
     """Record IntModel.forward for `spec` with exported parameters `params` (numpy or torch-cpu
-    tensors keyed like the reference state_dict) and plan it for batches up to max_batch."""
+    tensors keyed like the reference state_dict) and plan it for batches up to max_batch.
+    options: {key: value} for f8_net_set_option, applied before planning."""
+    net = record_net(spec, params, hw, input_fraclen)
+    for k, v in (options or {}).items():
+        net.set_option(k, v)
+    return net.finalize(max_batch)
+
+
+def record_net(spec: topology.NetSpec, params: dict, hw: int = 224, input_fraclen=None) -> F8Net:
+    """The recording half of build_net: the graph is in the handle, not yet planned (set planning options, then finalize)."""
     params = {k: (v.detach().cpu().numpy() if hasattr(v, 'detach') else np.asarray(v)) for k, v in params.items()}
     net = F8Net()
     head_in_fl = _fl(params, spec.head.key, 'input_fraclen')
@@ -265,4 +318,4 @@ def build_net(spec: topology.NetSpec, params: dict, max_batch: int, hw: int = 22
     t = net.linear(t, params[k + '.weight'], params[k + '.bias'], weight_fl=_fl(params, k, 'weight_fraclen'),
                    input_fl=_fl(params, k, 'input_fraclen'), input_signed=spec.fc_signed_in, label=k)
     net.output(t, as_float=True)                                 # `.float()`, fix_resnet.py:383
-    return net.finalize(max_batch)
+    return net

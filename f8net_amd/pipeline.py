@@ -21,7 +21,7 @@ def _stream(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
-def quantize_input(images, head_input_fraclen=None, input_symmetric=False, normalize=False):
+def quantize_input(images, head_input_fraclen=None, input_symmetric=False, normalize=False, check_input=False):
     """fix_train.py:683-692 as an op: float32 CUDA images -> int32 tensor tagged `.output_fraclen`.
 
     normalize False: (255 * x).round_().int(), fraclen 8 (the reference asserts x >= 0; so do we).
@@ -37,7 +37,8 @@ def quantize_input(images, head_input_fraclen=None, input_symmetric=False, norma
             raise ValueError('quantize_input: normalize=True needs the head conv input_fraclen')
         fl = int(head_input_fraclen)
     else:
-        assert torch.all(x >= 0)      # fix_train.py:689
+        if check_input:               # fix_train.py:689 `assert torch.all(input >= 0)`: a device -> host sync per batch, so opt-in
+            assert torch.all(x >= 0)
         fl = 8
     with torch.cuda.device(x.device):
         check(_lib.lib().f8_quantize_input_f32(x.data_ptr(), out.data_ptr(), x.numel(), int(bool(normalize)), fl,
@@ -62,14 +63,16 @@ def topk_correct(output, target, topk=(1, 5)):
     return correct
 
 
-def forward_loss(model, images, target, topk=(1, 5), normalize=False, distributed_all_reduce=False, group=None):
+def forward_loss(model, images, target, topk=(1, 5), normalize=False, distributed_all_reduce=False, group=None, check_input=False):
     """One evaluation step of the reference (fix_train.py:676-718) around an f8net_amd IntModel.
 
     Returns (output, top-k error lists): `errors[k]` = list of per-sample 1 - correct_k, after the reference's
     all-reduce-and-divide over ranks when `distributed_all_reduce` (each rank then holds the rank-mean of the flags at
     each batch position, exactly what `meter[...].cache_list` receives in the reference)."""
-    if not normalize:
-        assert torch.all(images >= 0)                  # fix_train.py:689
+    if check_input and not normalize:
+        # fix_train.py:689 asserts this on every batch; here it would be a device -> host synchronisation in front of every
+        # forward (it serialises the pipelined schedule), so it is opt-in.  Out-of-contract (negative) pixels clamp to 0.
+        assert torch.all(images >= 0)
     output = model.forward_f32(images, normalize=normalize)
     correct = topk_correct(output, target, topk)
     res = correct.reshape(-1)

@@ -61,7 +61,7 @@ def rand_normal_int(seed: int, key: str, shape, sigma: float) -> np.ndarray:
 
 
 def make_params(spec: topology.NetSpec, seed: int = 1234, fraclens=None,
-                w_sigma: float = 24.0) -> dict:
+                w_sigma: float = 24.0, auto_range: bool = False) -> dict:
     """Exported-IntModel-shaped parameter dict (numpy int32), keys as `state_dict()`.
 
     fraclens: optional {key: (input_fl, weight_fl)}; missing keys get seeded draws
@@ -72,6 +72,18 @@ def make_params(spec: topology.NetSpec, seed: int = 1234, fraclens=None,
     p = {}
     layers = [(c.key, (c.cout, c.cin // c.groups, c.k, c.k), c.signed_in) for c in spec.convs()]
     layers.append((spec.fc_key, (spec.num_classes, spec.fc_in), spec.fc_signed_in))
+    # auto_range (real fraclen tables whose formats assume TRAINED weight magnitudes, e.g. MobileNet-V2's unsigned fraclen-8
+    # project inputs): the weight spread of a layer is chosen so that its accumulators, requantised into the NEXT layer's
+    # format, land mid-range instead of saturating every value: sigma = 48 * 2^n / (x_rms * sqrt(fan)), n = the next requant shift
+    nxt = {}
+    if auto_range:
+        seq = [spec.head.key]
+        for b in spec.blocks:
+            seq.extend(c.key for c in b.body)
+        if spec.tail is not None:
+            seq.append(spec.tail.key)
+        seq.append(spec.fc_key)
+        nxt = {a: b for a, b in zip(seq, seq[1:])}
     for key, wshape, signed in layers:
         if key in fraclens:
             in_fl, w_fl = fraclens[key]
@@ -85,13 +97,32 @@ def make_params(spec: topology.NetSpec, seed: int = 1234, fraclens=None,
         # keep accumulators well inside int32 and outputs in a useful dynamic range:
         # depthwise layers (fan 9) get wider weights, as in the reference's logs (w_fl 0..1 there)
         sig = w_sigma if fan > 16 else 40.0
+        b_sigma = 0.5 * 2.0 ** (in_fl + w_fl)
+        if auto_range and key in nxt and nxt[key] in fraclens:
+            n = in_fl + w_fl - fraclens[nxt[key]][0] + (6 if nxt[key] == spec.fc_key else 0)
+            acc = 48.0 * 2.0 ** n / (30.0 if nxt[key] == spec.fc_key else 1.0)      # avg-pool: sum of 49 mostly positive values
+            sig = float(min(45.0, max(1.5, acc / (56.0 * fan ** 0.5))))
+            b_sigma = 0.25 * sig * 56.0 * fan ** 0.5
         w = np.clip(rand_normal_int(seed, key + '/w', wshape, sig), -127, 127)
-        b = rand_normal_int(seed, key + '/b', (wshape[0],), 0.5 * 2.0 ** (in_fl + w_fl))
+        b = rand_normal_int(seed, key + '/b', (wshape[0],), b_sigma)
         p[key + '.weight'] = w.astype(np.int32)
         p[key + '.bias'] = b.astype(np.int32)
         p[key + '.weight_fraclen'] = np.array(w_fl, dtype=np.int32)
         p[key + '.input_fraclen'] = np.array([in_fl], dtype=np.int32)
     return p
+
+
+def reference_params(spec: topology.NetSpec, seed: int = 1234) -> dict:
+    """Parameters on the reference's own learned fraclen table where its logs hold one (ResNet-50: NVIDIA-pretrained run;
+    MobileNet-V2: the mbv2_fix_quant log, with range-matched weights), seeded draws otherwise.  What the net goldens,
+    `bench.py` and the full-size tests use."""
+    fr = topology.real_fraclens(spec.arch)
+    if fr is not None and not spec.normalize:
+        # the exporter pins the head of a non-normalised net to unsigned 0..255 at fraclen 8 (fix_quant_ops.py:486-488; the
+        # MobileNet-V2 log predates that code and prints 6): IntModel.forward feeds the head conv without requantising
+        fr = dict(fr)
+        fr[spec.head.key] = (8, fr[spec.head.key][1])
+    return make_params(spec, seed=seed, fraclens=fr, auto_range=(spec.arch == 'mobilenet_v2'))
 
 
 def make_input(spec: topology.NetSpec, params: dict, n: int, hw: int = 224, seed: int = 1) -> tuple:

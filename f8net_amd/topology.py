@@ -184,3 +184,24 @@ for _tok in _r50_raw.split():
     _k, _v = _tok.split(':')
     _a, _b = _v.split('/')
     R50_NVIDIA_FRACLENS[_expand_short_key(_k)] = (int(_a), int(_b))
+
+
+# Learned fraction lengths of the reference's MobileNet-V2 run, as printed in its committed log
+# (`/root/reference/fraclen_visual/mbv2_fix_quant.out:1267-1901`; input_fl rounded as `int_conv` does,
+# fix_quant_ops.py:695-699).  Depthwise layers sit at 8/0, 8/1, 8/6, project convs read unsigned fraclen-8 inputs: requant
+# shifts up to 11 (avg-pool -> classifier) and unsigned `input_fl = 8` on non-head layers.  BASELINE config C3.
+MBV2_LOG_FRACLENS = {}
+_mbv2_raw = """head.0:6/7 s0l0b0:8/0 s0l0b1:1/7 s1l0b0:1/7 s1l0b1:4/7 s1l0b2:8/7 s1l1b0:7/5 s1l1b1:6/7 s1l1b2:8/7 s2l0b0:7/7
+s2l0b1:8/0 s2l0b2:7/7 s2l1b0:6/7 s2l1b1:6/7 s2l1b2:8/7 s2l2b0:6/7 s2l2b1:6/7 s2l2b2:8/7 s3l0b0:6/7 s3l0b1:6/7 s3l0b2:8/7
+s3l1b0:6/7 s3l1b1:6/7 s3l1b2:8/7 s3l2b0:6/7 s3l2b1:8/0 s3l2b2:6/7 s3l3b0:6/7 s3l3b1:6/7 s3l3b2:8/7 s4l0b0:6/7 s4l0b1:6/7
+s4l0b2:8/7 s4l1b0:7/7 s4l1b1:8/1 s4l1b2:8/7 s4l2b0:7/7 s4l2b1:8/1 s4l2b2:8/7 s5l0b0:7/7 s5l0b1:8/7 s5l0b2:8/7 s5l1b0:7/7
+s5l1b1:8/6 s5l1b2:8/7 s5l2b0:7/7 s5l2b1:8/0 s5l2b2:7/7 s6l0b0:7/7 s6l0b1:8/6 s6l0b2:8/7 tail.0:6/7 fc.0:8/7"""
+for _tok in _mbv2_raw.split():
+    _k, _v = _tok.split(':')
+    _a, _b = _v.split('/')
+    MBV2_LOG_FRACLENS['tail.0' if _k == 'tail.0' else _expand_short_key(_k)] = (int(_a), int(_b))
+
+
+def real_fraclens(arch: str):
+    """The reference's own learned (input_fl, weight_fl) table for `arch`, where its logs hold one (else None)."""
+    return {'resnet50': R50_NVIDIA_FRACLENS, 'mobilenet_v2': MBV2_LOG_FRACLENS}.get(arch)

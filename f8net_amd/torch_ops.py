@@ -1,0 +1,223 @@
+"""`torch.ops.f8net.*`: the C ABI of libf8net.so registered with the PyTorch dispatcher (torch.library).
+
+The reference has no operator registry — its integer path is plain `nn.Module` composition — so these are the
+"CUDAExtension-style" ops BASELINE.json's north_star asks for: each schema names one reference call site and its CUDA (HIP)
+implementation ends in one `f8_*` entry point of include/f8net.h; `Meta` implementations give shapes, so the ops trace under
+`torch.compile` / FakeTensor.  There is no CPU implementation: calling an op on CPU tensors raises NotImplementedError from
+the dispatcher.
+
+    f8net::requant(x, fl, input_fl, signed)          int_op_only_fix_quant            fix_quant_ops.py:90-114
+    f8net::relu_(x)                                  nn.ReLU(inplace) on int32        fix_resnet.py:39,77
+    f8net::add_align_(res, x, res_fl, x_fl)          residual align-add-clamp         fix_resnet.py:40-54
+    f8net::conv2d(x, w, b, stride, pad, groups, weight_fl, input_fl, input_signed)    `layer_(res)`, int nn.Conv2d of int_conv :680-714
+    f8net::linear(x, w, b, weight_fl, input_fl, input_signed)                         `self.classifier(x)`, int_fc :1165-1195
+    f8net::avgpool_sum(x)                            FXQAvgPool2d int branch          fix_quant_ops.py:126-134
+    f8net::maxpool(x, k, stride, pad)                head max-pool                    fix_resnet.py:358-359
+    f8net::net_forward(x, handle)                    IntModel.forward                 fix_resnet.py:352-383 (handle: register_net)
+    f8net::net_forward_f32(images, handle, normalize)  forward_loss input quantisation + IntModel.forward, fix_train.py:683-692
+
+conv2d / linear plan a one-node net per (weight tensor, its in-place version, geometry, input shape, device) and cache it
+(LRU); `F8Conv2d` / `F8Linear` / the pool modules in ops.py call these ops, so everything above the C ABI goes through the
+dispatcher.
+"""
+import collections
+import ctypes
+import weakref
+
+import torch
+from torch.library import Library
+
+from . import _lib
+from ._lib import check
+from .net import F8Net
+
+_DEF = Library('f8net', 'DEF')
+_DEF.define('requant(Tensor x, int fl, int input_fl, bool signed) -> Tensor')
+_DEF.define('relu_(Tensor(a!) x) -> Tensor(a!)')
+_DEF.define('add_align_(Tensor(a!) res, Tensor x, int res_fl, int x_fl) -> Tensor(a!)')
+_DEF.define('conv2d(Tensor x, Tensor weight, Tensor? bias, int stride, int pad, int groups, int weight_fl, int input_fl, bool input_signed) -> Tensor')
+_DEF.define('linear(Tensor x, Tensor weight, Tensor? bias, int weight_fl, int input_fl, bool input_signed) -> Tensor')
+_DEF.define('avgpool_sum(Tensor x) -> Tensor')
+_DEF.define('maxpool(Tensor x, int k, int stride, int pad) -> Tensor')
+_DEF.define('net_forward(Tensor x, int handle) -> Tensor')
+_DEF.define('net_forward_f32(Tensor images, int handle, bool normalize) -> Tensor')
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _i32(t, who):
+    if t.dtype != torch.int32:
+        raise TypeError(f'f8net::{who}: expects int32, got {t.dtype}')
+
+
+# ------------------------------------------------------------------------------------------ element-wise ops
+def _requant(x, fl, input_fl, signed):
+    _i32(x, 'requant')
+    x = x.contiguous()
+    res = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().f8_requant_i32(x.data_ptr(), res.data_ptr(), x.numel(), int(input_fl), int(fl), int(bool(signed)), _stream(x)))
+    return res
+
+
+def _relu_(x):
+    _i32(x, 'relu_')
+    assert x.is_contiguous()
+    with torch.cuda.device(x.device):
+        check(_lib.lib().f8_relu_i32(x.data_ptr(), x.numel(), _stream(x)))
+    return x
+
+
+def _add_align_(res, x, res_fl, x_fl):
+    _i32(res, 'add_align_')
+    _i32(x, 'add_align_')
+    assert res.shape == x.shape and res.is_contiguous() and x.is_contiguous()
+    with torch.cuda.device(res.device):
+        check(_lib.lib().f8_add_align_i32(res.data_ptr(), x.data_ptr(), res.numel(), int(res_fl), int(x_fl), None, _stream(res)))
+    return res
+
+
+# ------------------------------------------------------------------------------------------ one-node nets (LRU)
+class _PlanCache:
+    def __init__(self, cap=512):
+        self.cap = cap
+        self.d = collections.OrderedDict()
+
+    def get(self, key, tensors, n, build):
+        """key: hashable geometry; tensors: the parameter tensors the plan snapshots (identity + in-place version checked)."""
+        ent = self.d.get(key)
+        ver = tuple(None if t is None else (t._version, t.data_ptr()) for t in tensors)
+        if ent is not None:
+            refs, ever, net = ent
+            same = all((r is None and t is None) or (r is not None and r() is t) for r, t in zip(refs, tensors))
+            if same and ever == ver and net.max_batch >= n:
+                self.d.move_to_end(key)
+                return net
+        net = build(max(n, 1))
+        self.d[key] = (tuple(None if t is None else weakref.ref(t) for t in tensors), ver, net)
+        self.d.move_to_end(key)
+        while len(self.d) > self.cap:
+            self.d.popitem(last=False)
+        return net
+
+
+_plans = _PlanCache()
+
+
+def _np(t):
+    return None if t is None else t.detach().cpu().numpy()
+
+
+def _conv2d(x, weight, bias, stride, pad, groups, weight_fl, input_fl, input_signed):
+    _i32(x, 'conv2d')
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    key = ('conv', x.device.index, C, H, W, id(weight), None if bias is None else id(bias), stride, pad, groups, weight_fl, input_fl, bool(input_signed))
+
+    def build(n):
+        net = F8Net()
+        t = net.input(C, H, W, input_fl)
+        t = net.conv(t, _np(weight), _np(bias), stride=stride, pad=pad, groups=groups, weight_fl=weight_fl, input_fl=input_fl,
+                     input_signed=input_signed, quant_input=False, relu=False)
+        net.output(t, as_float=False)
+        return net.finalize(n)
+
+    net = _plans.get(key, (weight, bias), N, build)
+    k = weight.shape[2]
+    P, Q = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    return net.run(x).view(N, weight.shape[0], P, Q)
+
+
+def _linear(x, weight, bias, weight_fl, input_fl, input_signed):
+    _i32(x, 'linear')
+    N, C = x.shape[0], weight.shape[1]
+    x4 = x.contiguous().view(N, C, 1, 1)
+    key = ('fc', x.device.index, C, id(weight), None if bias is None else id(bias), weight_fl, input_fl, bool(input_signed))
+
+    def build(n):
+        net = F8Net()
+        t = net.input(C, 1, 1, input_fl)
+        t = net.linear(t, _np(weight), _np(bias), weight_fl=weight_fl, input_fl=input_fl, input_signed=input_signed, quant_input=False)
+        net.output(t, as_float=False)
+        return net.finalize(n)
+
+    return _plans.get(key, (weight, bias), N, build).run(x4)
+
+
+def _avgpool_sum(x):
+    _i32(x, 'avgpool_sum')
+    x = x.contiguous()
+    N, C, H, W = x.shape
+
+    def build(n):
+        net = F8Net()
+        t = net.input(C, H, W, 0)
+        t = net.avgpool_sum(t, 0)
+        net.output(t, as_float=False)
+        return net.finalize(n)
+
+    return _plans.get(('avg', x.device.index, C, H, W), (), N, build).run(x)
+
+
+def _maxpool(x, k, stride, pad):
+    _i32(x, 'maxpool')
+    x = x.contiguous()
+    N, C, H, W = x.shape
+
+    def build(n):
+        net = F8Net()
+        t = net.input(C, H, W, 0)
+        t = net.maxpool(t, k, stride, pad)
+        net.output(t, as_float=False)
+        return net.finalize(n)
+
+    P, Q = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    return _plans.get(('max', x.device.index, C, H, W, k, stride, pad), (), N, build).run(x).view(N, C, P, Q)
+
+
+# ------------------------------------------------------------------------------------------ whole nets
+_nets = {}
+
+
+def register_net(net: F8Net) -> int:
+    """Make a planned F8Net callable as torch.ops.f8net.net_forward(x, handle).  The registry holds a strong reference until
+    unregister_net(handle)."""
+    h = id(net)
+    _nets[h] = net
+    return h
+
+
+def unregister_net(handle: int):
+    _nets.pop(handle, None)
+
+
+def _net_forward(x, handle):
+    return _nets[handle].run(x.contiguous())
+
+
+def _net_forward_f32(images, handle, normalize):
+    return _nets[handle].run_f32(images.contiguous(), normalize)
+
+
+# ------------------------------------------------------------------------------------------ registration
+_CUDA = Library('f8net', 'IMPL', 'CUDA')
+for _n, _f in (('requant', _requant), ('relu_', _relu_), ('add_align_', _add_align_), ('conv2d', _conv2d), ('linear', _linear),
+               ('avgpool_sum', _avgpool_sum), ('maxpool', _maxpool), ('net_forward', _net_forward), ('net_forward_f32', _net_forward_f32)):
+    _CUDA.impl(_n, _f)
+
+_META = Library('f8net', 'IMPL', 'Meta')
+_META.impl('requant', lambda x, fl, input_fl, signed: torch.empty_like(x))
+_META.impl('relu_', lambda x: x)
+_META.impl('add_align_', lambda res, x, res_fl, x_fl: res)
+_META.impl('conv2d', lambda x, w, b, stride, pad, groups, wfl, ifl, sgn: x.new_empty(
+    (x.shape[0], w.shape[0], (x.shape[2] + 2 * pad - w.shape[2]) // stride + 1, (x.shape[3] + 2 * pad - w.shape[3]) // stride + 1)))
+_META.impl('linear', lambda x, w, b, wfl, ifl, sgn: x.new_empty((x.shape[0], w.shape[0])))
+_META.impl('avgpool_sum', lambda x: x.new_empty((x.shape[0], x.shape[1])))
+_META.impl('maxpool', lambda x, k, stride, pad: x.new_empty(
+    (x.shape[0], x.shape[1], (x.shape[2] + 2 * pad - k) // stride + 1, (x.shape[3] + 2 * pad - k) // stride + 1)))
+_META.impl('net_forward', lambda x, handle: x.new_empty((x.shape[0], _nets[handle].out_elems),
+                                                        dtype=torch.float32 if _nets[handle].out_float else torch.int32))
+_META.impl('net_forward_f32', lambda x, handle, normalize: x.new_empty((x.shape[0], _nets[handle].out_elems),
+                                                                      dtype=torch.float32 if _nets[handle].out_float else torch.int32))

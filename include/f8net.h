@@ -178,6 +178,17 @@ int f8_net_run(f8_net* net, const int32_t* input_dev, void* output_dev, int N, v
  * images_dev: float32 NCHW [N,C,H,W].  F8_ERR_INVALID if normalize == 0 and the net's input fraclen is not 8. */
 int f8_net_run_f32(f8_net* net, const float* images_dev, int normalize, void* output_dev, int N, void* stream);
 
+/* Same net, fed with the uint8 pixels a decoder produces (1 byte per pixel and channel instead of 4): the reference's
+ * `transforms.ToTensor()` [+ `transforms.Normalize(mean, std)`] (fix_train.py:299-329) and the input quantisation of
+ * forward_loss (fix_train.py:683-692) are folded into a 3 x 256 table (built per call on the host in the float32 operations
+ * torch executes, so the integers are the reference's bit for bit) that the input kernel looks up while it lays the image out
+ * for the head conv.  images_dev: uint8, NCHW [N,3,H,W] (nhwc == 0) or NHWC [N,H,W,3] (nhwc != 0).
+ * normalize == 0: x_int = the pixel value, fraclen 8 (needs an unsigned head at fraclen 8); mean / std ignored (may be NULL).
+ * normalize != 0: x_int = clamp(round_half_even(((k / 255 - mean[c]) / std[c]) * 2^fl)), fl = the head's input fraclen;
+ *                 mean, std: host float[3]. */
+int f8_net_run_u8(f8_net* net, const uint8_t* images_dev, int nhwc, int normalize, const float* mean, const float* std,
+                  void* output_dev, int N, void* stream);
+
 /* Optional measured tile selection: times every implicit-GEMM convolution launch of a sub-batch of an N-image run on
  * the current device with each tile shape that has a kernel instance (HIP events on `stream`) and keeps the fastest; a
  * tile only replaces the planner's choice for a > 3 % win.  Outputs are bit-identical for every tile.  Blocks until

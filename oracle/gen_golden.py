@@ -151,9 +151,9 @@ def child_model(arch):
     assert bool(mods[spec.fc_key].input_symmetric) == spec.fc_signed_in
 
     out = {}
-    fr = topology.R50_NVIDIA_FRACLENS if arch == 'resnet50' else None
     for seed in (1234,):
-        params = synth.make_params(spec, seed=seed, fraclens=fr)
+        # the reference's own learned fraclen tables where its logs hold one (ResNet-50 NVIDIA run, MobileNet-V2 log)
+        params = synth.reference_params(spec, seed=seed)
         # overwrite the exported layers in place with our integers
         with torch.no_grad():
             for key in spec.layer_keys():
@@ -417,6 +417,20 @@ def child_ops():
     fl = torch.tensor([5], dtype=torch.int32)
     q = (fix_quant(torch.from_numpy(xn.copy()), 8, fl * 1.0, 1, True)[0] * (2 ** fl)).int()
     out['inq/xn'], out['inq/s8_fl5'] = xn, q.numpy()
+    # --- the same from the decoder's uint8 pixels: torchvision is absent, so the tensor statements of
+    #     transforms.ToTensor (`img.to(float32).div(255)`) and transforms.Normalize (`tensor.sub_(mean).div_(std)`),
+    #     fix_train.py:299-329, are executed as written on torch; every pixel value occurs in every channel
+    u8 = np.concatenate([np.tile(np.arange(256, dtype=np.uint8).reshape(1, 1, 16, 16), (1, 3, 1, 1)),
+                         synth.rand_uniform_int(52, 'u8img', (1, 3, 16, 16), 0, 255).astype(np.uint8)])
+    t = torch.from_numpy(u8.copy()).to(dtype=torch.float32).div(255)
+    out['inq8/u8'] = u8
+    out['inq8/plain'] = (255 * t.clone()).round_().int().numpy()                   # fix_train.py:689-692
+    tn = t.clone()
+    tn.sub_(torch.from_numpy(mean)).div_(torch.from_numpy(std))
+    out['inq8/mean'], out['inq8/std'] = mean.reshape(3), std.reshape(3)
+    for fl8 in (4, 5, 6):
+        flt = torch.tensor([fl8], dtype=torch.int32)
+        out[f'inq8/s8_fl{fl8}'] = (fix_quant(tn.clone(), 8, flt * 1.0, 1, True)[0] * (2 ** flt)).int().numpy()   # fix_train.py:683-687
     # --- scoring (fix_train.py:697-704; fix_train.py itself cannot be imported here — torchvision / pytorchcv are absent —
     #     so its five tensor statements are executed as written, on torch, with FLAGS.topk = [1, 5])
     logits = synth.rand_normal_int(61, 'logits', (12, 40), 3.0e4).astype(np.float32)      # integer-valued, like int_op_only logits

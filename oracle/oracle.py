@@ -226,6 +226,20 @@ def quantize_input_u8(img01):
     return np.rint(255.0 * np.asarray(img01, dtype=np.float32)).astype(np.int32), 8
 
 
+def quantize_input_pixels(u8, normalize=False, mean=None, std=None, head_in_fl=None, signed=True):
+    """The decoder-side pipeline on uint8 pixels NCHW: transforms.ToTensor (`to(float32).div(255)`) [+ transforms.Normalize
+    (`sub_(mean).div_(std)`)], fix_train.py:299-329, then the input quantisation of forward_loss, fix_train.py:683-692 — each
+    statement in float32, one rounding per operation."""
+    t = np.asarray(u8).astype(np.float32) / np.float32(255.0)
+    if not normalize:
+        return np.rint(np.float32(255.0) * t).astype(np.int32), 8
+    m = np.asarray(mean, dtype=np.float32).reshape(1, -1, 1, 1)
+    sd = np.asarray(std, dtype=np.float32).reshape(1, -1, 1, 1)
+    t = (t - m) / sd
+    v = np.rint(t * np.float32(2.0 ** head_in_fl))
+    return (np.clip(v, -127, 127) if signed else np.clip(v, 0, 255)).astype(np.int32), head_in_fl
+
+
 def topk_correct(logits, target, topk=(1, 5)):
     """fix_train.py:697-704: rows of per-sample flags `target in top-k`.  Equal logits rank by lower class index (what a
     stable descending sort gives; torch.topk leaves the order of ties unspecified, tie-free inputs agree exactly)."""

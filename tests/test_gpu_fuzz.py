@@ -104,16 +104,22 @@ def test_resnet_like_random_fraclens(seed):
             if b.shortcut is not None:
                 in_fl = int(base[b.body[0].key + '.input_fraclen'][0])
                 fr[b.shortcut.key] = (in_fl, int(base[b.shortcut.key + '.weight_fraclen']))
-    params = synth.make_params(spec, seed=seed, fraclens=fr)
     n = [1, 2, 3][_rnd(seed, 'n', 0, 2)]
-    x, x_fl = synth.make_input(spec, params, n, 224, seed=seed + 7)
+    # A net cut after an early stage pools a 56x56 / 28x28 map: with full-range weights its sum can exceed 2^32 - 1, where the
+    # reference asserts (fix_quant_ops.py:132).  Every case must RUN, so the weight spread shrinks until the reference accepts.
+    want = None
+    for w_sigma in (24.0, 8.0, 2.5, 1.0):
+        params = synth.make_params(spec, seed=seed, fraclens=fr, w_sigma=w_sigma)
+        x, x_fl = synth.make_input(spec, params, n, 224, seed=seed + 7)
+        try:
+            want = oracle.net_forward(spec, params, x, x_fl)
+            break
+        except AssertionError:
+            continue
+    assert want is not None, 'no weight spread keeps the avg-pool sum inside the range the reference accepts'
     net = build_net(spec, params, max_batch=n, hw=224)
     plan = net.describe()
     if not any(k.startswith('F8_') for k in os.environ):     # default planner (tuning switches change the plan, not the results)
         assert 'fused_bottleneck_R' in plan and 'stem7x7s2+maxpool3x3s2' in plan
     got = net.run(torch.from_numpy(x).to(dev)).cpu().numpy()
-    try:
-        want = oracle.net_forward(spec, params, x, x_fl)
-    except AssertionError as e:          # e.g. the avg-pool sum over a 56x56 map exceeds 2^32-1: the reference asserts there too
-        pytest.skip(f'the reference rejects this data: {e}')
     np.testing.assert_array_equal(got, want, err_msg=plan)

@@ -54,6 +54,38 @@ def test_quantize_input_golden_and_ties(dev, ops):
         pipeline.quantize_input(torch.zeros(4, device=dev), head_input_fraclen=8, input_symmetric=True, normalize=True)   # fl > 7 signed
 
 
+@pytest.mark.parametrize('head', ['stem7x7', 'conv3x3'])
+@pytest.mark.parametrize('normalize,fl', [(False, 8), (True, 4), (True, 5), (True, 6)])
+@pytest.mark.parametrize('nhwc', [False, True])
+def test_uint8_input_entry_matches_reference_pipeline(dev, ops, head, normalize, fl, nhwc):
+    """f8_net_run_u8: uint8 pixels in, ToTensor / Normalize / forward_loss's quantisation as a table lookup
+    inside the input kernel.  The integers the head conv sees must be the ones torch computes from the same pixels (golden
+    `inq8/*`, every pixel value in every channel): the logits equal those of f8_net_run on the golden int32 tensor."""
+    from f8net_amd.net import F8Net
+    u8 = ops['inq8/u8']                                         # [2, 3, 16, 16]
+    ints = ops['inq8/plain'] if not normalize else ops[f'inq8/s8_fl{fl}']
+    k, stride, pad, cout = (7, 2, 3, 64) if head == 'stem7x7' else (3, 2, 1, 32)
+    w = np.clip(synth.rand_normal_int(81, 'u8w' + head, (cout, 3, k, k), 40.0), -127, 127).astype(np.int32)
+    b = synth.rand_normal_int(82, 'u8b', (cout,), 1.0e3).astype(np.int32)
+    net = F8Net()
+    t = net.input(3, 16, 16, fl)
+    t = net.conv(t, w, b, stride=stride, pad=pad, groups=1, weight_fl=6, input_fl=fl, input_signed=normalize, quant_input=False, relu=True)
+    net.output(t, as_float=False)
+    net.finalize(2)
+    want = net.run(torch.from_numpy(ints).to(dev)).cpu().numpy()
+    np.testing.assert_array_equal(want.reshape(2, cout, 8, 8), oracle.relu(oracle.conv2d(ints, w, b, stride, pad)))
+    img = torch.from_numpy(np.ascontiguousarray(u8.transpose(0, 2, 3, 1)) if nhwc else u8).to(dev)
+    got = net.run_u8(img, normalize=normalize, mean=ops['inq8/mean'], std=ops['inq8/std'], nhwc=nhwc).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    if not normalize:                                           # a signed head cannot take raw pixels; an unsigned fraclen-8 head needs no mean / std
+        got = net.run_u8(img, nhwc=nhwc).cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+    else:
+        from f8net_amd import _lib
+        with pytest.raises(_lib.F8Error):
+            net.run_u8(img, normalize=False, nhwc=nhwc)
+
+
 @pytest.mark.parametrize('arch,normalize', [('resnet18', False), ('resnet50', True), ('mobilenet_v2', False)])
 def test_fused_input_quantisation_equals_two_step(dev, arch, normalize):
     """model.forward_f32(images) == model(quantize_input(images)) == oracle on the quantised images, bit for bit."""

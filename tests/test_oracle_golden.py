@@ -80,14 +80,20 @@ def test_pools_add_input(ops):
     np.testing.assert_array_equal(q, ops['inq/u8'])
     q, fl = oracle.quantize_input_normalized(ops['inq/xn'], 5)
     np.testing.assert_array_equal(q, ops['inq/s8_fl5'])
+    # the same from uint8 pixels (every pixel value in every channel): ToTensor / Normalize / fix_quant executed by torch
+    q, fl = oracle.quantize_input_pixels(ops['inq8/u8'])
+    np.testing.assert_array_equal(q, ops['inq8/plain'])
+    assert fl == 8 and np.array_equal(q, ops['inq8/u8'].astype(np.int32))
+    for f in (4, 5, 6):
+        q, fl = oracle.quantize_input_pixels(ops['inq8/u8'], True, ops['inq8/mean'], ops['inq8/std'], f, True)
+        np.testing.assert_array_equal(q, ops[f'inq8/s8_fl{f}'])
 
 
 @pytest.mark.parametrize('arch', ['resnet18', 'resnet50', 'mobilenet_v1', 'mobilenet_v2'])
 def test_whole_net_vs_reference(arch, golden_dir):
     g = np.load(os.path.join(golden_dir, f'net_{arch}.npz'))
     spec = topology.get(arch, normalize=bool(g['normalize']))
-    fr = topology.R50_NVIDIA_FRACLENS if arch == 'resnet50' else None
-    params = synth.make_params(spec, seed=1234, fraclens=fr)
+    params = synth.reference_params(spec, seed=1234)
     for hw, n in ((64, 2), (224, 1)):
         tag = f's1234_hw{hw}_n{n}'
         x, x_fl = synth.make_input(spec, params, n, hw, seed=7)

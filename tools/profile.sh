@@ -1,16 +1,24 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes for bench.py.
-# Output under gpurun_out/prof_<tag>/ ; summaries are post-processed by tools/summarize_prof.py.
-TAG=${1:-r01}
+#   tools/profile.sh <tag> [bench args, e.g. --arch mobilenet_v2 --bs 128]
+# Output under gpurun_out/prof_<tag>/ ; summaries are post-processed by tools/summarize_prof.py (which also checks the stamp).
+TAG=${1:-r02}; shift
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# serialise the two sub-batches: per-kernel durations then match bench.py's live (sequential, HIP-event) measurement
+# serialise the in-flight runs: per-kernel durations then match bench.py's live (sequential, HIP-event) measurement
 export F8_SPLIT_STREAMS=0
-CMD="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+CMD="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline $*"
+echo "$*" > $OUT/bench_args.txt
+python - > $OUT/csrc_sha256.txt <<PY
+import sys; sys.path.insert(0, '$REPO')
+import bench; print(bench.csrc_sha256())
+PY
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
+# counters: their own runs, --pmc only (TCC: FETCH_SIZE and WRITE_SIZE do not fit one pass)
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $CMD > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $CMD > $OUT/pmc_write.log 2>&1
-find $OUT -name "*.csv" | head -20
-ls -la $OUT/*
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_mfma -o pmc -- $CMD > $OUT/pmc_mfma.log 2>&1
+tail -1 $OUT/trace.log > $OUT/bench_line.json
+ls $OUT/*/ | head -20

@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 databases written by tools/profile.sh into the committed summaries:
 
-    python tools/summarize_prof.py gpurun_out/prof_r01 r01
-      -> profiles/rocprof_r01_kernel_stats.md   (rocprofv3 --kernel-trace --stats summary)
-      -> profiles/rocprof_r01_pmc.md            (FETCH_SIZE / WRITE_SIZE per kernel, separate passes)
-      -> profiles/pmc_traffic.json              (HBM bytes per launch per kernel, read by bench.py)
+    python tools/summarize_prof.py gpurun_out/prof_r02 r02 [--main]
+      -> profiles/rocprof_r02_kernel_stats.md   (rocprofv3 --kernel-trace --stats summary)
+      -> profiles/rocprof_r02_pmc.md            (FETCH_SIZE / WRITE_SIZE per kernel, separate passes)
+      -> profiles/rocprof_r02_mfma.md           (INT8 MFMA instructions / busy cycles per kernel)
+      --main: also profiles/pmc_traffic.json and profiles/pmc_mfma.json, which bench.py reads for roofline.traffic /
+              roofline.mfma — both carry the sha256 of the kernel sources that were profiled and the workload; bench.py drops
+              them when either does not match the build it runs.
 
 HBM-byte correction (per /opt/skills/guides/MI355X_MICROARCH.md §HBM): on gfx950 FETCH_SIZE tallies
 128-byte fabric requests at 64 B, i.e. reports half the bytes of wide coalesced reads -> doubled here.
 Calibration on a known byte count in this code base: f8::input_kernel reads 128*3*224*224*4 =
 77.07 MB and FETCH_SIZE reports 38.6 MB.  WRITE_SIZE is taken as reported (KB).
+MFMA: SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of all SIMDs (= 32 x SQ_INSTS_VALU_MFMA_I8 for v_mfma_i32_32x32x32_i8);
+GRBM_GUI_ACTIVE sums the active cycles of the 8 XCDs; busy fraction = busy / (GUI_ACTIVE / 8 x 256 CU x 4 SIMD).
 """
 import json
 import os
@@ -25,14 +30,22 @@ def short(name):
 
 def main():
     src, tag = sys.argv[1], sys.argv[2]
+    is_main = '--main' in sys.argv[3:]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = os.path.join(root, 'profiles')
     os.makedirs(out, exist_ok=True)
+    stamp = open(os.path.join(src, 'csrc_sha256.txt')).read().strip()
+    bargs = open(os.path.join(src, 'bench_args.txt')).read().split()
+    arch = bargs[bargs.index('--arch') + 1] if '--arch' in bargs else 'resnet50'
+    bs = int(bargs[bargs.index('--bs') + 1]) if '--bs' in bargs else 128
+    workload = f'{arch}/bs{bs}'
+    cmd = 'python bench.py --steps 5 --warmup 2 --no-cpu-baseline ' + ' '.join(bargs)
     c = sqlite3.connect(os.path.join(src, 'trace', 'trace_results.db'))
     rows = list(c.execute('select name, total_calls, total_duration, average, percentage from top_kernels'))
     with open(os.path.join(out, f'rocprof_{tag}_kernel_stats.md'), 'w') as f:
-        f.write(f'# rocprofv3 --kernel-trace --stats — `python bench.py --steps 5 --warmup 2 --no-cpu-baseline` ({tag})\n\n')
-        f.write('Durations in microseconds (7 steps + 7 profiled passes = 14 forward passes of ResNet-50, bs 128; every launch covers the whole batch — pipelining mode 2, F8_SPLIT_STREAMS=0 so that no two runs overlap).\n\n')
+        f.write(f'# rocprofv3 --kernel-trace --stats — `{cmd.strip()}` ({tag}, {workload}, kernel sources {stamp[:16]})\n\n')
+        f.write('Durations in microseconds (forward passes of the timed loops + 7 profiled passes; every launch covers the whole batch — '
+                'pipelining mode 2, F8_SPLIT_STREAMS=0 so that no two runs overlap).\n\n')
         f.write('| kernel | calls | total us | avg us | % |\n|---|---:|---:|---:|---:|\n')
         for name, calls, tot, avg, pct in rows:
             f.write(f'| `{short(name)}` | {calls} | {tot:.1f} | {avg:.2f} | {pct:.2f} |\n')
@@ -49,7 +62,7 @@ def main():
         f_kb, w_kb = e.get('FETCH_SIZE_KB_avg', 0.0), e.get('WRITE_SIZE_KB_avg', 0.0)
         e['hbm_bytes_per_launch'] = round(2 * f_kb * 1024 + w_kb * 1024)
     with open(os.path.join(out, f'rocprof_{tag}_pmc.md'), 'w') as f:
-        f.write(f'# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), same command ({tag})\n\n')
+        f.write(f'# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), same command ({tag}, {workload}, kernel sources {stamp[:16]})\n\n')
         f.write('Per-launch averages. `hbm bytes` = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE correction, see '
                 'tools/summarize_prof.py).\n\n| kernel | launches | FETCH_SIZE KB | WRITE_SIZE KB | hbm MB / launch |\n|---|---:|---:|---:|---:|\n')
         for k, e in sorted(traffic.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch']):
@@ -57,9 +70,49 @@ def main():
                 continue
             f.write(f"| `{k}` | {e['launches']} | {e.get('FETCH_SIZE_KB_avg', 0):.0f} | {e.get('WRITE_SIZE_KB_avg', 0):.0f} | "
                     f"{e['hbm_bytes_per_launch'] / 1e6:.1f} |\n")
-    json.dump({k: v for k, v in traffic.items() if k.startswith('f8::')},
-              open(os.path.join(out, 'pmc_traffic.json'), 'w'), indent=1, sort_keys=True)
-    print('wrote', sorted(os.listdir(out)))
+    # ---- MFMA
+    mf = {}
+    db = os.path.join(src, 'pmc_mfma', 'pmc_results.db')
+    if os.path.exists(db):
+        c = sqlite3.connect(db)
+        q = 'select kernel_name, counter_name, count(*), avg(value), sum(value) from counters_collection group by kernel_name, counter_name'
+        for name, cn, n, avg, tot in c.execute(q):
+            k = short(name)
+            if not k.startswith('f8::'):
+                continue
+            e = mf.setdefault(k, {})
+            e[cn] = avg; e[cn + '_sum'] = tot; e['launches'] = n
+        tb = ta = ti = 0.0
+        for k, e in mf.items():
+            act = e.get('GRBM_GUI_ACTIVE', 0.0) / 8.0 * 1024.0
+            e['mfma_busy_frac'] = round(e.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / act, 5) if act else 0.0
+            tb += e.get('SQ_VALU_MFMA_BUSY_CYCLES_sum', 0.0); ta += e.get('GRBM_GUI_ACTIVE_sum', 0.0) / 8.0 * 1024.0
+            ti += e.get('SQ_INSTS_VALU_MFMA_I8_sum', 0.0)
+        passes = max((e['launches'] for k, e in mf.items() if 'input' in k), default=1)      # one input launch per forward pass
+        with open(os.path.join(out, f'rocprof_{tag}_mfma.md'), 'w') as f:
+            f.write(f'# rocprofv3 --pmc SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (own pass), same command ({tag}, {workload}, kernel sources {stamp[:16]})\n\n')
+            f.write('Per-launch averages.  `busy` = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the share of the launch during which a '
+                    'matrix pipe is busy, i.e. the achieved fraction of the INT8 MFMA peak (counter collection lengthens short kernels a little).\n\n')
+            f.write(f'Whole net: busy {100 * tb / ta if ta else 0:.2f} % of the kernel time; {ti / passes / bs:.0f} v_mfma_i32_32x32x32_i8 per image '
+                    f'(x 65536 op = {ti / passes / bs * 65536 / 1e9:.3f} Gop issued per image, halo recompute and tile padding included).\n\n')
+            f.write('| kernel | launches | MFMA_I8 insts | MFMA busy cycles | GUI_ACTIVE | busy |\n|---|---:|---:|---:|---:|---:|\n')
+            for k, e in sorted(mf.items(), key=lambda kv: -kv[1].get('GRBM_GUI_ACTIVE_sum', 0)):
+                f.write(f"| `{k}` | {e['launches']} | {e.get('SQ_INSTS_VALU_MFMA_I8', 0):.4g} | {e.get('SQ_VALU_MFMA_BUSY_CYCLES', 0):.4g} | "
+                        f"{e.get('GRBM_GUI_ACTIVE', 0):.4g} | {100 * e['mfma_busy_frac']:.2f} % |\n")
+        if is_main:
+            json.dump({'csrc_sha256': stamp, 'workload': workload, 'tag': tag, 'whole_net_mfma_busy_frac': round(tb / ta, 5) if ta else None,
+                       'whole_net_mfma_insts_per_img': round(ti / passes / bs, 1),
+                       'kernels': {k: {kk: vv for kk, vv in e.items() if not kk.endswith('_sum')} for k, e in mf.items()}},
+                      open(os.path.join(out, 'pmc_mfma.json'), 'w'), indent=1, sort_keys=True)
+    if is_main:
+        json.dump({'csrc_sha256': stamp, 'workload': workload, 'tag': tag, 'kernels': {k: v for k, v in traffic.items() if k.startswith('f8::')}},
+                  open(os.path.join(out, 'pmc_traffic.json'), 'w'), indent=1, sort_keys=True)
+    line = os.path.join(src, 'bench_line.json')
+    if os.path.exists(line):
+        txt = open(line).read().strip()
+        if txt.startswith('{'):
+            open(os.path.join(out, f'bench_{tag}_under_rocprof.json'), 'w').write(txt + '\n')
+    print('wrote', sorted(f for f in os.listdir(out) if tag in f))
 
 
 if __name__ == '__main__':
