@@ -115,6 +115,12 @@ class IntModel(nn.Module):
             self._plans[key] = ent
         return ent[1]
 
+    def replan(self):
+        """Drop every cached plan.  Plans are re-built automatically after `load_state_dict` and after in-place edits that bump
+        `Tensor._version` (`weight.copy_(...)`, `weight[...] = v`); edits through `.data` have a private version counter and
+        are invisible to that check (fingerprinting 25 M weights on every forward is not an option on this path): call this."""
+        self._plans = {}
+
     def set_pipelined(self, mode):
         """Let consecutive forwards overlap inside the library (f8_net_set_pipelined; 2 = two whole batches in flight).
         CONTRACT (include/f8net.h): a run then no longer waits for work queued on the stream after the PREVIOUS run's entry.

@@ -80,6 +80,17 @@ def _add_align_(res, x, res_fl, x_fl):
 
 
 # ------------------------------------------------------------------------------------------ one-node nets (LRU)
+def _fingerprint(t):
+    """(sum, position-weighted sum) of an integer tensor: `weight.data[...] = v` edits do NOT bump `Tensor._version` (`.data`
+    has its own counter), so the op-level plans are also keyed by content.  Two small reductions per parameter tensor and call:
+    this is the parity path (one launch chain per reference op), not the planned whole-net path."""
+    v = t.detach().reshape(-1).to(torch.int64)
+    if v.numel() == 0:
+        return (0, 0)
+    wgt = torch.arange(1, v.numel() + 1, device=v.device, dtype=torch.int64) % 65521
+    return (int(v.sum().item()), int((v * wgt).sum().item()))
+
+
 class _PlanCache:
     def __init__(self, cap=512):
         self.cap = cap
@@ -88,7 +99,7 @@ class _PlanCache:
     def get(self, key, tensors, n, build):
         """key: hashable geometry; tensors: the parameter tensors the plan snapshots (identity + in-place version checked)."""
         ent = self.d.get(key)
-        ver = tuple(None if t is None else (t._version, t.data_ptr()) for t in tensors)
+        ver = tuple(None if t is None else (t._version, t.data_ptr()) + _fingerprint(t) for t in tensors)
         if ent is not None:
             refs, ever, net = ent
             same = all((r is None and t is None) or (r is not None and r() is t) for r, t in zip(refs, tensors))

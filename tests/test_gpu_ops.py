@@ -298,9 +298,11 @@ def test_stage_opening_block_fused_matches_oracle(dev, variant):
     assert (np.abs(want.astype(np.int64)) > 2**30).any()
 
 
-@pytest.mark.parametrize('H,N', [(56, 2), (16, 3)])
-@pytest.mark.parametrize('variant', ['body_shifts_left', 'shortcut_shifts_left_signed_mid', 'different_input_formats'])
-@pytest.mark.parametrize('tail', ['i32', 'i8', 'both'])
+OPENER_CASES = [(16, 3, v, t) for v in ('body_shifts_left', 'shortcut_shifts_left_signed_mid', 'different_input_formats') for t in ('i32', 'i8', 'both')] + \
+               [(56, 2, 'body_shifts_left', 'both'), (56, 2, 'shortcut_shifts_left_signed_mid', 'both')]      # the full-height map once per fused variant
+
+
+@pytest.mark.parametrize('H,N,variant,tail', OPENER_CASES, ids=lambda v: str(v))
 def test_stage1_opening_block_stride2_fused_matches_oracle(dev, H, N, variant, tail):
     """ResNet-50's stage-1 opening block (256 -> 128 -> 3x3 / 2 -> 512 + strided 1x1 shortcut, 56 wide; fix_resnet.py:26-77) as
     a net of its own: ONE launch (f8_opener.hip) when body.0 and the shortcut read the same int8 form of the block input,
@@ -309,8 +311,6 @@ def test_stage1_opening_block_stride2_fused_matches_oracle(dev, H, N, variant, t
     from f8net_amd import topology
     from f8net_amd.net import F8Net
     Cin, MID, Cout, W = 256, 128, 512, 56
-    if H == 56 and (tail != 'both' or variant == 'different_input_formats'):
-        pytest.skip('the full-height map runs once per fused variant')
     body = [topology.ConvSpec('blk.body.0', Cin, MID, 1, 1, 0, relu=True),
             topology.ConvSpec('blk.body.2', MID, MID, 3, 2, 1, relu=True),
             topology.ConvSpec('blk.body.4', MID, Cout, 1, 1, 0)]

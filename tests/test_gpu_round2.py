@@ -65,8 +65,12 @@ def test_module_weight_edit_replans(dev):
     x = synth.rand_uniform_int(67, 'mx', (2, 32, 5, 5), 0, 255).astype(np.int32)
     y1 = m(_t(x, dev)).cpu().numpy()
     np.testing.assert_array_equal(y1, oracle.conv2d(x, w, np.zeros(32, np.int32), 1, 0))
-    m.weight.data[3, 5, 0, 0] = -99
+    m.weight.data[3, 5, 0, 0] = -99                     # through `.data`: no version bump, found by the content fingerprint
     w[3, 5, 0, 0] = -99
+    np.testing.assert_array_equal(m(_t(x, dev)).cpu().numpy(), oracle.conv2d(x, w, np.zeros(32, np.int32), 1, 0))
+    with torch.no_grad():
+        m.weight[7, 1, 0, 0] = 55                       # through the parameter: version bump
+    w[7, 1, 0, 0] = 55
     np.testing.assert_array_equal(m(_t(x, dev)).cpu().numpy(), oracle.conv2d(x, w, np.zeros(32, np.int32), 1, 0))
 
 
@@ -178,7 +182,7 @@ def test_mobilenet_v2_corner_formats(dev, case):
     if kind == 'dw':
         y = oracle.relu(y)
     q = oracle.requant(y, nfl, in_fl + w_fl, nsgn)
-    assert 0.02 < (np.abs(q) >= (127 if nsgn else 255)).mean() < 0.9 or in_fl + w_fl - nfl < 2      # the clamp is exercised, not everything saturates
+    assert np.unique(q).size > 4 and (np.abs(q) >= (127 if nsgn else 255)).mean() < 0.9     # a live signal, not everything saturated
     want = oracle.conv2d(q, w2, np.zeros(32, np.int32), 1, 0)
     P = (H + 2 * pad - k) // stride + 1
     got = net.run(_t(x, dev)).cpu().numpy().reshape(N, 32, P, P)
