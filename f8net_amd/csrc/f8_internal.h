@@ -150,6 +150,22 @@ struct FusedArgs {
     int32_t stg;                           // Options::opener_stg
 };
 
+// One launch for a MobileNet-V2 inverted-residual block: 1x1 expand -> depthwise 3x3 -> 1x1 project [+ int32 residual] (f8_ir.hip).
+struct IRArgs {
+    const int8_t* x8;                      // block input, int8 NHWC [N*H*W][CIN_S] in the expand conv's input format
+    const int32_t* xr;                     // block input, int32 I32T (residual operand) or nullptr
+    const int8_t* w0; const int32_t* b0;   // expand  [E32][CIN_S], offset-corrected bias [E32]
+    const int8_t* wd4; const int32_t* bd4; // depthwise: dot4 image [E32/4][36 B], bias (+128*sum(w) for unsigned inputs) [E32]
+    const int8_t* w4; const int32_t* b4;   // project [COUT_S][E32], offset-corrected bias [COUT_S]
+    int32_t N, H, W, Ho, Wo, stride, R, G, tiles_per_img, E32;
+    int32_t n1, lo1, hi1; uint32_t xor1;   // requant expand output -> depthwise input format
+    int32_t n2, lo2, hi2; uint32_t xor2;   // requant depthwise output -> project input format
+    int32_t relu_a, relu_b, relu0;         // ReLU after expand / depthwise / project
+    int32_t acc_shl, res_shl, relu1;       // residual join
+    int32_t* out32; QuantOut q[2];
+    int32_t xp, off_patch, off_mid2, off_w;   // LDS layout (filled by launch_fused_ir)
+};
+
 // ResNet head in one launch: 7x7/2 conv + ReLU + requant (unsigned 8-bit) + 3x3/2 max-pool (f8_stem.hip).
 struct StemPoolArgs {
     const int8_t* x; uint32_t x_bytes;     // haloed NHWC4 input [N][Hp][Wp][4], halo = conv pad + org pixels
@@ -176,6 +192,9 @@ bool fused_ds_supported(int C, int MID, int COUT, int H, int W, int* R);
 // stage-opening block with a stride-2 3x3 (f8_opener.hip); H, W = input map
 bool fused_opener_supported(int C, int MID, int COUT, int H, int W, int* R);
 hipError_t launch_fused_opener(const FusedArgs& a, hipStream_t s);
+// MobileNet-V2 inverted residual (f8_ir.hip): instance for the padded channel pair + a tile (R rows or G whole images) that fits LDS
+bool fused_ir_config(int cinS, int coutS, int H, int W, int stride, int* R, int* G);
+hipError_t launch_fused_ir(const IRArgs& a, int cinS, int coutS, hipStream_t s);
 // 3x3 / stride 1 / pad 1 with the input patch resident in LDS (f8_conv3x3.hip); config = false: no instance
 bool conv3x3_patch_config(int cin, int H, int W, int coutP, int* R, int* IMGS, int* BN);
 hipError_t launch_conv3x3_patch(const ConvArgs& a, int cin, hipStream_t s);

@@ -80,6 +80,7 @@ struct Node {
     int sp_pool = -1, sp_conv = -1;      // stem conv <-> max-pool fused into one launch (f8_stem.hip)
     int fbd_a = -1, fbd_b = -1;          // shortcut conv hosting a fused stage-opening block (DS): body.0 / body.2 (body.4 = `dual`)
     bool fbd_s2 = false;                 // ... whose 3x3 and shortcut have stride 2 (f8_opener.hip)
+    int ir_a = -1, ir_b = -1, ir_R = 0, ir_G = 0;   // project conv of a fused inverted-residual block: its expand / depthwise convs, tile
     int dual = -1;                     // 1x1 conv hosting a join whose other operand is ANOTHER 1x1 conv (node id): one dual-GEMM launch
     int dual_host = -1;                // ... and that other conv: the node that carries it
     int p3_R = 0, p3_imgs = 0, p3_bn = 0;   // 3x3 conv on the LDS-patch kernel (p3_R > 0): rows / images per tile, cout tile
@@ -88,7 +89,7 @@ struct Node {
     size_t rc_off = 0, cc_off = 0; int ncc = 0;      // border-class tables (0 = single class)
     ConvTile tile{};
 };
-enum StepKind { S_INPUT, S_CONV, S_DW, S_ADD, S_MAXPOOL, S_AVGPOOL, S_REQUANT, S_OUTPUT, S_FUSED, S_STEMPOOL };
+enum StepKind { S_INPUT, S_CONV, S_DW, S_ADD, S_MAXPOOL, S_AVGPOOL, S_REQUANT, S_OUTPUT, S_FUSED, S_STEMPOOL, S_IR };
 struct OutSel { int t = -1; int f32 = -1; int f8[2] = {-1, -1}; };
 struct Step {
     int kind; int node;
@@ -757,6 +758,35 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         h.fbd_a = ta.prod; h.fbd_b = tb.prod; h.fb_R = R; h.fbd_s2 = bs == 2;
     }
 
+    // ---- 1e. MobileNet-V2 inverted residual: 1x1 expand (ReLU) -> depthwise 3x3 (ReLU) -> 1x1 project [+ residual with the
+    //          block input], intermediates read by nobody else  ->  one launch (f8_ir.hip), the expanded tensors stay in LDS
+    for (int i = 0; opt.fuse_ir && i < nn; ++i) {
+        Node& c = ND[i];
+        if (c.kind != N_CONV || c.cd.groups != 1 || c.cd.kernel != 1 || c.cd.stride != 1 || c.cd.pad != 0 || !c.cd.quant_input ||
+            c.absorbed_by >= 0 || c.fb_a >= 0 || c.dual >= 0 || c.dual_host >= 0) continue;
+        const Tensor& tb = T[c.a];
+        if (tb.consumers.size() != 1 || c.a == net->out_t) continue;
+        Node& b = ND[tb.prod];
+        if (b.kind != N_CONV || b.cd.groups == 1 || b.cd.groups != b.cd.cin || b.cd.kernel != 3 || b.cd.pad != 1 || (b.cd.stride != 1 && b.cd.stride != 2) ||
+            !b.cd.quant_input || b.fused_add >= 0 || b.absorbed_by >= 0) continue;
+        const Tensor& ta = T[b.a];
+        if (ta.consumers.size() != 1 || b.a == net->out_t) continue;
+        Node& a0 = ND[ta.prod];
+        if (a0.kind != N_CONV || a0.cd.groups != 1 || a0.cd.kernel != 1 || a0.cd.stride != 1 || a0.cd.pad != 0 || a0.fused_add >= 0 ||
+            a0.absorbed_by >= 0 || a0.dual >= 0 || a0.dual_host >= 0 || !a0.cd.quant_input) continue;
+        if (ND[T[a0.a].prod].kind == N_INPUT) continue;          // the network input has its own layouts
+        if (c.fused_add >= 0) {                                   // a residual join must be with the block input
+            const Node& ad = ND[c.fused_add];
+            const int other = (ad.a == c.out) ? ad.b : ad.a;
+            if (other != a0.a || b.cd.stride != 1) continue;
+        }
+        const Tensor& x = T[a0.a];
+        int R = 0, G = 0;
+        if (!fused_ir_config(x.Cs, round_up(c.cd.cout, 32), x.H, x.W, b.cd.stride, &R, &G)) continue;
+        a0.absorbed_by = i; b.absorbed_by = i;
+        c.ir_a = ta.prod; c.ir_b = tb.prod; c.ir_R = R; c.ir_G = G;
+    }
+
     // ---- 2. which forms does each tensor need?  (reverse order: consumers before producers)
     {
         Tensor& O = T[net->out_t];
@@ -773,7 +803,8 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 consumer_format(s, nd.cd, &n, "finalize");
                 nd.depthwise = nd.cd.groups != 1;
                 if ((nd.absorbed_by >= 0 && ND[nd.absorbed_by].fbd_b == i) || (nd.dual_host >= 0 && ND[nd.dual_host].fbd_a >= 0)) break;   // DS: in LDS
-                if (nd.fb_a >= 0 || (nd.absorbed_by >= 0 && ND[nd.absorbed_by].fb_b == i)) {
+                if (nd.fb_a >= 0 || (nd.absorbed_by >= 0 && ND[nd.absorbed_by].fb_b == i) || nd.ir_a >= 0 ||
+                    (nd.absorbed_by >= 0 && ND[nd.absorbed_by].ir_b == i)) {
                     // source lives in LDS inside the fused launch: no HBM form.  (The block's first conv
                     // still reads the block input from HBM and falls through to the generic case.)
                     if (nd.fused_add >= 0) {
@@ -930,6 +961,43 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     if (nd.fbd_s2) snprintf(kb, sizeof kb, "f8::fused_opener_kernel<%d, %d, %d, %d, %d, %s>", na.cd.cin, na.cd.cout, x.W, nd.fb_R, nd.cd.cout,
                                             (opt.opener_stg && st.out.f8[0] >= 0) ? "true" : "false");
                     else snprintf(kb, sizeof kb, "f8::fused_bottleneck_kernel<%d, %d, %d, %d, %d, true>", na.cd.cin, na.cd.cout, x.W, nd.fb_R, nd.cd.cout);
+                    st.kernel = kb;
+                    break;
+                }
+                if (nd.ir_a >= 0) {
+                    // ---- fused inverted residual: nd is the project conv
+                    Node& na = ND[nd.ir_a]; Node& nb = ND[nd.ir_b];
+                    Tensor& x = T[na.a];
+                    st.kind = S_IR;
+                    st.src_t = na.a;
+                    int n0 = 0; consumer_format(x, na.cd, &n0, "finalize");
+                    st.src_f = find_form(x, FORM_I8, n0, na.cd.input_signed ? 1 : 0);
+                    pack_conv_weights(net, na, x, T[na.out]);
+                    nb.depthwise = true;
+                    pack_dw_weights(net, nb, T[nb.a]);
+                    pack_conv_weights(net, nd, T[nd.a], T[nd.out]);
+                    st.relu0 = nd.cd.relu;
+                    if (nd.fused_add >= 0) {
+                        const Node& ad = ND[nd.fused_add];
+                        st.res_t = na.a; st.res_f = find_form(x, FORM_I32, 0, 0);
+                        const int dfl = T[nd.out].fl - x.fl;
+                        st.acc_shl = dfl < 0 ? -dfl : 0; st.res_shl = dfl > 0 ? dfl : 0;
+                        st.relu1 = ad.relu;
+                        out_t = ad.out;
+                    }
+                    select_outputs(net, out_t, &st.out, &extra);
+                    Tensor& o = T[out_t];
+                    const double px = (double)x.H * x.W, pxo = (double)o.H * o.W;
+                    st.ops_per_img = 2.0 * (px * na.cd.cin * na.cd.cout + pxo * 9.0 * nb.cd.cout + pxo * (double)nd.cd.cin * nd.cd.cout);
+                    double b = px * x.Cs + (st.res_t >= 0 ? px * x.Cs * 4 : 0);
+                    if (st.out.f32 >= 0) b += pxo * o.Cs * 4;
+                    for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += pxo * o.Cs;
+                    st.bytes_per_img = b;
+                    st.bytes_const = (double)na.coutP * (na.ktot + 4) + (double)T[nb.a].Cs * 13 + (double)nd.coutP * (nd.ktot + 4);
+                    char kb[200];
+                    snprintf(kb, sizeof kb, "fused_ir_s%d_%s:", nb.cd.stride, nd.ir_G > 1 ? ("G" + std::to_string(nd.ir_G)).c_str() : ("R" + std::to_string(nd.ir_R)).c_str());
+                    st.name = std::string(kb) + tname(net, na.out) + "+" + tname(net, nb.out) + "+" + tname(net, nd.out);
+                    snprintf(kb, sizeof kb, "f8::fused_ir_kernel<%d, %d>", x.Cs, nd.coutP);
                     st.kernel = kb;
                     break;
                 }
@@ -1165,7 +1233,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                         // in-place residual: out32 of a conv/add step may overwrite a residual operand that dies here
                         // (each thread reads its element before writing it; same geometry, so it also holds per chunk)
                         if (F.kind == FORM_I32 && (int)ti == st.out.t && (int)f == st.out.f32 && st.res_t >= 0 &&
-                            (st.kind == S_CONV || st.kind == S_ADD || st.kind == S_FUSED)) {
+                            (st.kind == S_CONV || st.kind == S_ADD || st.kind == S_FUSED || st.kind == S_IR)) {
                             Form& R = T[st.res_t].forms[st.res_f];
                             if (R.last == sj && R.bytes_per_img == F.bytes_per_img && R.kind == FORM_I32) {
                                 F.off = R.off; R.last = -2;   // ownership moves to F
@@ -1392,6 +1460,31 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1;
             fill_out(&a.out32, a.q);
             e = launch_fused_bottleneck(a, s);
+            break;
+        }
+        case S_IR: {
+            const Node& na = net->nodes[nd.ir_a]; const Node& nb = net->nodes[nd.ir_b];
+            const Tensor& x = T[st.src_t]; const Form& xF = x.forms[st.src_f];
+            const Tensor& oT = T[nd.out];
+            IRArgs a{};
+            a.x8 = (const int8_t*)fp(xF);
+            if (st.res_t >= 0) a.xr = (const int32_t*)fp(T[st.res_t].forms[st.res_f]);
+            a.w0 = (const int8_t*)(net->d_w + na.w_off); a.b0 = (const int32_t*)(net->d_w + na.b_off);
+            a.wd4 = (const int8_t*)(net->d_w + nb.rc_off); a.bd4 = (const int32_t*)(net->d_w + nb.cc_off);
+            a.w4 = (const int8_t*)(net->d_w + nd.w_off); a.b4 = (const int32_t*)(net->d_w + nd.b_off);
+            a.N = N; a.H = x.H; a.W = x.W; a.Ho = oT.H; a.Wo = oT.W; a.stride = nb.cd.stride; a.R = nd.ir_R; a.G = nd.ir_G;
+            a.tiles_per_img = oT.H / nd.ir_R; a.E32 = na.coutP;
+            auto fmt = [&](const Node& cons, const Tensor& src, int32_t* n, int32_t* lo, int32_t* hi, uint32_t* x_or) {
+                int nn = 0; consumer_format(src, cons.cd, &nn, "run");
+                *n = nn; *lo = cons.cd.input_signed ? -127 : 0; *hi = cons.cd.input_signed ? 127 : 255;
+                *x_or = cons.cd.input_signed ? 0u : 0x80808080u;
+            };
+            fmt(nb, T[nb.a], &a.n1, &a.lo1, &a.hi1, &a.xor1);
+            fmt(nd, T[nd.a], &a.n2, &a.lo2, &a.hi2, &a.xor2);
+            a.relu_a = na.cd.relu; a.relu_b = nb.cd.relu; a.relu0 = st.relu0;
+            a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1;
+            fill_out(&a.out32, a.q);
+            e = launch_fused_ir(a, x.Cs, nd.coutP, s);
             break;
         }
         case S_DW: {
