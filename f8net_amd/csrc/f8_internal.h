@@ -17,7 +17,7 @@ struct Options {
     int fuse_ds = 1;             // stage-opening block at unchanged resolution in one launch
     int fuse_opener = 1;         // stage-opening block with a stride-2 3x3 in one launch
     int fuse_stem = 1;           // stem conv + max-pool in one launch
-    int fuse_ir = 1;             // MobileNet-V2 inverted residual (expand -> depthwise -> project) in one launch
+    int fuse_ir = 1;             // MobileNet-V2 inverted residual (expand -> depthwise -> project) in one launch: 1 = where it wins, 2 = always
     int patch3x3 = 1;            // LDS-patch 3x3 kernel
     int dual_wide = 2048;        // dual-GEMM joins with at least this many couts use the 128x128 tile
     int deep_nk = 7;             // K loops of at least this many steps use the deepest DMA ring

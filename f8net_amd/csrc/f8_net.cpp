@@ -204,7 +204,7 @@ static const OptKey kOptKeys[] = {
     {"fuse_ds", "F8_FUSE_DS", &Options::fuse_ds, 0, 1, true},
     {"fuse_opener", "F8_FUSE_OPENER", &Options::fuse_opener, 0, 1, true},
     {"fuse_stem", "F8_FUSE_STEM", &Options::fuse_stem, 0, 1, true},
-    {"fuse_ir", "F8_FUSE_IR", &Options::fuse_ir, 0, 1, true},
+    {"fuse_ir", "F8_FUSE_IR", &Options::fuse_ir, 0, 2, true},
     {"patch3x3", "F8_PATCH3X3", &Options::patch3x3, 0, 1, true},
     {"dual_wide", "F8_DUAL_WIDE", &Options::dual_wide, 0, 1 << 30, true},
     {"deep_nk", "F8_DEEP_NK", &Options::deep_nk, 1, 1 << 20, true},
@@ -774,6 +774,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         Node& a0 = ND[ta.prod];
         if (a0.kind != N_CONV || a0.cd.groups != 1 || a0.cd.kernel != 1 || a0.cd.stride != 1 || a0.cd.pad != 0 || a0.fused_add >= 0 ||
             a0.absorbed_by >= 0 || a0.dual >= 0 || a0.dual_host >= 0 || !a0.cd.quant_input) continue;
+        if (a0.ir_a >= 0 || a0.fb_a >= 0 || a0.fbd_a >= 0) continue;   // already the host of another fused launch (chains of 1x1 / dw / 1x1 / dw ...)
         if (ND[T[a0.a].prod].kind == N_INPUT) continue;          // the network input has its own layouts
         if (c.fused_add >= 0) {                                   // a residual join must be with the block input
             const Node& ad = ND[c.fused_add];
@@ -783,6 +784,15 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         const Tensor& x = T[a0.a];
         int R = 0, G = 0;
         if (!fused_ir_config(x.Cs, round_up(c.cd.cout, 32), x.H, x.W, b.cd.stride, &R, &G)) continue;
+        if (opt.fuse_ir == 1) {
+            // Where the fused launch wins (MobileNet-V2, 128 images, fused vs the three launches, us): 56x56 / 2: 64 vs 77; 28x28:
+            // 50 vs 53; 28x28 / 2: 33 vs 38; 14x14, E = 384: 33 vs 39.  It loses where one workgroup's chunk loop is the critical
+            // path — 7x7 maps (64 workgroups for 128 images: 85 vs 36) and E = 576 at 14x14 (51 vs 47) — and on the two largest
+            // maps, where a 2-row tile recomputes every expand row twice and the requantisation of the expanded tensor is VALU
+            // bound (112x112 / 2: 153 vs 139; 56x56: 141 vs 127).  fuse_ir = 2 fuses every block that has an instance.
+            const int opx = T[c.out].H * T[c.out].W;
+            if (opx < 196 || round_up(a0.cd.cout, 32) > 384 || x.W > 56 || (x.W >= 56 && b.cd.stride == 1)) continue;
+        }
         a0.absorbed_by = i; b.absorbed_by = i;
         c.ir_a = ta.prod; c.ir_b = tb.prod; c.ir_R = R; c.ir_G = G;
     }

@@ -80,7 +80,7 @@ def test_run_without_gpu_fails_loudly():
 
 
 @pytest.mark.parametrize('arch,launches,fused,dual', [('resnet18', 24, 0, 0), ('resnet50', 41, 5, 3), ('mobilenet_v1', 31, 0, 0),
-                                                       ('mobilenet_v2', 24, 0, 0)])
+                                                       ('mobilenet_v2', 40, 0, 0)])
 def test_plan_fuses_requant_relu_residual(arch, launches, fused, dual):
     spec = topology.get(arch)
     net = build_net(spec, synth.make_params(spec, 1), max_batch=8, hw=224)
@@ -102,7 +102,7 @@ def test_plan_fuses_requant_relu_residual(arch, launches, fused, dual):
     assert opener == (1 if arch == 'resnet50' else 0)
     # MobileNet-V2: every inverted-residual block (expand -> depthwise -> project [+ residual]) is ONE launch (f8_ir.hip)
     ir = [l for l in plan.splitlines() if 'fused_ir_' in l]
-    assert len(ir) == (16 if arch == 'mobilenet_v2' else 0)
+    assert len(ir) == (8 if arch == 'mobilenet_v2' else 0)      # the blocks where the fused launch wins (option fuse_ir = 2: all 16)
     assert plan.count('_res:') + plan.count('_dual:') + fused + opener + sum('res=1' in l for l in ir) == n_res_blocks
     assert net.weight_bytes > 0 and net.arena_bytes > 0
 

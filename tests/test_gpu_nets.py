@@ -123,6 +123,22 @@ def test_full_size_batch_properties(dev, arch, n):
     assert np.count_nonzero(full) > 0.9 * full.size
 
 
+def test_every_inverted_residual_block_fused_matches_golden(dev, golden_dir):
+    """Option fuse_ir = 2 plans EVERY MobileNet-V2 block onto fused_ir_kernel (the default fuses the ones where it wins): all
+    eight channel-pair instances, row tiles and whole-image tiles, both strides, with and without residual — logits equal the
+    goldens captured from the reference."""
+    from f8net_amd.net import build_net
+    g, spec, params = _golden_setup('mobilenet_v2', golden_dir)
+    for hw, n in ((64, 2), (224, 1)):
+        x, _ = synth.make_input(spec, params, n, hw, seed=7)
+        net = build_net(spec, params, max_batch=n, hw=hw, options={'fuse_ir': 2})
+        assert net.describe().count('fused_ir_') == 16
+        np.testing.assert_array_equal(net.run(torch.from_numpy(x).to(dev)).cpu().numpy(), g[f's1234_hw{hw}_n{n}/logits'])
+    x, fl = synth.make_input(spec, params, 11, 224, seed=13)          # ragged batch: whole-image tiles of 2 with an odd image count
+    net = build_net(spec, params, max_batch=11, hw=224, options={'fuse_ir': 2})
+    np.testing.assert_array_equal(net.run(torch.from_numpy(x).to(dev)).cpu().numpy(), oracle.net_forward(spec, params, x, fl))
+
+
 @pytest.mark.parametrize('mode', [1, 2])
 def test_pipelined_runs_overlap_safely(dev, mode):
     """f8_net_set_pipelined (1: lagged sub-batches, 2: whole batches alternating between two streams / arena copies):
