@@ -643,14 +643,26 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
         // Measured (128-image launches): identity 56x56 block 208.5 -> 200.2 us; the DS instance (no residual stream, write-
         // bound) 114.6 -> 120.6 us, so it keeps its direct stores.  (Most of the ablation's 19 % turned out to be the bytes
         // themselves: the int8 copy is a tenth of a block's traffic, all of it writes.)
-        constexpr bool STG = ALLW && D3 == 2 && !DS;     // the W2 region (36 KB) is dead in P3: room for both buffers
-        static_assert(!STG || (W2ALL >= 2 * 16384 && OUT_PX <= 128 && OUT_PX >= 64 && (NC3 % 2) == 0), "staging buffers / pairs of chunks");
-        char* const stg = ring;
+        // Buffers (16 KB each, regions that are dead in P3): MID = 64: the W2 region; MID = 128: the patch and — from the second pair on,
+        // when every wave has read its chunk-invariant mid2 fragments (chunk 0) and passed chunk 1's barrier — mid2; MID = 256: the
+        // patch behind the W4 slot in its head, and mid2 likewise.  Measured per 128 images (same box): 28x28 blocks 335 -> 324 us; the
+        // 14x14 blocks 374 -> 385 us (their P3 is four chunks deep: the extra barrier-coupled LDS round trip costs more than the
+        // 32-byte pieces), so MID = 256 keeps its direct stores, like the write-bound DS instance.
+        constexpr bool STG = !DS && MID != 256;
+        static_assert(!STG || (OUT_PX <= 128 && OUT_PX >= 64 && (NC3 % 2) == 0), "staging buffers / pairs of chunks");
+        static_assert(!STG || !ALLW || W2ALL >= 2 * 16384, "MID = 64: both buffers in the W2 region");
+        static_assert(!STG || ALLW || MID != 128 || (PATCH_BYTES >= 16384 && MID2_BYTES >= 16384), "MID = 128: patch / mid2");
+        static_assert(!STG || ALLW || MID != 256 || (PATCH_BYTES >= 2 * 16384 && MID2_BYTES >= 16384), "MID = 256: patch tail / mid2");
+        auto stgbuf = [&](int b) -> char* {
+            if constexpr (ALLW) return ring + b * 16384;
+            else if constexpr (MID == 256) return b == 0 ? patch + 16384 : mid2;
+            else return b == 0 ? patch : mid2;
+        };
         const bool stage0 = STG && a.q[0].ptr != nullptr;
         const int n_direct = (a.out32 ? 4 : 0) + ((!STG && a.q[0].ptr) ? 1 : 0) + (a.q[1].ptr ? 1 : 0);   // direct stores per wave per chunk
         auto stores_of = [&](int x) { return n_direct + ((stage0 && x >= 2 && !(x & 1)) ? 2 : 0); };       // VMEM stores issued during chunk x
         auto flush_pair = [&](int c0) {                  // chunks c0, c0+1 -> 128-byte lines; exactly two store instructions per wave
-            const char* buf = stg + ((c0 >> 1) & 1) * 16384;
+            const char* buf = stgbuf((c0 >> 1) & 1);
             const int npx = rows_out * W;
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
@@ -747,7 +759,7 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
                 const v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
                 if (STG && k == 0) {                     // 16 bytes of pixel `opix`, column (c & 1) * 64 + wb * 32 + lh * 16 of its 128-byte row
                     const int c16 = (c & 1) * 4 + wb * 2 + lh;
-                    *(v4i*)(stg + ((c >> 1) & 1) * 16384 + opix * 128 + ((c16 ^ (opix & 7)) << 4)) = o;
+                    *(v4i*)(stgbuf((c >> 1) & 1) + opix * 128 + ((c16 ^ (opix & 7)) << 4)) = o;
                 } else if (opix_ok) {
                     *(v4i*)(a.q[k].ptr + (size_t)m * COUT + cot + 16 * lh) = o;
                 }
@@ -759,6 +771,8 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
             // newer than res(c) in the queue: per earlier chunk of the window its stores, and the W4 + residual requests of the
             // two later chunks (WL + 4 each); everything older — including the stores of chunk c-4 — has to be back
             const int st = c < 3 ? c : 3;
+            int st_sum = 0;                              // stores issued by the (up to three) chunks before this one
+            for (int j = 1; j <= st; ++j) st_sum += stores_of(c - j);
 #if defined(F8_ABL_P3_NORES)
             wait_vmcnt_dyn(2 * (WL + 0) + st * n_store);
 #elif defined(F8_ABL_P3_NOSTORE)
@@ -768,7 +782,8 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
 #elif defined(F8_ABL_P3_NOSTORE32)
             wait_vmcnt_dyn(2 * (WL + 4) + st * (n_store - 4));
 #else
-            wait_vmcnt_dyn(2 * (WL + 4) + st * n_store);
+            (void)n_store;
+            wait_vmcnt_dyn(2 * (WL + 4) + st_sum);
 #endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                // chunk 0: also "mid2 complete"; slot (c+3)%4 was read in chunk c-1
@@ -785,6 +800,7 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
                 load_res(rq[(k + 3) & 3], cn);
 #endif
             }
+            if (stage0 && c >= 2 && !(c & 1)) flush_pair(c - 2);   // the pair before this one is complete since this chunk's barrier
             const char* base = w4slot(k);
             if (c == 0) {
 #pragma unroll
@@ -831,8 +847,11 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
 #if defined(F8_ABL_P3_NOSTORE) || defined(F8_ABL_P3_NOSTORE8)
                 if (s0[0] == 0x12345678 && s1[1] == 0x7654321)
 #endif
-                if (opix_ok) {
-                    v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
+                const v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
+                if (STG && kq == 0) {                    // staged: 16 bytes of pixel opix, column (c & 1) * 64 + wb * 32 + lh * 16 of its 128-byte row
+                    const int c16 = (c & 1) * 4 + wb * 2 + lh;
+                    *(v4i*)(stgbuf((c >> 1) & 1) + opix * 128 + ((c16 ^ (opix & 7)) << 4)) = o;
+                } else if (opix_ok) {
                     *(v4i*)(a.q[kq].ptr + (size_t)m * COUT + cot + 16 * lh) = o;
                 }
             }
@@ -845,6 +864,11 @@ fused_bottleneck_kernel(const FusedArgs a) {   // MID <= 128: <= 128 VGPRs so th
                 chunk4(c + 1, std::integral_constant<int, 1>{});
                 chunk4(c + 2, std::integral_constant<int, 2>{});
                 chunk4(c + 3, std::integral_constant<int, 3>{});
+            }
+            if (stage0) {                                // the last pair
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                flush_pair(NC3 - 2);
             }
         } else {
             for (int c = 0; c < NC3; c += 2) {

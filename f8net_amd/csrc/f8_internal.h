@@ -23,12 +23,13 @@ struct Options {
     int deep_nk = 7;             // K loops of at least this many steps use the deepest DMA ring
     int bk128 = 0;               // 128-byte K steps in conv_igemm_kernel
     int dw_dot4 = 1;             // v_dot4 depthwise kernel
-    int stem_wpc = 2;            // resident stem workgroups per CU
+    int stem_wpc = 3;            // resident stem workgroups per CU (2 / 3 / 4: 84.0 / 84.5 / 84.7 k img/s, same box)
     int opener_stg = 1;          // stride-2 opener: int8 output staged through LDS into 128-byte lines
     int chunk56 = -1, chunk28 = -1, chunk14 = -1;   // images per chunk of the fused blocks (-1: derived from chunk_budget_mb, 0: whole batch)
     int chunk_budget_mb = 96;    // a chunk's int32 stream must fit this much memory-side cache (3/8 of the 256 MiB Infinity Cache)
     int chunk_ds = 1, chunk_opener = 0;             // chunk the stage-opening blocks too (the stride-2 opener runs one workgroup per
                                                     // CU, 7 per image: measured 139 us in one 128-image launch, 161 us in 4 chunks)
+    int whole_batch_launches = 0;   // planning hint: launches will cover the whole batch (f8_net_set_pipelined(2)), not max_batch / split images
     int pipeline_depth = 2;      // f8_net_set_pipelined(2): runs in flight (2..4, at most `split` arena copies)
     int split_streams = 1;       // 0: same launches serialised on the caller's stream (profiling)
     int graph = 0;               // hipGraph capture / replay of a run

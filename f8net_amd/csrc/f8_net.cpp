@@ -224,6 +224,7 @@ static const OptKey kOptKeys[] = {
     {"stagger_pipelined", "F8_STAGGER_PIPELINED", &Options::stagger_pipelined, 0, 1 << 20, false},
     {"check_device", "F8_CHECK_DEVICE", &Options::check_device, 0, 1, false},
     {"pipeline_depth", "F8_PIPELINE_DEPTH", &Options::pipeline_depth, 2, 4, false},
+    {"whole_batch_launches", "F8_WHOLE_BATCH_LAUNCHES", &Options::whole_batch_launches, 0, 1, true},
 };
 static const OptKey* find_opt(const char* key) {
     if (!key) return nullptr;
@@ -706,7 +707,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         const int C = a0.cd.cin, MID = a0.cd.cout;
         if (c.cd.cout != C || b.cd.cin != MID || b.cd.cout != MID || c.cd.cin != MID) continue;
         int R = 0;
-        if (!fused_bottleneck_supported(C, MID, x.H, x.W, std::max(1, max_batch / opt.split), opt.fuse_stages, &R)) continue;
+        if (!fused_bottleneck_supported(C, MID, x.H, x.W, opt.whole_batch_launches ? max_batch : std::max(1, max_batch / opt.split), opt.fuse_stages, &R)) continue;
         a0.absorbed_by = i; b.absorbed_by = i; b.no_classes = true;
         c.fb_a = ta.prod; c.fb_b = tb.prod; c.fb_R = R;
     }
