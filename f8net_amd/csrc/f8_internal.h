@@ -165,6 +165,8 @@ struct IRArgs {
     int32_t acc_shl, res_shl, relu1;       // residual join
     int32_t* out32; QuantOut q[2];
     int32_t xp, off_patch, off_mid2, off_w;   // LDS layout (filled by launch_fused_ir)
+    // magic numbers (fast_div) for / W, / (H*W), / Wo, / (R*Wo): [magic, sh1, sh2]
+    uint32_t mW, mHW, mWo, mRWo; int32_t s1W, s2W, s1HW, s2HW, s1Wo, s2Wo, s1RWo, s2RWo;
 };
 
 // ResNet head in one launch: 7x7/2 conv + ReLU + requant (unsigned 8-bit) + 3x3/2 max-pool (f8_stem.hip).

@@ -54,15 +54,30 @@ __global__ void __launch_bounds__(256) fused_ir_kernel(const IRArgs a) {
     const int P1_PX = Geff * nvr * W, np1 = (P1_PX + 31) >> 5;
     const int RWo = R * Wo, OUT_PX = Geff * RWo;
     const int nchunk = (a.E32 + 63) >> 6;
+    // pixel index -> (image g, row, column) without hardware division (host magic numbers).  Row tiles (G == 1) have g == 0;
+    // whole-image tiles (G > 1) have nvr == H.
+    auto split_in = [&](int px, int& g, int& vr, int& c) {
+        g = a.G > 1 ? (int)fast_div((unsigned)px, a.mHW, a.s1HW, a.s2HW) : 0;
+        const int r = px - g * nvr * W;
+        vr = (int)fast_div((unsigned)r, a.mW, a.s1W, a.s2W);
+        c = r - vr * W;
+    };
+    auto split_out = [&](int op, int& g, int& orow, int& ocol) {
+        g = a.G > 1 ? (int)fast_div((unsigned)op, a.mRWo, a.s1RWo, a.s2RWo) : 0;
+        const int r = op - g * RWo;
+        orow = (int)fast_div((unsigned)r, a.mWo, a.s1Wo, a.s2Wo);
+        ocol = r - orow * Wo;
+    };
 
     // ---- block input tile -> X (k-blocked: [kk][px][32 B], so a fragment read is 1 KB contiguous per wave)
     {
         const int nslot = a.xp * KK1 * 2;
         for (int sl = tid; sl < nslot; sl += 256) {
-            const int kk = sl / (a.xp * 2), rem = sl - kk * (a.xp * 2), px = rem >> 1, half = rem & 1;
+            const int kk = KK1 == 1 ? 0 : sl / (a.xp * 2), rem = sl - kk * (a.xp * 2), px = rem >> 1, half = rem & 1;
             v4i v = {0, 0, 0, 0};
             if (px < P1_PX) {
-                const int g = px / (nvr * W), r = px - g * nvr * W, vr = r / W, c = r - vr * W;
+                int g, vr, c;
+                split_in(px, g, vr, c);
                 const size_t gpx = ((size_t)(n0 + g) * H + vr0 + vr) * W + c;
                 v = *(const v4i*)(a.x8 + gpx * CIN_S + kk * 32 + half * 16);
             }
@@ -152,7 +167,8 @@ __global__ void __launch_bounds__(256) fused_ir_kernel(const IRArgs a) {
             const int px = pt * 32 + l31;
             const bool ok = px < P1_PX;
             const int pxc = ok ? px : 0;
-            const int g = pxc / (nvr * W), r = pxc - g * nvr * W, vr = r / W, c = r - vr * W;
+            int g, vr, c;
+            split_in(pxc, g, vr, c);
             const int ent = (g * PR + (vr0 + vr - in_row0)) * PW + c + 1;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -180,7 +196,8 @@ __global__ void __launch_bounds__(256) fused_ir_kernel(const IRArgs a) {
         for (int it = tid; it < OUT_PX * 4; it += 256) {
             const int op = it >> 2, cg = it & 3;
             if (cg >= nct * 2) continue;
-            const int g = op / RWo, r = op - g * RWo, orow = r / Wo, ocol = r - orow * Wo;
+            int g, orow, ocol;
+            split_out(op, g, orow, ocol);
             const char* pp = patch + ((size_t)((g * PR + orow * s) * PW + ocol * s)) * 64 + cg * 16;
             v4i xw[3][3];
 #pragma unroll
@@ -244,7 +261,8 @@ __global__ void __launch_bounds__(256) fused_ir_kernel(const IRArgs a) {
     if (wave * 32 >= OUT_PX) return;
     const bool ok = opx < OUT_PX;
     const int oc = ok ? opx : 0;
-    const int g = oc / RWo, r = oc - g * RWo, orow = r / Wo, ocol = r - orow * Wo;
+    int g, orow, ocol;
+    split_out(oc, g, orow, ocol);
     const int m = ((n0 + g) * a.Ho + p0 + orow) * Wo + ocol;
     const int floor0 = a.relu0 ? 0 : INT32_MIN, floor1 = a.relu1 ? 0 : -2147483647;
 #pragma unroll

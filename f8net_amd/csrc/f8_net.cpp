@@ -1494,6 +1494,10 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             fmt(nd, T[nd.a], &a.n2, &a.lo2, &a.hi2, &a.xor2);
             a.relu_a = na.cd.relu; a.relu_b = nb.cd.relu; a.relu0 = st.relu0;
             a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1;
+            make_magic((uint32_t)x.W, &a.mW, &a.s1W, &a.s2W);
+            make_magic((uint32_t)(x.H * x.W), &a.mHW, &a.s1HW, &a.s2HW);
+            make_magic((uint32_t)oT.W, &a.mWo, &a.s1Wo, &a.s2Wo);
+            make_magic((uint32_t)(nd.ir_R * oT.W), &a.mRWo, &a.s1RWo, &a.s2RWo);
             fill_out(&a.out32, a.q);
             e = launch_fused_ir(a, x.Cs, nd.coutP, s);
             break;
