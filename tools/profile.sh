@@ -9,6 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # serialise the in-flight runs: per-kernel durations then match bench.py's live (sequential, HIP-event) measurement
 export F8_SPLIT_STREAMS=0
+export F8_BENCH_LEAN=1      # the headline loop only: keeps the counter databases small
 CMD="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline $*"
 echo "$*" > $OUT/bench_args.txt
 python - > $OUT/csrc_sha256.txt <<PY
@@ -21,4 +22,7 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $CMD > $OUT/p
 timeout 600 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $CMD > $OUT/pmc_write.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_mfma -o pmc -- $CMD > $OUT/pmc_mfma.log 2>&1
 tail -1 $OUT/trace.log > $OUT/bench_line.json
-ls $OUT/*/ | head -20
+# summarise on the box and drop the databases (gpurun merges at most 64 MiB back)
+python $REPO/tools/summarize_prof.py $OUT $TAG --out $OUT/summary ${MAIN:+--main} > $OUT/summarize.log 2>&1 || tail -5 $OUT/summarize.log
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma
+ls $OUT $OUT/summary

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 databases written by tools/profile.sh into the committed summaries:
 
-    python tools/summarize_prof.py gpurun_out/prof_r02 r02 [--main]
+    python tools/summarize_prof.py gpurun_out/prof_r02 r02 [--main] [--out DIR]
       -> profiles/rocprof_r02_kernel_stats.md   (rocprofv3 --kernel-trace --stats summary)
       -> profiles/rocprof_r02_pmc.md            (FETCH_SIZE / WRITE_SIZE per kernel, separate passes)
       -> profiles/rocprof_r02_mfma.md           (INT8 MFMA instructions / busy cycles per kernel)
@@ -33,6 +33,8 @@ def main():
     is_main = '--main' in sys.argv[3:]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = os.path.join(root, 'profiles')
+    if '--out' in sys.argv[3:]:                              # tools/profile.sh summarises on the GPU box into gpurun_out/prof_<tag>/summary
+        out = sys.argv[sys.argv.index('--out') + 1]
     os.makedirs(out, exist_ok=True)
     stamp = open(os.path.join(src, 'csrc_sha256.txt')).read().strip()
     bargs = open(os.path.join(src, 'bench_args.txt')).read().split()
