@@ -80,16 +80,18 @@ struct Node {
     int sp_pool = -1, sp_conv = -1;      // stem conv <-> max-pool fused into one launch (f8_stem.hip)
     int fbd_a = -1, fbd_b = -1;          // shortcut conv hosting a fused stage-opening block (DS): body.0 / body.2 (body.4 = `dual`)
     bool fbd_s2 = false;                 // ... whose 3x3 and shortcut have stride 2 (f8_opener.hip)
+    int p12_a = -1;                      // 3x3 conv hosting "1x1 -> 3x3 in one launch" (f8_p12.hip): its 1x1 producer
     int ir_a = -1, ir_b = -1, ir_R = 0, ir_G = 0;   // project conv of a fused inverted-residual block: its expand / depthwise convs, tile
     int dual = -1;                     // 1x1 conv hosting a join whose other operand is ANOTHER 1x1 conv (node id): one dual-GEMM launch
     int dual_host = -1;                // ... and that other conv: the node that carries it
     int p3_R = 0, p3_imgs = 0, p3_bn = 0;   // 3x3 conv on the LDS-patch kernel (p3_R > 0): rows / images per tile, cout tile
     bool no_classes = false;           // pack a single bias class (the consumer kernel pads with real zeros itself)
     size_t w_off = 0, b_off = 0; int coutP = 0, ck = 0, ktot = 0;
+    size_t wf_off = 0;                 // second image of the packed weights in MFMA-fragment order (pack_frag_weights), 0 = none
     size_t rc_off = 0, cc_off = 0; int ncc = 0;      // border-class tables (0 = single class)
     ConvTile tile{};
 };
-enum StepKind { S_INPUT, S_CONV, S_DW, S_ADD, S_MAXPOOL, S_AVGPOOL, S_REQUANT, S_OUTPUT, S_FUSED, S_STEMPOOL, S_IR };
+enum StepKind { S_INPUT, S_CONV, S_DW, S_ADD, S_MAXPOOL, S_AVGPOOL, S_REQUANT, S_OUTPUT, S_FUSED, S_STEMPOOL, S_IR, S_P12 };
 struct OutSel { int t = -1; int f32 = -1; int f8[2] = {-1, -1}; };
 struct Step {
     int kind; int node;
@@ -205,6 +207,7 @@ static const OptKey kOptKeys[] = {
     {"fuse_opener", "F8_FUSE_OPENER", &Options::fuse_opener, 0, 1, true},
     {"fuse_stem", "F8_FUSE_STEM", &Options::fuse_stem, 0, 1, true},
     {"fuse_ir", "F8_FUSE_IR", &Options::fuse_ir, 0, 2, true},
+    {"fuse_p12", "F8_FUSE_P12", &Options::fuse_p12, 0, 1, true},
     {"patch3x3", "F8_PATCH3X3", &Options::patch3x3, 0, 1, true},
     {"dual_wide", "F8_DUAL_WIDE", &Options::dual_wide, 0, 1 << 30, true},
     {"deep_nk", "F8_DEEP_NK", &Options::deep_nk, 1, 1 << 20, true},
@@ -570,6 +573,23 @@ static void pack_conv_weights(f8_net* net, Node& nd, const Tensor& src, const Te
     }
 }
 
+// A second image of a conv's packed weights ([coutP][ktot], K-contiguous) in MFMA-fragment order:
+//   [cout tile of 32][K32 step][lane 0..63][16 B],  lane l = row (l & 31) of the tile, bytes [32 * step + 16 * (l >> 5), +16)
+// — the A operand of one v_mfma_i32_32x32x32_i8 is one contiguous 1 KB, so a wave fetches it with one coalesced instruction straight
+// into registers (f8_p12.hip: no LDS staging, no barrier in the K loop).
+static void pack_frag_weights(f8_net* net, Node& nd) {
+    const size_t bytes = (size_t)nd.coutP * nd.ktot;
+    nd.wf_off = round_up_z(net->wblob.size(), 256);
+    net->wblob.resize(nd.wf_off + bytes, 0);
+    const int8_t* src = (const int8_t*)net->wblob.data() + nd.w_off;
+    int8_t* dst = (int8_t*)net->wblob.data() + nd.wf_off;
+    const int steps = nd.ktot / 32;
+    for (int t = 0; t < nd.coutP / 32; ++t)
+        for (int s = 0; s < steps; ++s)
+            for (int l = 0; l < 64; ++l)
+                memcpy(dst + (((size_t)t * steps + s) * 64 + l) * 16, src + (size_t)(t * 32 + (l & 31)) * nd.ktot + s * 32 + (l >> 5) * 16, 16);
+}
+
 static void pack_dw_weights(f8_net* net, Node& nd, const Tensor& src) {
     // Two images of the depthwise weights:
     //  (1) [9][Cs] tap-major + plain bias            — scalar kernel (int32 outputs, fallback)
@@ -707,7 +727,13 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         const int C = a0.cd.cin, MID = a0.cd.cout;
         if (c.cd.cout != C || b.cd.cin != MID || b.cd.cout != MID || c.cd.cin != MID) continue;
         int R = 0;
-        if (!fused_bottleneck_supported(C, MID, x.H, x.W, opt.whole_batch_launches ? max_batch : std::max(1, max_batch / opt.split), opt.fuse_stages, &R)) continue;
+        if (!fused_bottleneck_supported(C, MID, x.H, x.W, opt.whole_batch_launches ? max_batch : std::max(1, max_batch / opt.split), opt.fuse_stages, &R)) {
+            // no whole-block instance (the 7x7 maps of stage 3): body.0 + body.2 as one launch, the residual-carrying 1x1 stays
+            if (opt.fuse_p12 && fused_p12_supported(C, MID, x.H, x.W) && a0.cd.relu && b.cd.relu && tb.consumers.size() == 1) {
+                a0.absorbed_by = tb.prod; b.p12_a = ta.prod; b.no_classes = true;
+            }
+            continue;
+        }
         a0.absorbed_by = i; b.absorbed_by = i; b.no_classes = true;
         c.fb_a = ta.prod; c.fb_b = tb.prod; c.fb_R = R;
     }
@@ -814,6 +840,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 consumer_format(s, nd.cd, &n, "finalize");
                 nd.depthwise = nd.cd.groups != 1;
                 if ((nd.absorbed_by >= 0 && ND[nd.absorbed_by].fbd_b == i) || (nd.dual_host >= 0 && ND[nd.dual_host].fbd_a >= 0)) break;   // DS: in LDS
+                if (nd.p12_a >= 0) break;                    // the 1x1's output lives in LDS inside the launch
                 if (nd.fb_a >= 0 || (nd.absorbed_by >= 0 && ND[nd.absorbed_by].fb_b == i) || nd.ir_a >= 0 ||
                     (nd.absorbed_by >= 0 && ND[nd.absorbed_by].ir_b == i)) {
                     // source lives in LDS inside the fused launch: no HBM form.  (The block's first conv
@@ -972,6 +999,34 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     if (nd.fbd_s2) snprintf(kb, sizeof kb, "f8::fused_opener_kernel<%d, %d, %d, %d, %d, %s>", na.cd.cin, na.cd.cout, x.W, nd.fb_R, nd.cd.cout,
                                             (opt.opener_stg && st.out.f8[0] >= 0) ? "true" : "false");
                     else snprintf(kb, sizeof kb, "f8::fused_bottleneck_kernel<%d, %d, %d, %d, %d, true>", na.cd.cin, na.cd.cout, x.W, nd.fb_R, nd.cd.cout);
+                    st.kernel = kb;
+                    break;
+                }
+                if (nd.p12_a >= 0) {
+                    // ---- 1x1 -> 3x3 of a 7x7 bottleneck block in one launch: nd is the 3x3
+                    Node& na = ND[nd.p12_a];
+                    Tensor& x = T[na.a];
+                    st.kind = S_P12;
+                    st.src_t = na.a;
+                    int n0 = 0; consumer_format(x, na.cd, &n0, "finalize");
+                    st.src_f = find_form(x, FORM_I8, n0, na.cd.input_signed ? 1 : 0);
+                    pack_conv_weights(net, na, x, T[na.out]);
+                    pack_conv_weights(net, nd, T[nd.a], T[nd.out]);
+                    pack_frag_weights(net, na);
+                    pack_frag_weights(net, nd);
+                    st.relu0 = nd.cd.relu;
+                    select_outputs(net, out_t, &st.out, &extra);
+                    if (st.out.f32 >= 0) return fail(F8_ERR_UNSUPPORTED, "finalize: the fused 1x1 -> 3x3 launch writes int8 forms only");
+                    Tensor& o = T[out_t];
+                    const double px = (double)x.H * x.W;
+                    st.ops_per_img = 2.0 * px * ((double)na.cd.cin * na.cd.cout + 9.0 * nd.cd.cin * nd.cd.cout);
+                    double b = px * x.Cs;
+                    for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += px * o.Cs;
+                    st.bytes_per_img = b;
+                    st.bytes_const = (double)na.coutP * (na.ktot + 4) + (double)nd.coutP * (nd.ktot + 4);
+                    st.name = "fused_p12:" + tname(net, na.out) + "+" + tname(net, nd.out);
+                    char kb[96];
+                    snprintf(kb, sizeof kb, "f8::fused_p12_kernel<%d, %d>", na.cd.cin, na.cd.cout);
                     st.kernel = kb;
                     break;
                 }
@@ -1471,6 +1526,22 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1;
             fill_out(&a.out32, a.q);
             e = launch_fused_bottleneck(a, s);
+            break;
+        }
+        case S_P12: {
+            const Node& na = net->nodes[nd.p12_a];
+            const Tensor& x = T[st.src_t]; const Form& xF = x.forms[st.src_f];
+            FusedArgs a{};
+            a.x8 = (const int8_t*)fp(xF); a.x_bytes = (uint32_t)(xF.bytes_per_img * N);
+            a.w0 = (const int8_t*)(net->d_w + na.wf_off); a.w0_bytes = (uint32_t)((size_t)na.coutP * na.ktot);     // fragment order
+            a.w2 = (const int8_t*)(net->d_w + nd.wf_off); a.w2_bytes = (uint32_t)((size_t)nd.coutP * nd.ktot);
+            a.b0 = (const int32_t*)(net->d_w + na.b_off); a.b2 = (const int32_t*)(net->d_w + nd.b_off);
+            a.N = N; a.H = x.H; a.W = x.W; a.C = na.cd.cin; a.MID = na.cd.cout;
+            { int nn = 0; consumer_format(T[nd.a], nd.cd, &nn, "run"); a.n1 = nn; a.lo1 = nd.cd.input_signed ? -127 : 0; a.hi1 = nd.cd.input_signed ? 127 : 255;
+              a.xor1 = nd.cd.input_signed ? 0u : 0x80808080u; }
+            a.relu_a = na.cd.relu; a.relu_b = nd.cd.relu;
+            fill_out(&a.out32, a.q);
+            e = launch_fused_p12(a, s);
             break;
         }
         case S_IR: {

@@ -79,7 +79,7 @@ def test_run_without_gpu_fails_loudly():
     assert rc < 0 and b'hip' in _lib.lib().f8_last_error().lower()
 
 
-@pytest.mark.parametrize('arch,launches,fused,dual', [('resnet18', 24, 0, 0), ('resnet50', 41, 5, 3), ('mobilenet_v1', 31, 0, 0),
+@pytest.mark.parametrize('arch,launches,fused,dual', [('resnet18', 24, 0, 0), ('resnet50', 39, 5, 3), ('mobilenet_v1', 31, 0, 0),
                                                        ('mobilenet_v2', 40, 0, 0)])
 def test_plan_fuses_requant_relu_residual(arch, launches, fused, dual):
     spec = topology.get(arch)
@@ -104,6 +104,8 @@ def test_plan_fuses_requant_relu_residual(arch, launches, fused, dual):
     ir = [l for l in plan.splitlines() if 'fused_ir_' in l]
     assert len(ir) == (8 if arch == 'mobilenet_v2' else 0)      # the blocks where the fused launch wins (option fuse_ir = 2: all 16)
     assert plan.count('_res:') + plan.count('_dual:') + fused + opener + sum('res=1' in l for l in ir) == n_res_blocks
+    # the 7x7 identity blocks of ResNet-50: body.0 + body.2 are one launch (f8_p12.hip), the residual-carrying 1x1 stays
+    assert plan.count('fused_p12:') == (2 if arch == 'resnet50' else 0)
     assert net.weight_bytes > 0 and net.arena_bytes > 0
 
 
@@ -122,13 +124,13 @@ def test_plan_keeps_int32_only_where_semantics_need_it():
     assert not any(re.search(r'conv1x1s1_t\d+x\d+x\d+:stage_\d_layer_0\.body\.4 ', l) for l in lines)
     # the stage-0 opening block (body.0 and shortcut.0 share one int8 form of the block input in the real fraclen table)
     # is ONE launch: 1x1 -> 3x3 -> [1x1 + shortcut 1x1] + join
-    assert sum('fused_bottleneck_ds' in l for l in lines) == 1 and net.num_launches == 29
+    assert sum('fused_bottleneck_ds' in l for l in lines) == 1 and net.num_launches == 27
     # ... and so is the stage-1 opening block with its stride-2 3x3 (the 56x56x128 intermediate never exists in HBM)
     assert sum('fused_opener_s2' in l for l in lines) == 1
     # the five 14x14 identity blocks are fused too at this batch (64 images per launch = 128 workgroups), not at bs 32
     assert sum('fused_bottleneck' in l and 'stage_2' in l for l in lines) == 5
     small = build_net(spec, synth.make_params(spec, 1234, topology.R50_NVIDIA_FRACLENS), max_batch=32, hw=224)
-    assert small.num_launches == 39 and not any('fused_bottleneck' in l and 'stage_2' in l for l in small.describe().splitlines())
+    assert small.num_launches == 37 and not any('fused_bottleneck' in l and 'stage_2' in l for l in small.describe().splitlines())
     # the head is ONE launch: stem conv + ReLU + requant + max-pool (requant commutes with max; the 112x112 map stays in LDS)
     assert any('stem7x7s2+maxpool3x3s2' in l for l in lines) and not any('maxpool_i' in l for l in lines)
     # algorithmic bytes are reported per launch and sum to less than the structural model
