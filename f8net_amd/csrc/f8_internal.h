@@ -17,6 +17,7 @@ struct Options {
     int fuse_ds = 1;             // stage-opening block at unchanged resolution in one launch
     int fuse_opener = 1;         // stage-opening block with a stride-2 3x3 in one launch
     int fuse_stem = 1;           // stem conv + max-pool in one launch
+    int wreg = 1;                // late 1x1 convs on conv1x1_wreg_kernel (weights straight to registers, f8_wreg.hip)
     int fuse_p12 = 1;            // 7x7 identity blocks: body.0 + body.2 in one launch, split over a workgroup pair per image (f8_p12.hip)
     int fuse_ir = 1;             // MobileNet-V2 inverted residual (expand -> depthwise -> project) in one launch: 1 = where it wins, 2 = always
     int patch3x3 = 1;            // LDS-patch 3x3 kernel
@@ -199,6 +200,9 @@ hipError_t launch_fused_opener(const FusedArgs& a, hipStream_t s);
 // 1x1 -> 3x3 of a 7x7 bottleneck block in one launch (f8_p12.hip); FusedArgs: x8, w0 / b0, w2 / b2, requant 1, q[] = the int8 outputs
 bool fused_p12_supported(int C, int MID, int H, int W);
 hipError_t launch_fused_p12(const FusedArgs& a, hipStream_t s);
+// 1x1 conv with the weights streamed into registers (f8_wreg.hip); ConvArgs::w = the fragment-order image of the weights
+bool conv1x1_wreg_supported(int ck, int coutP);
+hipError_t launch_conv1x1_wreg(const ConvArgs& a, hipStream_t s);
 // MobileNet-V2 inverted residual (f8_ir.hip): instance for the padded channel pair + a tile (R rows or G whole images) that fits LDS
 bool fused_ir_config(int cinS, int coutS, int H, int W, int stride, int* R, int* G);
 hipError_t launch_fused_ir(const IRArgs& a, int cinS, int coutS, hipStream_t s);

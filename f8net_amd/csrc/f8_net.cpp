@@ -80,6 +80,7 @@ struct Node {
     int sp_pool = -1, sp_conv = -1;      // stem conv <-> max-pool fused into one launch (f8_stem.hip)
     int fbd_a = -1, fbd_b = -1;          // shortcut conv hosting a fused stage-opening block (DS): body.0 / body.2 (body.4 = `dual`)
     bool fbd_s2 = false;                 // ... whose 3x3 and shortcut have stride 2 (f8_opener.hip)
+    bool wreg = false;                   // 1x1 conv on conv1x1_wreg_kernel (f8_wreg.hip)
     int p12_a = -1;                      // 3x3 conv hosting "1x1 -> 3x3 in one launch" (f8_p12.hip): its 1x1 producer
     int ir_a = -1, ir_b = -1, ir_R = 0, ir_G = 0;   // project conv of a fused inverted-residual block: its expand / depthwise convs, tile
     int dual = -1;                     // 1x1 conv hosting a join whose other operand is ANOTHER 1x1 conv (node id): one dual-GEMM launch
@@ -208,6 +209,7 @@ static const OptKey kOptKeys[] = {
     {"fuse_stem", "F8_FUSE_STEM", &Options::fuse_stem, 0, 1, true},
     {"fuse_ir", "F8_FUSE_IR", &Options::fuse_ir, 0, 2, true},
     {"fuse_p12", "F8_FUSE_P12", &Options::fuse_p12, 0, 1, true},
+    {"wreg", "F8_WREG", &Options::wreg, 0, 1, true},
     {"patch3x3", "F8_PATCH3X3", &Options::patch3x3, 0, 1, true},
     {"dual_wide", "F8_DUAL_WIDE", &Options::dual_wide, 0, 1 << 30, true},
     {"deep_nk", "F8_DEEP_NK", &Options::deep_nk, 1, 1 << 20, true},
@@ -1156,6 +1158,16 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 st.bytes_const = nd.depthwise ? (double)s.Cs * 13 : (double)nd.coutP * (nd.ktot + 4);
                 if (nd.dual >= 0) st.bytes_const += (double)ND[nd.dual].coutP * (ND[nd.dual].ktot + 4);
                 label_conv_step(net, st, nd);
+                // late, weight-heavy 1x1 convs with int8 outputs only: weights straight to registers (f8_wreg.hip)
+                if (opt.wreg && !nd.depthwise && !nd.stem && d.kernel == 1 && d.stride == 1 && d.pad == 0 && d.groups == 1 && nd.fused_add < 0 &&
+                    nd.dual < 0 && st.out.f32 < 0 && !st.dense && conv1x1_wreg_supported(nd.ck, nd.coutP)) {
+                    nd.wreg = true;
+                    pack_frag_weights(net, nd);
+                    st.name = "conv1x1s1_wreg:" + tname(net, nd.out);
+                    char kb[96];
+                    snprintf(kb, sizeof kb, "f8::conv1x1_wreg_kernel<%d, %d>", nd.ck, nd.coutP);
+                    st.kernel = kb;
+                }
                 break;
             }
             case N_ADD: {
@@ -1458,7 +1470,8 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
                 a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1;
             }
             fill_out(&a.out32, a.q);
-            e = nd.p3_R > 0 ? launch_conv3x3_patch(a, d.cin, s) : launch_conv(a, nd.tile, s);
+            if (nd.wreg) { a.w = (const int8_t*)(net->d_w + nd.wf_off); e = launch_conv1x1_wreg(a, s); }
+            else e = nd.p3_R > 0 ? launch_conv3x3_patch(a, d.cin, s) : launch_conv(a, nd.tile, s);
             break;
         }
         case S_STEMPOOL: {
@@ -1648,7 +1661,7 @@ int f8_net_autotune(f8_net* net, int N, void* stream) {
     for (auto& st : net->steps) {
         if (st.kind != S_CONV) continue;
         Node& nd = net->nodes[st.node];
-        if (nd.p3_R > 0) continue;
+        if (nd.p3_R > 0 || nd.wreg) continue;
         const ConvTile keep = nd.tile;
         ConvTile best = keep; float best_ms = 1e30f;
         for (int c = 0; c < 4; ++c) {

@@ -103,9 +103,14 @@ fused_p12_kernel(const FusedArgs a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(base + i * 8192 + wave * 1024), 16, off, 0, 0, 0);
         }
     };
+    // biases: requested first (older than the DMAs), parked in registers, stored to LDS after the first barrier of P1 — a store right
+    // here made the compiler wait vmcnt(0) behind the DMAs: both x8 quarters had to land before the first weight load was issued
+    static_assert(Cfg::BIAS_INTS == 2 * 512, "two bias words per thread");
+    const int bias_pre[2] = {a.b0[tid], a.b2[tid]};
+    __builtin_amdgcn_sched_barrier(0);
     issue_x(0);
     issue_x(1);
-    for (int i = tid; i < Cfg::BIAS_INTS; i += 512) bias_lds[i] = i < MID ? a.b0[i] : a.b2[i - MID];
+    __builtin_amdgcn_sched_barrier(0);                   // the counted waits of P1 need the weight loads younger than these DMAs
     {   // patch <- biased zero (the border keeps it; P1 writes the 49 interior entries)
         const v4i zv = {(int)a.xor1, (int)a.xor1, (int)a.xor1, (int)a.xor1};
         for (int o = tid * 16; o < PW * PW * MID; o += 512 * 16) *(v4i*)(patch + o) = zv;
@@ -159,7 +164,8 @@ fused_p12_kernel(const FusedArgs a) {
                 wait_vmcnt<(NBUF - 1) * 2 * NB1>();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                if constexpr (Q >= 1 && Q + 1 < 4) issue_x(Q + 1);
+                if constexpr (Q == 0) { bias_lds[tid] = bias_pre[0]; bias_lds[MID + tid] = bias_pre[1]; }      // read after later barriers
+                if constexpr (Q >= 1 && Q + 1 < 4) { issue_x(Q + 1); __builtin_amdgcn_sched_barrier(0); }
             }
             if constexpr (B + NBUF - 1 < NBAT1) load_batch(wbuf[(B + NBUF - 1) % NBUF], (B + NBUF - 1) * NB1);
             mul_batch(wbuf[B % NBUF], xq + ((B / BPQ) & 1) * XQ_BYTES, (B % BPQ) * NB1);

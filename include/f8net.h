@@ -219,8 +219,10 @@ int f8_net_set_input_ready(f8_net* net, void* event);
  * chunk56) and otherwise the measured best; two handles in one process may differ.  Keys that decide the plan must be set
  * before f8_net_finalize (F8_ERR_STATE afterwards); scheduling keys may change between runs.
  *   planning  : split (1..4 concurrent sub-batches = arena copies), fuse_blocks, fuse_stages (bit mask, -1 = auto), fuse_dual,
- *               fuse_ds, fuse_opener, fuse_stem, fuse_ir (1 = where it wins, 2 = every block), patch3x3, dual_wide, deep_nk, bk128,
- *               dw_dot4, opener_stg, whole_batch_launches (hint: runs will use f8_net_set_pipelined(2))
+ *               fuse_ds, fuse_opener, fuse_stem, fuse_ir (1 = where it wins, 2 = every block), fuse_p12 (7x7 block: first two
+ *               convs in one launch), wreg (weights-in-registers 1x1 kernel for the 512 -> 256 / 1024 -> 512 reductions),
+ *               patch3x3, dual_wide, deep_nk, bk128, dw_dot4, opener_stg, whole_batch_launches (hint: runs will use
+ *               f8_net_set_pipelined(2))
  *   scheduling: chunk56 / chunk28 / chunk14 (images per chunk of the fused blocks; -1 = derived from chunk_budget_mb, 0 = whole
  *               batch), chunk_budget_mb (memory-side cache a chunk's int32 stream may occupy), chunk_ds, chunk_opener,
  *               split_streams, graph, stagger, stagger_pipelined, stem_wpc, check_device, pipeline_depth (2..4 runs in flight)

@@ -251,6 +251,54 @@ def test_downsample_block_dual_gemm_matches_oracle(dev, shape, variant):
     assert (np.abs(want.astype(np.int64)) > 2**30).any()       # the join ran at full int32 width (wrap-around arithmetic)
 
 
+WREG_SHAPES = [(512, 256, 1024, 12, 3), (1024, 512, 2048, 14, 2), (1024, 512, 2048, 6, 5), (1024, 512, 2048, 28, 1)]   # Cin, MID, Cout, H, N
+
+
+@pytest.mark.parametrize('shape', WREG_SHAPES, ids=lambda g: 'x'.join(map(str, g)))
+@pytest.mark.parametrize('signed_mid', [False, True])
+def test_weights_in_registers_1x1_matches_oracle(dev, shape, signed_mid):
+    """body.0 of the stage-2 / stage-3 opening blocks runs on conv1x1_wreg_kernel (f8_wreg.hip): pixel counts that are not a
+    multiple of the 64-pixel tile, grids below one workgroup per XCD, both int8 output conventions.  Three runs each: the kernel's
+    counted vmcnt wait once returned with a DMA in flight (scheduler-hoisted weight loads), which showed as sporadic mismatches."""
+    from f8net_amd import topology
+    from f8net_amd.net import F8Net
+    Cin, MID, Cout, H, N = shape
+    body = [topology.ConvSpec('blk.body.0', Cin, MID, 1, 1, 0, relu=not signed_mid),
+            topology.ConvSpec('blk.body.2', MID, MID, 3, 2, 1, relu=True),
+            topology.ConvSpec('blk.body.4', MID, Cout, 1, 1, 0)]
+    body[1].signed_in = signed_mid
+    sc = topology.ConvSpec('blk.shortcut.0', Cin, Cout, 1, 2, 0)
+    b = topology.BlockSpec('blk', body, sc, residual=True, post_relu=True)
+    fls = {'blk.body.0': (4, 7), 'blk.body.2': (3, 6), 'blk.body.4': (3, 5), 'blk.shortcut.0': (5, 7)}
+    x_fl = 9
+    params = {}
+    for c in body + [sc]:
+        in_fl, w_fl = fls[c.key]
+        params[c.key + '.weight'] = np.clip(synth.rand_normal_int(25, c.key + 'w', (c.cout, c.cin, c.k, c.k), 40.0), -127, 127).astype(np.int32)
+        params[c.key + '.bias'] = synth.rand_normal_int(26, c.key + 'b', (c.cout,), 2.0 ** 16).astype(np.int32)
+        params[c.key + '.weight_fraclen'] = np.array(w_fl, np.int32)
+        params[c.key + '.input_fraclen'] = np.array([in_fl], np.int32)
+    x = synth.rand_normal_int(27, f'wregx{shape}', (N, Cin, H, H), 2.0e3).astype(np.int32)
+    net = F8Net()
+    t = net.input(Cin, H, H, x_fl)
+    r = t
+    for c in body:
+        r = net.conv(r, params[c.key + '.weight'], params[c.key + '.bias'], stride=c.stride, pad=c.pad, groups=1,
+                     weight_fl=fls[c.key][1], input_fl=fls[c.key][0], input_signed=c.signed_in, quant_input=True, relu=c.relu)
+    s_ = net.conv(t, params[sc.key + '.weight'], params[sc.key + '.bias'], stride=2, pad=0, groups=1,
+                  weight_fl=fls[sc.key][1], input_fl=fls[sc.key][0], input_signed=False, quant_input=True, relu=False)
+    r = net.add(r, s_, relu=True)
+    net.output(r, as_float=False)
+    net.finalize(N)
+    assert 'conv1x1s1_wreg:' in net.describe(), net.describe()
+    want, want_fl = oracle.block_forward(b, params, x, x_fl)
+    assert net.output_fraclen == want_fl
+    xd = _t(x, dev)
+    for _ in range(3):
+        got = net.run(xd).cpu().numpy().reshape(want.shape)
+        np.testing.assert_array_equal(got, want)
+
+
 @pytest.mark.parametrize('variant', ['body_shifts_left', 'shortcut_shifts_left', 'different_input_formats'])
 def test_stage_opening_block_fused_matches_oracle(dev, variant):
     """ResNet-50's stage-0 opening block (64 -> 64 -> 64 -> 256 + 1x1 shortcut, stride 1, 56 wide) as a net of its own:
