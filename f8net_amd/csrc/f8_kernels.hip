@@ -750,9 +750,14 @@ __global__ void __launch_bounds__(256) topk_correct_kernel(const float* logits, 
         for (int k = 0; k < nk; ++k) correct[(size_t)k * N + n] = (valid && rank < ks.k[k]) ? 1.f : 0.f;
 }
 
-// Stem form only, W % 4 == 0: one thread = 4 consecutive pixels (3 dwordx4 plane reads, one dwordx4 write).
+// Stem form only, W % 4 == 0: one thread = 4 consecutive pixels (3 dwordx4 plane reads, one dwordx4 write).  KIND: 0 int32 planes,
+// 1 fp32 planes (quantised here), 2 uint8 NCHW planes, 3 uint8 NHWC pixels (both through the LUT); C is a compile-time 3 for the
+// image case so the channel loop unrolls and the pixel values stay in registers (the runtime-C form indexed a private array with a
+// loop counter: 2.5 TB/s on a pure streaming kernel).
+template <int KIND, int CT>
 __global__ void __launch_bounds__(256) input_stem4_kernel(const InArgs a) {
     const int W4 = a.W >> 2;
+    const int C = CT ? CT : a.C;
     const size_t total = (size_t)a.N * a.H * W4;
     const size_t plane = (size_t)a.H * a.W;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -760,31 +765,31 @@ __global__ void __launch_bounds__(256) input_stem4_kernel(const InArgs a) {
         size_t t = idx / W4;
         const int h = (int)(t % a.H);
         const int n = (int)(t / a.H);
-        const size_t pix0 = ((size_t)n * a.C * a.H + h) * a.W + w;
+        const size_t pix0 = ((size_t)n * C * a.H + h) * a.W + w;
         int v[4][4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 4; ++c) {
+            const bool live = CT ? c < CT : c < C;
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[c][j] = 0;
-        for (int c = 0; c < a.C; ++c) {
-            if (a.xu8) {
-                // uint8 pixels (1 B / px / channel instead of 4): NCHW = one dword of the plane, NHWC = 4 strided bytes
+            if (!live) continue;
+            if constexpr (KIND == 3) {
                 const int16_t* lut = a.lut + (c < 3 ? c : 2) * 256;
-                if (a.u8_nhwc) {
-                    const uint8_t* p = a.xu8 + ((((size_t)n * a.H + h) * a.W) + w) * a.C + c;
+                const uint8_t* p = a.xu8 + ((((size_t)n * a.H + h) * a.W) + w) * C + c;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[c][j] = lut[p[(size_t)j * a.C]];
-                } else {
-                    const unsigned d = *(const unsigned*)(a.xu8 + pix0 + c * plane);
+                for (int j = 0; j < 4; ++j) v[c][j] = lut[p[(size_t)j * C]];
+            } else if constexpr (KIND == 2) {
+                // uint8 pixels (1 B / px / channel instead of 4): one dword of the plane
+                const int16_t* lut = a.lut + (c < 3 ? c : 2) * 256;
+                const unsigned d = *(const unsigned*)(a.xu8 + pix0 + c * plane);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[c][j] = lut[(d >> (8 * j)) & 0xffu];
-                }
-            } else if (a.xf) {
+                for (int j = 0; j < 4; ++j) v[c][j] = lut[(d >> (8 * j)) & 0xffu];
+            } else if constexpr (KIND == 1) {
                 const v4f f = *(const v4f*)(a.xf + pix0 + c * plane);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[c][j] = quant_in(f[j], a.scale, a.qlo, a.qhi);
             } else {
-                const v4i x = *(const v4i*)(a.x + pix0 + c * plane);
+                const v4i x = __builtin_nontemporal_load((const v4i*)(a.x + pix0 + c * plane));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[c][j] = x[j];
             }
@@ -1029,7 +1034,12 @@ hipError_t launch_add(const AddArgs& a, hipStream_t s) {
 }
 hipError_t launch_input(const InArgs& a, hipStream_t s) {
     if (a.stem && !a.out8 && !a.out32 && (a.W & 3) == 0 && a.C <= 4) {
-        hipLaunchKernelGGL(input_stem4_kernel, dim3(grid_for((size_t)a.N * a.H * (a.W >> 2), 256, 1 << 20)), dim3(256), 0, s, a);
+        const dim3 grid(grid_for((size_t)a.N * a.H * (a.W >> 2), 256, 1 << 20));
+        const int kind = a.xu8 ? (a.u8_nhwc ? 3 : 2) : a.xf ? 1 : 0;
+#define F8_IN(K, CT) hipLaunchKernelGGL((input_stem4_kernel<K, CT>), grid, dim3(256), 0, s, a)
+        if (a.C == 3) { if (kind == 0) F8_IN(0, 3); else if (kind == 1) F8_IN(1, 3); else if (kind == 2) F8_IN(2, 3); else F8_IN(3, 3); }
+        else          { if (kind == 0) F8_IN(0, 0); else if (kind == 1) F8_IN(1, 0); else if (kind == 2) F8_IN(2, 0); else F8_IN(3, 0); }
+#undef F8_IN
         return hipGetLastError();
     }
     hipLaunchKernelGGL(input_kernel, dim3(grid_for((size_t)a.N * a.H * a.W)), dim3(256), 0, s, a);

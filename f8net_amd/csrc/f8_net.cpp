@@ -81,6 +81,7 @@ struct Node {
     int fbd_a = -1, fbd_b = -1;          // shortcut conv hosting a fused stage-opening block (DS): body.0 / body.2 (body.4 = `dual`)
     bool fbd_s2 = false;                 // ... whose 3x3 and shortcut have stride 2 (f8_opener.hip)
     bool wreg = false;                   // 1x1 conv on conv1x1_wreg_kernel (f8_wreg.hip)
+    bool wstat = false;                  // 1x1 conv / dual GEMM / residual join on conv1x1_wstat_kernel (f8_wstat.hip)
     int p12_a = -1;                      // 3x3 conv hosting "1x1 -> 3x3 in one launch" (f8_p12.hip): its 1x1 producer
     int ir_a = -1, ir_b = -1, ir_R = 0, ir_G = 0;   // project conv of a fused inverted-residual block: its expand / depthwise convs, tile
     int dual = -1;                     // 1x1 conv hosting a join whose other operand is ANOTHER 1x1 conv (node id): one dual-GEMM launch
@@ -210,6 +211,8 @@ static const OptKey kOptKeys[] = {
     {"fuse_ir", "F8_FUSE_IR", &Options::fuse_ir, 0, 2, true},
     {"fuse_p12", "F8_FUSE_P12", &Options::fuse_p12, 0, 1, true},
     {"wreg", "F8_WREG", &Options::wreg, 0, 1, true},
+    {"wstat", "F8_WSTAT", &Options::wstat, 0, 1, true},
+    {"wstat_min_tiles", "F8_WSTAT_MIN_TILES", &Options::wstat_min_tiles, 0, 1 << 20, true},
     {"patch3x3", "F8_PATCH3X3", &Options::patch3x3, 0, 1, true},
     {"dual_wide", "F8_DUAL_WIDE", &Options::dual_wide, 0, 1 << 30, true},
     {"deep_nk", "F8_DEEP_NK", &Options::deep_nk, 1, 1 << 20, true},
@@ -1158,8 +1161,35 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 st.bytes_const = nd.depthwise ? (double)s.Cs * 13 : (double)nd.coutP * (nd.ktot + 4);
                 if (nd.dual >= 0) st.bytes_const += (double)ND[nd.dual].coutP * (ND[nd.dual].ktot + 4);
                 label_conv_step(net, st, nd);
+                // 1x1 convs (plain, with the residual join, or as the dual GEMM of a stage-opening block) whose weight slice per wave
+                // fits the register file: weight-stationary kernel, when a launch gives every workgroup a few pixel tiles to walk
+                if (opt.wstat && !nd.depthwise && !nd.stem && d.kernel == 1 && d.pad == 0 && d.groups == 1 && !st.dense) {
+                    const int k1 = nd.dual >= 0 ? ND[nd.dual].ktot : 0;
+                    const bool has_res = nd.dual < 0 && st.res_t >= 0;
+                    const bool g_ok = nd.dual < 0 || (ND[nd.dual].cd.kernel == 1 && ND[nd.dual].cd.pad == 0 && ND[nd.dual].cd.groups == 1);
+                    if (g_ok && conv1x1_wstat_supported(nd.ck, k1, nd.coutP, has_res)) {
+                        const int imgs = opt.whole_batch_launches ? max_batch : std::max(1, max_batch / opt.split);
+                        const long tiles = ((long)imgs * (long)opix + 31) / 32;
+                        const int ngroups = nd.coutP / (32 * conv1x1_wstat_waves(nd.ck, k1));
+                        const int cus = net->num_cu > 0 ? net->num_cu : 256;
+                        if (tiles >= (long)opt.wstat_min_tiles * std::max(1, cus / ngroups)) {
+                            nd.wstat = true;
+                            pack_frag_weights(net, nd);
+                            if (nd.dual >= 0) pack_frag_weights(net, ND[nd.dual]);
+                            const size_t colon = st.name.find(':');
+                            st.name = std::string(nd.dual >= 0 ? "conv1x1_wstat_dual" : has_res ? "conv1x1_wstat_res" : "conv1x1_wstat") +
+                                      (colon == std::string::npos ? ":" + tname(net, nd.out) : st.name.substr(colon));
+                            char kb[144];
+                            bool fast = !st.relu0 || (nd.dual < 0 && !has_res && st.out.f32 < 0);      // keep in sync with conv1x1_wstat_fast
+                            for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0 && T[st.out.t].forms[st.out.f8[k]].n <= 0) fast = false;
+                            snprintf(kb, sizeof kb, "f8::conv1x1_wstat_kernel<%d, %d, %d, %s, %s, %d, %s>", nd.ck, k1, conv1x1_wstat_waves(nd.ck, k1), has_res ? "true" : "false",
+                                     st.out.f32 >= 0 ? "true" : "false", (st.out.f8[0] >= 0 ? 1 : 0) + (st.out.f8[1] >= 0 ? 1 : 0), fast ? "true" : "false");
+                            st.kernel = kb;
+                        }
+                    }
+                }
                 // late, weight-heavy 1x1 convs with int8 outputs only: weights straight to registers (f8_wreg.hip)
-                if (opt.wreg && !nd.depthwise && !nd.stem && d.kernel == 1 && d.stride == 1 && d.pad == 0 && d.groups == 1 && nd.fused_add < 0 &&
+                if (!nd.wstat && opt.wreg && !nd.depthwise && !nd.stem && d.kernel == 1 && d.stride == 1 && d.pad == 0 && d.groups == 1 && nd.fused_add < 0 &&
                     nd.dual < 0 && st.out.f32 < 0 && !st.dense && conv1x1_wreg_supported(nd.ck, nd.coutP)) {
                     nd.wreg = true;
                     pack_frag_weights(net, nd);
@@ -1470,7 +1500,11 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
                 a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1;
             }
             fill_out(&a.out32, a.q);
-            if (nd.wreg) { a.w = (const int8_t*)(net->d_w + nd.wf_off); e = launch_conv1x1_wreg(a, s); }
+            if (nd.wstat) {
+                a.w = (const int8_t*)(net->d_w + nd.wf_off);
+                if (nd.dual >= 0) a.w2 = (const int8_t*)(net->d_w + net->nodes[nd.dual].wf_off);
+                e = launch_conv1x1_wstat(a, net->num_cu, s);
+            } else if (nd.wreg) { a.w = (const int8_t*)(net->d_w + nd.wf_off); e = launch_conv1x1_wreg(a, s); }
             else e = nd.p3_R > 0 ? launch_conv3x3_patch(a, d.cin, s) : launch_conv(a, nd.tile, s);
             break;
         }
@@ -1661,7 +1695,7 @@ int f8_net_autotune(f8_net* net, int N, void* stream) {
     for (auto& st : net->steps) {
         if (st.kind != S_CONV) continue;
         Node& nd = net->nodes[st.node];
-        if (nd.p3_R > 0 || nd.wreg) continue;
+        if (nd.p3_R > 0 || nd.wreg || nd.wstat) continue;
         const ConvTile keep = nd.tile;
         ConvTile best = keep; float best_ms = 1e30f;
         for (int c = 0; c < 4; ++c) {

@@ -220,7 +220,9 @@ int f8_net_set_input_ready(f8_net* net, void* event);
  * before f8_net_finalize (F8_ERR_STATE afterwards); scheduling keys may change between runs.
  *   planning  : split (1..4 concurrent sub-batches = arena copies), fuse_blocks, fuse_stages (bit mask, -1 = auto), fuse_dual,
  *               fuse_ds, fuse_opener, fuse_stem, fuse_ir (1 = where it wins, 2 = every block), fuse_p12 (7x7 block: first two
- *               convs in one launch), wreg (weights-in-registers 1x1 kernel for the 512 -> 256 / 1024 -> 512 reductions),
+ *               convs in one launch), wstat (weight-stationary 1x1 kernel: plain, dual-GEMM and residual-join instances) with
+ *               wstat_min_tiles (pixel tiles per workgroup a launch must offer; 0 = always), wreg (weights-streamed 1x1 kernel for the
+ *               512 -> 256 / 1024 -> 512 reductions of smaller launches),
  *               patch3x3, dual_wide, deep_nk, bk128, dw_dot4, opener_stg, whole_batch_launches (hint: runs will use
  *               f8_net_set_pipelined(2))
  *   scheduling: chunk56 / chunk28 / chunk14 (images per chunk of the fused blocks; -1 = derived from chunk_budget_mb, 0 = whole

@@ -131,6 +131,11 @@ def test_plan_keeps_int32_only_where_semantics_need_it():
     assert sum('fused_bottleneck' in l and 'stage_2' in l for l in lines) == 5
     small = build_net(spec, synth.make_params(spec, 1234, topology.R50_NVIDIA_FRACLENS), max_batch=32, hw=224)
     assert small.num_launches == 37 and not any('fused_bottleneck' in l and 'stage_2' in l for l in small.describe().splitlines())
+    # the 1x1 convs around the stage-2 / stage-3 opening blocks and the closing 1x1 of the 7x7 blocks run weight-stationary (f8_wstat.hip)
+    # when a launch gives every workgroup at least two pixel tiles; smaller launches keep the tile-per-workgroup kernels
+    assert [l.split()[1].split(':')[0] for l in lines if 'wstat' in l] == ['conv1x1_wstat', 'conv1x1_wstat_dual', 'conv1x1_wstat', 'conv1x1_wstat_dual',
+                                                                          'conv1x1_wstat_res', 'conv1x1_wstat_res']
+    assert sum('wstat' in l for l in small.describe().splitlines()) < 6
     # the head is ONE launch: stem conv + ReLU + requant + max-pool (requant commutes with max; the 112x112 map stays in LDS)
     assert any('stem7x7s2+maxpool3x3s2' in l for l in lines) and not any('maxpool_i' in l for l in lines)
     # algorithmic bytes are reported per launch and sum to less than the structural model

@@ -299,6 +299,78 @@ def test_weights_in_registers_1x1_matches_oracle(dev, shape, signed_mid):
         np.testing.assert_array_equal(got, want)
 
 
+# Cin, MID, Cout, H, N, identity block?  (stage-2 opener, stage-3 opener at two sizes, 7x7 identity block, a one-tile launch)
+WSTAT_SHAPES = [(512, 256, 1024, 12, 3, False), (1024, 512, 2048, 14, 2, False), (1024, 512, 2048, 6, 5, False),
+                (2048, 512, 2048, 7, 5, True), (2048, 512, 2048, 7, 1, True), (512, 256, 1024, 4, 1, False)]
+
+
+@pytest.mark.parametrize('shape', WSTAT_SHAPES, ids=lambda g: 'x'.join(map(str, g)))
+@pytest.mark.parametrize('variant', ['body_shifts_left', 'other_shifts_left_signed_mid'])
+@pytest.mark.parametrize('tail', ['i32', 'both'])
+def test_weight_stationary_1x1_matches_oracle(dev, shape, variant, tail):
+    """conv1x1_wstat_kernel (f8_wstat.hip), forced onto small launches with wstat_min_tiles = 0: body.0 of a stage-opening block
+    (plain instance, K = 512 / 1024), its body.4 + strided shortcut as ONE dual GEMM (K = 512 + 256 on 8 waves, 1024 + 512 on 4),
+    and body.4 of a 7x7 identity block with the int32 residual join; int32-only and int32 + int8 outputs, both align directions,
+    pixel counts that are not a multiple of the 32-pixel tile, fewer tiles than workgroups.  Three runs each (counted vmcnt ring)."""
+    from f8net_amd import topology
+    from f8net_amd.net import F8Net
+    Cin, MID, Cout, H, N, identity = shape
+    st = 1 if identity else 2
+    body = [topology.ConvSpec('blk.body.0', Cin, MID, 1, 1, 0, relu=True),
+            topology.ConvSpec('blk.body.2', MID, MID, 3, st, 1, relu=True),
+            topology.ConvSpec('blk.body.4', MID, Cout, 1, 1, 0)]
+    sc = None if identity else topology.ConvSpec('blk.shortcut.0', Cin, Cout, 1, 2, 0)
+    b = topology.BlockSpec('blk', body, sc, residual=True, post_relu=True)
+    x_fl = 9
+    fls = {'blk.body.0': (4, 7), 'blk.body.2': (3, 6), 'blk.body.4': (3, 5), 'blk.shortcut.0': (4, 7)}       # body out fl 8 < 11 / 9
+    if variant == 'other_shifts_left_signed_mid':
+        fls.update({'blk.body.4': (6, 7), 'blk.shortcut.0': (4, 6)})                                             # 13 > 10 / 9
+        body[1].signed_in = True
+        body[0].relu = False
+    params = {}
+    for c in body + ([sc] if sc else []):
+        in_fl, w_fl = fls[c.key]
+        params[c.key + '.weight'] = np.clip(synth.rand_normal_int(55, c.key + 'w' + variant, (c.cout, c.cin, c.k, c.k), 40.0), -127, 127).astype(np.int32)
+        params[c.key + '.bias'] = synth.rand_normal_int(56, c.key + 'b', (c.cout,), 2.0 ** 27 if c.key.endswith(('body.4', 'shortcut.0')) else 2.0 ** 14).astype(np.int32)
+        params[c.key + '.weight_fraclen'] = np.array(w_fl, np.int32)
+        params[c.key + '.input_fraclen'] = np.array([in_fl], np.int32)
+    x = synth.rand_normal_int(57, f'wsx{shape}{variant}', (N, Cin, H, H), 2.0e3 if not identity else 2.0 ** 27).astype(np.int32)
+    net = F8Net()
+    net.set_option('wstat_min_tiles', 0)
+    t = net.input(Cin, H, H, x_fl)
+    r = t
+    for c in body:
+        r = net.conv(r, params[c.key + '.weight'], params[c.key + '.bias'], stride=c.stride, pad=c.pad, groups=1,
+                     weight_fl=fls[c.key][1], input_fl=fls[c.key][0], input_signed=c.signed_in, quant_input=True, relu=c.relu)
+    if sc:
+        s_ = net.conv(t, params[sc.key + '.weight'], params[sc.key + '.bias'], stride=2, pad=0, groups=1,
+                      weight_fl=fls[sc.key][1], input_fl=fls[sc.key][0], input_signed=False, quant_input=True, relu=False)
+        r = net.add(r, s_, relu=True)
+    else:
+        r = net.add(r, t, relu=True)
+    want, want_fl = oracle.block_forward(b, params, x, x_fl)
+    assert (np.abs(want.astype(np.int64)) > 2**30).any()       # the join ran at full int32 width
+    if tail == 'both':                                         # a consumer of the int8 copy, joined with the int32 stream
+        wt = np.clip(synth.rand_normal_int(58, 'tailw', (Cout, Cout, 1, 1), 40.0), -127, 127).astype(np.int32)
+        bt = synth.rand_normal_int(59, 'tailb', (Cout,), 1.0e4).astype(np.int32)
+        in_fl_t, w_fl_t = 2, 6
+        c2 = net.conv(r, wt, bt, stride=1, pad=0, groups=1, weight_fl=w_fl_t, input_fl=in_fl_t, input_signed=False, quant_input=True, relu=False)
+        y = oracle.conv2d(oracle.requant(want, in_fl_t, want_fl, False), wt, bt, 1, 0)
+        r = net.add(c2, r, relu=False)
+        want, _ = oracle.add_align(y, want, in_fl_t + w_fl_t, want_fl)
+    net.output(r, as_float=False)
+    net.finalize(N)
+    plan = net.describe()
+    if identity:
+        assert 'conv1x1_wstat_res:' in plan, plan
+    else:
+        assert 'conv1x1_wstat:' in plan and 'conv1x1_wstat_dual:' in plan, plan
+    xd = _t(x, dev)
+    for _ in range(3):
+        got = net.run(xd).cpu().numpy().reshape(want.shape)
+        np.testing.assert_array_equal(got, want)
+
+
 @pytest.mark.parametrize('variant', ['body_shifts_left', 'shortcut_shifts_left', 'different_input_formats'])
 def test_stage_opening_block_fused_matches_oracle(dev, variant):
     """ResNet-50's stage-0 opening block (64 -> 64 -> 64 -> 256 + 1x1 shortcut, stride 1, 56 wide) as a net of its own:
