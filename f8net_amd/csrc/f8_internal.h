@@ -19,6 +19,7 @@ struct Options {
     int fuse_stem = 1;           // stem conv + max-pool in one launch
     int wstat = 1;               // weight-stationary 1x1 kernel (f8_wstat.hip) where a launch gives every workgroup >= wstat_min_tiles pixel tiles
     int wstat_min_tiles = 2;
+    int s2wreg = 1;              // stride-2 3x3 convs of the stage-2 / stage-3 openers on conv3x3s2_wreg_kernel (f8_s2conv.hip)
     int wreg = 1;                // late 1x1 convs on conv1x1_wreg_kernel (weights straight to registers, f8_wreg.hip)
     int fuse_p12 = 1;            // 7x7 identity blocks: body.0 + body.2 in one launch, split over a workgroup pair per image (f8_p12.hip)
     int fuse_ir = 1;             // MobileNet-V2 inverted residual (expand -> depthwise -> project) in one launch: 1 = where it wins, 2 = always
@@ -205,6 +206,9 @@ hipError_t launch_fused_p12(const FusedArgs& a, hipStream_t s);
 // 1x1 conv with the weights streamed into registers (f8_wreg.hip); ConvArgs::w = the fragment-order image of the weights
 bool conv1x1_wreg_supported(int ck, int coutP);
 hipError_t launch_conv1x1_wreg(const ConvArgs& a, hipStream_t s);
+// 3x3 / stride 2 / pad 1 with the input patch in LDS and the weights streamed into registers (f8_s2conv.hip); ConvArgs::w = fragment order
+bool conv3x3s2_wreg_supported(int ck, int HO, int WO, int coutP);
+hipError_t launch_conv3x3s2_wreg(const ConvArgs& a, hipStream_t s);
 // weight-stationary 1x1 conv / dual GEMM / residual join (f8_wstat.hip); ConvArgs::w (and w2) = fragment-order images
 bool conv1x1_wstat_supported(int k0, int k1, int coutP, bool has_res);
 int conv1x1_wstat_waves(int k0, int k1);

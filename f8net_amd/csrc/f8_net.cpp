@@ -81,6 +81,7 @@ struct Node {
     int fbd_a = -1, fbd_b = -1;          // shortcut conv hosting a fused stage-opening block (DS): body.0 / body.2 (body.4 = `dual`)
     bool fbd_s2 = false;                 // ... whose 3x3 and shortcut have stride 2 (f8_opener.hip)
     bool wreg = false;                   // 1x1 conv on conv1x1_wreg_kernel (f8_wreg.hip)
+    bool s2w = false;                    // 3x3 / stride 2 conv on conv3x3s2_wreg_kernel (f8_s2conv.hip)
     bool wstat = false;                  // 1x1 conv / dual GEMM / residual join on conv1x1_wstat_kernel (f8_wstat.hip)
     int p12_a = -1;                      // 3x3 conv hosting "1x1 -> 3x3 in one launch" (f8_p12.hip): its 1x1 producer
     int ir_a = -1, ir_b = -1, ir_R = 0, ir_G = 0;   // project conv of a fused inverted-residual block: its expand / depthwise convs, tile
@@ -211,6 +212,7 @@ static const OptKey kOptKeys[] = {
     {"fuse_ir", "F8_FUSE_IR", &Options::fuse_ir, 0, 2, true},
     {"fuse_p12", "F8_FUSE_P12", &Options::fuse_p12, 0, 1, true},
     {"wreg", "F8_WREG", &Options::wreg, 0, 1, true},
+    {"s2wreg", "F8_S2WREG", &Options::s2wreg, 0, 1, true},
     {"wstat", "F8_WSTAT", &Options::wstat, 0, 1, true},
     {"wstat_min_tiles", "F8_WSTAT_MIN_TILES", &Options::wstat_min_tiles, 0, 1 << 20, true},
     {"patch3x3", "F8_PATCH3X3", &Options::patch3x3, 0, 1, true},
@@ -1188,6 +1190,17 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                         }
                     }
                 }
+                // the stride-2 3x3 of a late stage-opening block, int8 outputs only: input patch in LDS, weights straight to registers
+                if (opt.s2wreg && !nd.depthwise && !nd.stem && d.kernel == 3 && d.stride == 2 && d.pad == 1 && d.groups == 1 && nd.fused_add < 0 &&
+                    nd.dual < 0 && st.out.f32 < 0 && !st.dense && nd.ck == d.cin && s.H == 2 * T[nd.out].H && s.W == 2 * T[nd.out].W &&
+                    conv3x3s2_wreg_supported(nd.ck, T[nd.out].H, T[nd.out].W, nd.coutP)) {
+                    nd.s2w = true;
+                    pack_frag_weights(net, nd);
+                    st.name = "conv3x3s2_wreg:" + tname(net, nd.out);
+                    char kb[96];
+                    snprintf(kb, sizeof kb, "f8::conv3x3s2_wreg_kernel<%d, %d, %d, %d>", nd.ck, T[nd.out].H, T[nd.out].W, nd.coutP);
+                    st.kernel = kb;
+                }
                 // late, weight-heavy 1x1 convs with int8 outputs only: weights straight to registers (f8_wreg.hip)
                 if (!nd.wstat && opt.wreg && !nd.depthwise && !nd.stem && d.kernel == 1 && d.stride == 1 && d.pad == 0 && d.groups == 1 && nd.fused_add < 0 &&
                     nd.dual < 0 && st.out.f32 < 0 && !st.dense && conv1x1_wreg_supported(nd.ck, nd.coutP)) {
@@ -1500,7 +1513,8 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
                 a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1;
             }
             fill_out(&a.out32, a.q);
-            if (nd.wstat) {
+            if (nd.s2w) { a.w = (const int8_t*)(net->d_w + nd.wf_off); e = launch_conv3x3s2_wreg(a, s); }
+            else if (nd.wstat) {
                 a.w = (const int8_t*)(net->d_w + nd.wf_off);
                 if (nd.dual >= 0) a.w2 = (const int8_t*)(net->d_w + net->nodes[nd.dual].wf_off);
                 e = launch_conv1x1_wstat(a, net->num_cu, s);
@@ -1695,7 +1709,7 @@ int f8_net_autotune(f8_net* net, int N, void* stream) {
     for (auto& st : net->steps) {
         if (st.kind != S_CONV) continue;
         Node& nd = net->nodes[st.node];
-        if (nd.p3_R > 0 || nd.wreg || nd.wstat) continue;
+        if (nd.p3_R > 0 || nd.wreg || nd.wstat || nd.s2w) continue;
         const ConvTile keep = nd.tile;
         ConvTile best = keep; float best_ms = 1e30f;
         for (int c = 0; c < 4; ++c) {

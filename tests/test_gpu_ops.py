@@ -301,7 +301,8 @@ def test_weights_in_registers_1x1_matches_oracle(dev, shape, signed_mid):
 
 # Cin, MID, Cout, H, N, identity block?  (stage-2 opener, stage-3 opener at two sizes, 7x7 identity block, a one-tile launch)
 WSTAT_SHAPES = [(512, 256, 1024, 12, 3, False), (1024, 512, 2048, 14, 2, False), (1024, 512, 2048, 6, 5, False),
-                (2048, 512, 2048, 7, 5, True), (2048, 512, 2048, 7, 1, True), (512, 256, 1024, 4, 1, False)]
+                (2048, 512, 2048, 7, 5, True), (2048, 512, 2048, 7, 1, True), (512, 256, 1024, 4, 1, False),
+                (512, 256, 1024, 28, 3, False), (1024, 512, 2048, 14, 5, False)]     # full-size maps: body.2 on conv3x3s2_wreg_kernel
 
 
 @pytest.mark.parametrize('shape', WSTAT_SHAPES, ids=lambda g: 'x'.join(map(str, g)))
@@ -365,6 +366,9 @@ def test_weight_stationary_1x1_matches_oracle(dev, shape, variant, tail):
         assert 'conv1x1_wstat_res:' in plan, plan
     else:
         assert 'conv1x1_wstat:' in plan and 'conv1x1_wstat_dual:' in plan, plan
+        # the stride-2 3x3 of the real stage-2 / stage-3 openers: input patch in LDS, weights streamed (f8_s2conv.hip); image borders
+        # through the border-class bias (unsigned mid) or real zeros (signed mid), odd image counts (workgroup groups of 4 images)
+        assert ('conv3x3s2_wreg:' in plan) == ((MID, H) in ((256, 28), (512, 14))), plan
     xd = _t(x, dev)
     for _ in range(3):
         got = net.run(xd).cpu().numpy().reshape(want.shape)
