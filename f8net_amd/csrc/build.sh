@@ -19,6 +19,8 @@ $HIPCC $FLAGS -c f8_s2conv.hip -o ../../build/f8_s2conv.o 2> ../../build/f8_s2co
 $HIPCC $FLAGS -x hip -c f8_net.cpp -o ../../build/f8_net.o &
 wait
 for f in f8_kernels f8_fused f8_conv3x3 f8_stem f8_opener f8_ir f8_p12 f8_wreg f8_wstat f8_s2conv; do grep -E "error|warning:" ../../build/$f.log | grep -v Rpass || true; done
+# a failed compile leaves the previous object in place: the link below would silently ship stale code
+if grep -lE "(^|[^a-z])error( generated|:)" ../../build/f8_*.log; then echo "ERROR: compile errors (logs above)"; exit 1; fi
 $HIPCC --offload-arch=gfx950 -shared -fPIC ../../build/f8_kernels.o ../../build/f8_fused.o ../../build/f8_conv3x3.o ../../build/f8_stem.o ../../build/f8_opener.o ../../build/f8_ir.o ../../build/f8_p12.o ../../build/f8_wreg.o ../../build/f8_wstat.o ../../build/f8_s2conv.o ../../build/f8_net.o -o $OUT
 echo "built $(readlink -f $OUT)"
 # a kernel whose host stub was silently dropped would only fail at dlopen time: catch it here

@@ -17,6 +17,7 @@ struct Options {
     int fuse_ds = 1;             // stage-opening block at unchanged resolution in one launch
     int fuse_opener = 1;         // stage-opening block with a stride-2 3x3 in one launch
     int fuse_stem = 1;           // stem conv + max-pool in one launch
+    int fuse_input = 1;          // ... which also reads the raw network input (no input launch, no haloed NHWC4 copy)
     int wstat = 1;               // weight-stationary 1x1 kernel (f8_wstat.hip) where a launch gives every workgroup >= wstat_min_tiles pixel tiles
     int wstat_min_tiles = 2;
     int s2wreg = 1;              // stride-2 3x3 convs of the stage-2 / stage-3 openers on conv3x3s2_wreg_kernel (f8_s2conv.hip)
@@ -185,6 +186,13 @@ struct StemPoolArgs {
     int32_t* out32;                        // pooled int32 (I32T, 64 channels) or nullptr
     QuantOut q[2];                         // pooled int8 NHWC (64 channels) in up to two formats
     int32_t wpc;                           // Options::stem_wpc
+    // raw network input read by the stem launch itself (no input launch, no haloed NHWC4 copy): NCHW planes, raw_kind 0 = int32 (xi),
+    // 1 = fp32 quantised on the fly (xf, scale, qlo, qhi), 2 = uint8 through `lut`; raw_kind < 0: the haloed form `x`
+    int32_t raw_kind, rC, rH, rW;
+    const int32_t* xi; const float* xf; const uint8_t* xu8;
+    float scale; int32_t qlo, qhi;
+    uint32_t xor8;                         // 0x80808080 when the stem's input format is unsigned (stored biased)
+    int16_t lut[3 * 256];
 };
 
 struct ConvTile { int bm, bn, bk; };

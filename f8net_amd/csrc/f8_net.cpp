@@ -104,6 +104,7 @@ struct Step {
     OutSel out;
     int acc_shl = 0, res_shl = 0, relu0 = 0, relu1 = 0;
     bool dense = false;
+    bool raw_input = false;            // S_INPUT: its work is done by the stem launch (S_STEMPOOL with the same flag) unless the run's input is uint8 NHWC
     std::string name, kernel;          // kernel = device symbol as rocprofv3 prints it
     double bytes_per_img = 0, bytes_const = 0, ops_per_img = 0;
 };
@@ -209,6 +210,7 @@ static const OptKey kOptKeys[] = {
     {"fuse_ds", "F8_FUSE_DS", &Options::fuse_ds, 0, 1, true},
     {"fuse_opener", "F8_FUSE_OPENER", &Options::fuse_opener, 0, 1, true},
     {"fuse_stem", "F8_FUSE_STEM", &Options::fuse_stem, 0, 1, true},
+    {"fuse_input", "F8_FUSE_INPUT", &Options::fuse_input, 0, 1, true},
     {"fuse_ir", "F8_FUSE_IR", &Options::fuse_ir, 0, 2, true},
     {"fuse_p12", "F8_FUSE_P12", &Options::fuse_p12, 0, 1, true},
     {"wreg", "F8_WREG", &Options::wreg, 0, 1, true},
@@ -1268,6 +1270,17 @@ int f8_net_finalize(f8_net* net, int max_batch) {
             bool only_stem = !o.forms.empty();
             for (auto& F : o.forms) only_stem = only_stem && F.kind == FORM_STEM;
             if (only_stem && (o.W & 3) == 0 && o.C <= 4) st.kernel = "f8::input_stem4_kernel";
+            // the fused stem launch can read the raw input itself: the input step then launches nothing (run_step)
+            if (only_stem && o.C == 3 && net->opt.fuse_input) {
+                Step* stem = nullptr; int users = 0;
+                for (auto& s2 : net->steps) if (s2.src_t == st.out.t) { ++users; if (s2.kind == S_STEMPOOL) stem = &s2; }
+                if (stem && users == 1) {
+                    st.raw_input = stem->raw_input = true;
+                    stem->bytes_per_img += (double)o.C * o.H * o.W * 4 - (double)o.H * o.W * 4;      // int32 planes instead of the NHWC4 copy
+                    st.bytes_per_img = 0;
+                    st.name = "input(read by the stem launch)";
+                }
+            }
         }
     // ---- 4. lifetimes and arena layout (first-fit over a free list; in-place residual update)
     for (size_t si = 0; si < net->steps.size(); ++si) {
@@ -1467,6 +1480,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
     switch (st.kind) {
         case S_INPUT: {
             const Tensor& o = T[st.out.t];
+            if (st.raw_input && !(net->in_u8 && net->in_u8_nhwc)) break;       // the stem launch reads the caller's buffer
             InArgs a{}; a.x = input + (size_t)n0 * o.C * o.H * o.W; a.N = N; a.C = o.C; a.H = o.H; a.W = o.W;
             if (net->in_f32) { a.xf = net->in_f32 + (size_t)n0 * o.C * o.H * o.W; a.scale = net->in_scale; a.qlo = net->in_lo; a.qhi = net->in_hi; }
             if (net->in_u8) { a.xu8 = net->in_u8 + (size_t)n0 * o.C * o.H * o.W; a.u8_nhwc = net->in_u8_nhwc; memcpy(a.lut, net->in_lut, sizeof a.lut); }
@@ -1533,6 +1547,14 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             a.N = N; a.Hp = sF.Hp; a.Wp = sF.Wp; a.org = sF.pad - nd.cd.pad;
             a.Pc = cT.H; a.Qc = cT.W; a.P = oT.H; a.Q = oT.W;
             a.relu0 = st.relu0; a.wpc = net->opt.stem_wpc;
+            a.raw_kind = -1;
+            if (st.raw_input && !(net->in_u8 && net->in_u8_nhwc)) {
+                const size_t img = (size_t)sT.C * sT.H * sT.W;
+                a.rC = sT.C; a.rH = sT.H; a.rW = sT.W; a.xor8 = sF.sgn ? 0u : 0x80808080u;
+                if (net->in_u8) { a.raw_kind = 2; a.xu8 = net->in_u8 + (size_t)n0 * img; memcpy(a.lut, net->in_lut, sizeof a.lut); }
+                else if (net->in_f32) { a.raw_kind = 1; a.xf = net->in_f32 + (size_t)n0 * img; a.scale = net->in_scale; a.qlo = net->in_lo; a.qhi = net->in_hi; }
+                else { a.raw_kind = 0; a.xi = input + (size_t)n0 * img; }
+            }
             fill_out(&a.out32, a.q);
             e = launch_stem_pool(a, s);
             break;

@@ -22,6 +22,11 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 
 namespace {
+// rint(x * scale) clamped (fix_train.py:683-692 through input_kernel's quant_in)
+__device__ __forceinline__ int quant_in_stem(float x, float scale, int lo, int hi) {
+    const float r = rintf(__fmul_rn(x, scale));      // one IEEE multiply, as quant_in (f8_kernels.hip)
+    return (int)fminf(fmaxf(r, (float)lo), (float)hi);
+}
 constexpr int TP = 7, TQ = 8;                       // pooled pixels per tile
 constexpr int RH = 2 * TP + 1, RW = 2 * TQ + 1;     // conv region 15 x 17
 constexpr int RPX = RH * RW;                        // 255
@@ -37,6 +42,7 @@ constexpr int CT_BYTES = 256 * CT_PITCH;            // conv tile of ONE 32-chann
 constexpr int LDS_TOTAL = 2 * PATCH_BYTES + W_BYTES + CT_BYTES;      // two patch slots
 }
 
+template <int KIND>
 __global__ void __launch_bounds__(512) stem_pool_kernel(const StemPoolArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[LDS_TOTAL];
     char* const wl = lds + 2 * PATCH_BYTES;
@@ -85,8 +91,69 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemPoolArgs a) {
         if (dma_wave)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(lds + slot * PATCH_BYTES + wave * 1024), 16, off, 0, 0, 0);
     };
+    // KIND >= 0: the patch is built from the raw NCHW input instead (f8_net_run / _f32 / _u8 without an input launch): this thread's
+    // slot = 4 consecutive pixels of one patch row, 3 planes -> 12 element loads one tile ahead (registers), converted, packed to
+    // NHWC4 bytes and stored to the other patch slot at the end of the iteration.  Out-of-image elements load 0 through the buffer
+    // range check = the (biased) zero of the padding.
+    const __amdgpu_buffer_rsrc_t rraw = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(KIND == 0 ? (const void*)a.xi : KIND == 1 ? (const void*)a.xf : (const void*)a.xu8), 0,
+        (unsigned)((size_t)a.N * a.rC * a.rH * a.rW * (KIND == 2 ? 1 : 4)), 0x00020000);
+    int rawv[KIND >= 0 ? 12 : 1];
+    unsigned rawok = 0;                                  // bit j: column j of the slot lies inside the image (and so does the row)
+    auto load_raw = [&](int t) {
+        if constexpr (KIND >= 0) {
+            int n, tp, tq; tile_of(t, &n, &tp, &tq);
+            const int row = 2 * (2 * TP * tp - 1) - 3 + ppr, col0 = 2 * (2 * TQ * tq - 1) - 3 + ppc * 4;
+            const bool rok = tid < PSLOTS && row >= 0 && row < a.rH;
+            rawok = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rawok |= (rok && col0 + j >= 0 && col0 + j < a.rW) ? 1u << j : 0u;
+            const unsigned plane = (unsigned)(a.rH * a.rW);
+            // element (n, c, row, col0): a slot that runs over the END of its row reads into the next row (masked below; beyond the last
+            // element of the buffer the range check returns 0)
+            const unsigned e0 = (unsigned)((n * a.rC * a.rH + row) * a.rW + col0);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const unsigned e = rawok && c < a.rC ? e0 + (unsigned)c * plane : kOOB;
+                if constexpr (KIND == 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rawv[c * 4 + j] = (int)__builtin_amdgcn_raw_buffer_load_b8(rraw, e == kOOB ? kOOB : e + j, 0, 0);
+                } else if (tq == 0) {                    // wave-uniform: the image's left edge — a slot may START before its row (and, on
+                                                         // the first row of the first image, before the buffer): element loads
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        rawv[c * 4 + j] = __builtin_amdgcn_raw_buffer_load_b32(rraw, (e != kOOB && ((rawok >> j) & 1u)) ? (e + j) * 4u : kOOB, 0, 0);
+                } else {
+                    const v4i q4 = __builtin_amdgcn_raw_buffer_load_b128(rraw, e == kOOB ? kOOB : e * 4u, 0, 0);      // 4-byte aligned is enough
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rawv[c * 4 + j] = q4[j];
+                }
+            }
+        }
+    };
+    auto store_raw = [&](int slot) {
+        if constexpr (KIND >= 0) {
+            int v[3][4];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = rawv[c * 4 + j];
+                    int q;
+                    if constexpr (KIND == 0) q = r;
+                    else if constexpr (KIND == 1) q = quant_in_stem(__builtin_bit_cast(float, r), a.scale, a.qlo, a.qhi);
+                    else q = (int)a.lut[c * 256 + (r & 0xff)];
+                    v[c][j] = ((rawok >> j) & 1u) && c < a.rC ? q : 0;
+                }
+            v4i o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (int)(pack4(v[0][j], v[1][j], v[2][j], 0) ^ a.xor8);
+            if (tid < PSLOTS) *(v4i*)(lds + slot * PATCH_BYTES + tid * 16) = o;
+        }
+    };
     const int t0 = blockIdx.x, step = gridDim.x;
-    if (t0 < ntiles) issue_patch(t0, 0);
+    if constexpr (KIND < 0) { if (t0 < ntiles) issue_patch(t0, 0); }
+    else if (t0 < ntiles) { load_raw(t0); store_raw(0); }
     const int floor0 = a.relu0 ? 0 : INT32_MIN;
     const char* wrow = wl + l31 * WROW + lh * 16;
 
@@ -94,10 +161,17 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemPoolArgs a) {
     for (int t = t0; t < ntiles; t += step, ++it) {
         const int cur = it & 1;
         const bool more = t + step < ntiles;
-        if (more) issue_patch(t + step, cur ^ 1);                    // that slot's tile was consumed before the previous epilogue barrier
-        // patch(t) (and, the first time, the weights) landed: only the next patch (waves 0..5), issued after it, may stay in
-        // flight; the previous tile's output stores are waited for as well (a handful of small stores per wave)
-        if (more && dma_wave) wait_vmcnt<1>(); else wait_vmcnt<0>();
+        if constexpr (KIND < 0) {
+            if (more) issue_patch(t + step, cur ^ 1);                // that slot's tile was consumed before the previous epilogue barrier
+            // patch(t) (and, the first time, the weights) landed: only the next patch (waves 0..5), issued after it, may stay in
+            // flight; the previous tile's output stores are waited for as well (a handful of small stores per wave)
+            if (more && dma_wave) wait_vmcnt<1>(); else wait_vmcnt<0>();
+        } else {
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) { load_raw(t + step); __builtin_amdgcn_sched_barrier(0); wait_vmcnt<(KIND == 2 ? 12 : 3)>(); }   // only the next tile's loads stay in flight
+            else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this thread's patch stores of the previous iteration
+        }
         __builtin_amdgcn_s_barrier();
 
         int n, tp, tq; tile_of(t, &n, &tp, &tq);
@@ -160,6 +234,7 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemPoolArgs a) {
             }
         }
         // the next iteration's first barrier separates these ct reads from the next epilogue's ct writes
+        if constexpr (KIND >= 0) { if (more) store_raw(cur ^ 1); }   // that slot's tile was consumed before this iteration's first barrier
     }
 }
 
@@ -174,7 +249,12 @@ hipError_t launch_stem_pool(const StemPoolArgs& a, hipStream_t s) {
     static int ncu = 0;
     if (!ncu) { int dev = 0; hipDeviceProp_t p; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
     const int grid = ntiles < ncu * wpc ? ntiles : ncu * wpc;
-    hipLaunchKernelGGL(stem_pool_kernel, dim3(grid), dim3(512), 0, s, a);
+    switch (a.raw_kind) {
+        case 0: hipLaunchKernelGGL(stem_pool_kernel<0>, dim3(grid), dim3(512), 0, s, a); break;
+        case 1: hipLaunchKernelGGL(stem_pool_kernel<1>, dim3(grid), dim3(512), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(stem_pool_kernel<2>, dim3(grid), dim3(512), 0, s, a); break;
+        default: hipLaunchKernelGGL(stem_pool_kernel<-1>, dim3(grid), dim3(512), 0, s, a); break;
+    }
     return hipGetLastError();
 }
 

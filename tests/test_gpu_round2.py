@@ -157,6 +157,37 @@ MBV2_CORNERS = [
 ]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('normalize', [True, False])
+def test_stem_reads_the_raw_input_itself(dev, normalize):
+    """fuse_input (default): the fused stem launch builds its patch from the caller's NCHW buffer — int32 (f8_net_run), fp32 quantised
+    on the fly (f8_net_run_f32), uint8 through the table (f8_net_run_u8) — and the input launch does nothing; uint8 NHWC keeps the input
+    launch.  Every entry equals the plan with the option off, bit for bit: image borders (first row of the first image included: a slot
+    there starts before the buffer), ragged batch, both input formats (signed = normalize, unsigned)."""
+    import torch
+    from f8net_amd.net import build_net
+    spec = topology.get('resnet18', normalize=normalize)
+    params = synth.reference_params(spec, seed=77)
+    n, hw = 3, 224                                      # the fused stem needs whole 7 x 8 pooled tiles
+    x, x_fl = synth.make_input(spec, params, n, hw, seed=3)
+    nets = {v: build_net(spec, params, max_batch=4, hw=hw, options={'fuse_input': v}) for v in (0, 1)}
+    assert 'read by the stem launch' in nets[1].describe() and 'read by the stem launch' not in nets[0].describe()
+    xt = torch.from_numpy(x).to(dev)
+    ref = nets[0].run(xt).cpu().numpy()
+    np.testing.assert_array_equal(nets[1].run(xt).cpu().numpy(), ref)
+    np.testing.assert_array_equal(ref, oracle.net_forward(spec, params, x, x_fl))
+    img = torch.from_numpy(synth.rand_uniform_int(9, 'u8img', (n, 3, hw, hw), 0, 255).astype(np.uint8)).to(dev)
+    f32 = img.to(torch.float32) / 255.0
+    if normalize:
+        mean = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1); std = torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)
+        f32 = ((f32 - mean) / std).contiguous()
+    np.testing.assert_array_equal(nets[1].run_f32(f32, normalize).cpu().numpy(), nets[0].run_f32(f32, normalize).cpu().numpy())
+    kw = dict(normalize=normalize, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)) if normalize else dict(normalize=False)
+    u0 = nets[0].run_u8(img, **kw).cpu().numpy()
+    np.testing.assert_array_equal(nets[1].run_u8(img, **kw).cpu().numpy(), u0)
+    np.testing.assert_array_equal(nets[1].run_u8(img.permute(0, 2, 3, 1).contiguous(), nhwc=True, **kw).cpu().numpy(), u0)
+
+
 @pytest.mark.parametrize('case', MBV2_CORNERS, ids=lambda c: f'{c[0]}{c[1]}x{c[2]}s{c[3]}_{c[4]}_{c[5]}to{c[6]}')
 def test_mobilenet_v2_corner_formats(dev, case):
     """Unsigned `input_fl = 8` on non-head layers, weight_fl 0 / 1 depthwise, requant shifts >= 12: one conv

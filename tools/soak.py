@@ -13,7 +13,8 @@ runs = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 spec = topology.get('resnet50', normalize=True)
 params = synth.make_params(spec, seed=1234, fraclens=topology.R50_NVIDIA_FRACLENS)
 n = 128
-net = build_net(spec, params, max_batch=n, hw=224)
+whole = os.environ.get('F8_SOAK_WHOLE', '1') == '1'      # plan as bench.py does: a launch covers the whole batch under mode 2
+net = build_net(spec, params, max_batch=n, hw=224, options={'whole_batch_launches': 1} if whole else None)
 xs = [torch.from_numpy(synth.make_input(spec, params, n, 224, seed=50 + i)[0]).cuda() for i in range(3)]
 want = [net.run(x).clone() for x in xs]
 torch.cuda.synchronize()
