@@ -287,12 +287,12 @@ __global__ void __launch_bounds__(512) conv3x3_patch_kernel(const ConvArgs a) {
 template <int CIN, int W, int R, int IMGS, int BN, int KB>
 static hipError_t launch_patch_t(const ConvArgs& a, hipStream_t s) {
     using Cfg = PatchCfg<CIN, W, R, IMGS, BN, KB>;
-    static bool attr_set = false;
-    if (!attr_set) {   // dynamic LDS above 64 KB must be opted into once per kernel
+    static unsigned long long attr_done = 0; int attr_dev = -1;
+    if (!dyn_lds_opted_in(&attr_done, &attr_dev)) {   // dynamic LDS above 64 KB must be opted into once per kernel
         hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<CIN, W, R, IMGS, BN, KB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<CIN, W, R, IMGS, BN, KB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (attr_dev >= 0) attr_done |= 1ull << attr_dev;
     }
     const int nimg = a.M / a.PQ;
     const int tiles = (IMGS > 1) ? (nimg + IMGS - 1) / IMGS : nimg * (a.H / R);

@@ -900,11 +900,11 @@ static hipError_t launch_fused_t(const FusedArgs& a, hipStream_t s) {
                                                                                                    : Cfg::PATCH_BYTES + Cfg::MID2_BYTES + W2ALL + 2 * W4STAGE;
     constexpr int LDS = (MID == 64 ? ALLW_END : (MID == 256 ? Cfg::PATCH_BYTES + 4 * Cfg::RING : Cfg::LDS_BYTES)) + (DS ? 2 * COUT * 4 : 0) + ((MID == 256 && !DS) ? COUT * 4 : 0);   // + bias_lds; MID == 256: 4-stage P1 ring
     static_assert(LDS <= 80 * 1024 || MID > 64, "two workgroups per CU");
-    static bool attr_set = false;
-    if (!attr_set) {   // dynamic LDS above 64 KB must be opted into once per kernel
+    static unsigned long long attr_done = 0; int attr_dev = -1;
+    if (!dyn_lds_opted_in(&attr_done, &attr_dev)) {   // dynamic LDS above 64 KB must be opted into once per kernel
         hipError_t e = hipFuncSetAttribute((const void*)fused_bottleneck_kernel<C, MID, W, R, COUT, DS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (attr_dev >= 0) attr_done |= 1ull << attr_dev;
     }
     const int grid = a.N * a.tiles_per_img;
 #ifdef F8_TRACE

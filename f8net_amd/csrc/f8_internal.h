@@ -20,6 +20,7 @@ struct Options {
     int fuse_input = 1;          // ... which also reads the raw network input (no input launch, no haloed NHWC4 copy)
     int wstat = 1;               // weight-stationary 1x1 kernel (f8_wstat.hip) where a launch gives every workgroup >= wstat_min_tiles pixel tiles
     int wstat_min_tiles = 2;
+    int wstat_fast = 1;          // 0: always the general epilogue (requant in either direction, explicit ReLU floor)
     int s2wreg = 1;              // stride-2 3x3 convs of the stage-2 / stage-3 openers on conv3x3s2_wreg_kernel (f8_s2conv.hip)
     int wreg = 1;                // late 1x1 convs on conv1x1_wreg_kernel (weights straight to registers, f8_wreg.hip)
     int fuse_p12 = 1;            // 7x7 identity blocks: body.0 + body.2 in one launch, split over a workgroup pair per image (f8_p12.hip)
@@ -87,6 +88,7 @@ struct ConvArgs {
     int32_t sN2, sP2, sQ2, ktot2;          // input byte strides of x2 (per image / output row / output col), its K
     void* trace;                           // tuning builds (F8_TRACE) only; nullptr otherwise
     int32_t deep_nk;                       // Options::deep_nk (ring depth rule of launch_conv_t)
+    int32_t no_fast;                       // !Options::wstat_fast
 };
 
 // Depthwise 3x3 (groups == C), NHWC int8 in, VALU.
@@ -194,6 +196,15 @@ struct StemPoolArgs {
     uint32_t xor8;                         // 0x80808080 when the stem's input format is unsigned (stored biased)
     int16_t lut[3 * 256];
 };
+
+// Dynamic LDS above 64 KB must be opted into per kernel AND per device (a process that drives several GPUs launches the same
+// kernel on each of them).  `done`: one static bit mask per call site (bit = device ordinal); a benign race sets the attribute twice.
+inline bool dyn_lds_opted_in(unsigned long long* done, int* dev_out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { *dev_out = -1; return false; }
+    *dev_out = dev;
+    return ((*done >> dev) & 1ull) != 0;
+}
 
 struct ConvTile { int bm, bn, bk; };
 

@@ -217,6 +217,7 @@ static const OptKey kOptKeys[] = {
     {"s2wreg", "F8_S2WREG", &Options::s2wreg, 0, 1, true},
     {"wstat", "F8_WSTAT", &Options::wstat, 0, 1, true},
     {"wstat_min_tiles", "F8_WSTAT_MIN_TILES", &Options::wstat_min_tiles, 0, 1 << 20, true},
+    {"wstat_fast", "F8_WSTAT_FAST", &Options::wstat_fast, 0, 1, true},
     {"patch3x3", "F8_PATCH3X3", &Options::patch3x3, 0, 1, true},
     {"dual_wide", "F8_DUAL_WIDE", &Options::dual_wide, 0, 1 << 30, true},
     {"deep_nk", "F8_DEEP_NK", &Options::deep_nk, 1, 1 << 20, true},
@@ -1184,7 +1185,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                             st.name = std::string(nd.dual >= 0 ? "conv1x1_wstat_dual" : has_res ? "conv1x1_wstat_res" : "conv1x1_wstat") +
                                       (colon == std::string::npos ? ":" + tname(net, nd.out) : st.name.substr(colon));
                             char kb[144];
-                            bool fast = !st.relu0 || (nd.dual < 0 && !has_res && st.out.f32 < 0);      // keep in sync with conv1x1_wstat_fast
+                            bool fast = opt.wstat_fast && (!st.relu0 || (nd.dual < 0 && !has_res && st.out.f32 < 0));      // keep in sync with conv1x1_wstat_fast
                             for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0 && T[st.out.t].forms[st.out.f8[k]].n <= 0) fast = false;
                             snprintf(kb, sizeof kb, "f8::conv1x1_wstat_kernel<%d, %d, %d, %s, %s, %d, %s>", nd.ck, k1, conv1x1_wstat_waves(nd.ck, k1), has_res ? "true" : "false",
                                      st.out.f32 >= 0 ? "true" : "false", (st.out.f8[0] >= 0 ? 1 : 0) + (st.out.f8[1] >= 0 ? 1 : 0), fast ? "true" : "false");
@@ -1515,7 +1516,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
                 a.origin = -(d.pad * sT.W + d.pad) * sT.Cs; a.H = sT.H; a.W = sT.W; a.pad = d.pad; a.kw = d.kernel;
                 a.tapH = sT.W * sT.Cs; a.tapW = sT.Cs;
             }
-            a.relu0 = st.relu0; a.deep_nk = net->opt.deep_nk;
+            a.relu0 = st.relu0; a.deep_nk = net->opt.deep_nk; a.no_fast = net->opt.wstat_fast ? 0 : 1;
             if (st.res_t >= 0) { a.res = (const int32_t*)fp(T[st.res_t].forms[st.res_f]); a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1; }
             if (nd.dual >= 0) {
                 const Node& g = net->nodes[nd.dual];

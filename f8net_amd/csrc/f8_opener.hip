@@ -470,11 +470,11 @@ fused_opener_kernel(const FusedArgs a) {
 template <int C, int MID, int W, int R, int COUT, bool STG>
 static hipError_t launch_opener_t(const FusedArgs& a, hipStream_t s) {
     using Cfg = OpenerCfg<C, MID, W, R, COUT>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_done = 0; int attr_dev = -1;
+    if (!dyn_lds_opted_in(&attr_done, &attr_dev)) {
         hipError_t e = hipFuncSetAttribute((const void*)fused_opener_kernel<C, MID, W, R, COUT, STG>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (attr_dev >= 0) attr_done |= 1ull << attr_dev;
     }
     const int grid = a.N * a.tiles_per_img;
 #ifdef F8_TRACE

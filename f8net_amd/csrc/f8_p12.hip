@@ -291,11 +291,11 @@ bool fused_p12_supported(int C, int MID, int H, int W) { return C == 2048 && MID
 hipError_t launch_fused_p12(const FusedArgs& a, hipStream_t s) {
     if (!fused_p12_supported(a.C, a.MID, a.H, a.W)) return hipErrorInvalidValue;
     using Cfg = P12Cfg<2048, 512>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_done = 0; int attr_dev = -1;
+    if (!dyn_lds_opted_in(&attr_done, &attr_dev)) {
         hipError_t e = hipFuncSetAttribute((const void*)fused_p12_kernel<2048, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (attr_dev >= 0) attr_done |= 1ull << attr_dev;
     }
     const int grid = (a.N + 3) / 4 * 8;
 #ifdef F8_TRACE

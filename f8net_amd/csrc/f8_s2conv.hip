@@ -155,11 +155,11 @@ bool conv3x3s2_wreg_supported(int ck, int HO, int WO, int coutP) {
 template <int CIN, int HO, int WO, int COUT>
 static hipError_t launch_s2_t(const ConvArgs& a, int N, hipStream_t s) {
     using Cfg = S2Cfg<CIN, HO, WO, COUT>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_done = 0; int attr_dev = -1;
+    if (!dyn_lds_opted_in(&attr_done, &attr_dev)) {
         hipError_t e = hipFuncSetAttribute((const void*)conv3x3s2_wreg_kernel<CIN, HO, WO, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::PATCH_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (attr_dev >= 0) attr_done |= 1ull << attr_dev;
     }
     hipLaunchKernelGGL((conv3x3s2_wreg_kernel<CIN, HO, WO, COUT>), dim3((N + 3) / 4 * 8), dim3(512), Cfg::PATCH_BYTES, s, a, N);
     return hipGetLastError();

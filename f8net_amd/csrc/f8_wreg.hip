@@ -134,8 +134,7 @@ hipError_t launch_conv1x1_wreg(const ConvArgs& a, hipStream_t s) {
     const int grid = (a.M + 63) / 64;
     if (a.CK == 512 && a.coutP == 256) { hipLaunchKernelGGL((conv1x1_wreg_kernel<512, 256>), dim3(grid), dim3(512), 0, s, a); return hipGetLastError(); }
     if (a.CK == 1024 && a.coutP == 512) {
-        static bool attr_set = false;                    // 64 KB of static LDS is the default limit exactly: nothing to raise
-        (void)attr_set;
+        // 64 KB of static LDS is the default limit exactly: nothing to raise
         hipLaunchKernelGGL((conv1x1_wreg_kernel<1024, 512>), dim3(grid), dim3(512), 0, s, a);
         return hipGetLastError();
     }

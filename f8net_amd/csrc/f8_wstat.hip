@@ -381,11 +381,11 @@ int conv1x1_wstat_waves(int k0, int k1) { return k0 + k1 > 1024 ? 4 : 8; }
 template <int K0, int K1, int NW, bool RES, bool OUT32, int NQ, bool FAST>
 static hipError_t launch_wstat_t(const ConvArgs& a, int num_cu, hipStream_t s) {
     using Cfg = WstatCfg<K0, K1, NW>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_done = 0; int attr_dev = -1;
+    if (!dyn_lds_opted_in(&attr_done, &attr_dev)) {
         hipError_t e = hipFuncSetAttribute((const void*)conv1x1_wstat_kernel<K0, K1, NW, RES, OUT32, NQ, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (attr_dev >= 0) attr_done |= 1ull << attr_dev;
     }
     const int T = (a.M + 31) / 32, NG = a.coutP / (32 * NW);
     int MG = num_cu * Cfg::WG_PER_CU / NG; if (MG < 1) MG = 1; if (MG > T) MG = T;
@@ -435,6 +435,7 @@ static hipError_t launch_wstat_o(const ConvArgs& a, int num_cu, hipStream_t s) {
 // absent or can ride in the clamp's lower bound (no int32 output, no join: requant is monotonic and maps 0 to 0, so
 // requant(max(v, 0)) = max(requant(v), 0))
 bool conv1x1_wstat_fast(const ConvArgs& a) {
+    if (a.no_fast) return false;
     for (int k = 0; k < 2; ++k) if (a.q[k].ptr && a.q[k].n <= 0) return false;
     const bool join = a.res != nullptr || a.x2 != nullptr;
     return !a.relu0 || (!join && !a.out32);

@@ -221,7 +221,7 @@ int f8_net_set_input_ready(f8_net* net, void* event);
  *   planning  : split (1..4 concurrent sub-batches = arena copies), fuse_blocks, fuse_stages (bit mask, -1 = auto), fuse_dual,
  *               fuse_ds, fuse_opener, fuse_stem, fuse_input (the fused stem launch reads the caller's NCHW buffer itself), fuse_ir (1 = where it wins, 2 = every block), fuse_p12 (7x7 block: first two
  *               convs in one launch), wstat (weight-stationary 1x1 kernel: plain, dual-GEMM and residual-join instances) with
- *               wstat_min_tiles (pixel tiles per workgroup a launch must offer; 0 = always), wreg (weights-streamed 1x1 kernel for the
+ *               wstat_min_tiles (pixel tiles per workgroup a launch must offer; 0 = always) and wstat_fast (0 = general epilogue), wreg (weights-streamed 1x1 kernel for the
  *               512 -> 256 / 1024 -> 512 reductions of smaller launches),
  *               patch3x3, dual_wide, deep_nk, bk128, dw_dot4, opener_stg, whole_batch_launches (hint: runs will use
  *               f8_net_set_pipelined(2))

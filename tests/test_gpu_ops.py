@@ -307,7 +307,7 @@ WSTAT_SHAPES = [(512, 256, 1024, 12, 3, False), (1024, 512, 2048, 14, 2, False),
 
 @pytest.mark.parametrize('shape', WSTAT_SHAPES, ids=lambda g: 'x'.join(map(str, g)))
 @pytest.mark.parametrize('variant', ['body_shifts_left', 'other_shifts_left_signed_mid'])
-@pytest.mark.parametrize('tail', ['i32', 'both'])
+@pytest.mark.parametrize('tail', ['i32', 'both', 'two_formats'])
 def test_weight_stationary_1x1_matches_oracle(dev, shape, variant, tail):
     """conv1x1_wstat_kernel (f8_wstat.hip), forced onto small launches with wstat_min_tiles = 0: body.0 of a stage-opening block
     (plain instance, K = 512 / 1024), its body.4 + strided shortcut as ONE dual GEMM (K = 512 + 256 on 8 waves, 1024 + 512 on 4),
@@ -338,6 +338,8 @@ def test_weight_stationary_1x1_matches_oracle(dev, shape, variant, tail):
     x = synth.rand_normal_int(57, f'wsx{shape}{variant}', (N, Cin, H, H), 2.0e3 if not identity else 2.0 ** 27).astype(np.int32)
     net = F8Net()
     net.set_option('wstat_min_tiles', 0)
+    if tail == 'two_formats':
+        net.set_option('wstat_fast', 0)                        # the general epilogue (either shift direction, explicit ReLU floor)
     t = net.input(Cin, H, H, x_fl)
     r = t
     for c in body:
@@ -359,9 +361,20 @@ def test_weight_stationary_1x1_matches_oracle(dev, shape, variant, tail):
         y = oracle.conv2d(oracle.requant(want, in_fl_t, want_fl, False), wt, bt, 1, 0)
         r = net.add(c2, r, relu=False)
         want, _ = oracle.add_align(y, want, in_fl_t + w_fl_t, want_fl)
+    if tail == 'two_formats':                                  # two consumers that read the block output in DIFFERENT int8 formats
+        ys = []
+        cs = []
+        for k, in_fl_t in enumerate((2, 3)):
+            wt = np.clip(synth.rand_normal_int(60 + k, 'tailw2', (64, Cout, 1, 1), 40.0), -127, 127).astype(np.int32)
+            cs.append(net.conv(r, wt, None, stride=1, pad=0, groups=1, weight_fl=6 - k, input_fl=in_fl_t, input_signed=bool(k), quant_input=True, relu=False))
+            ys.append(oracle.conv2d(oracle.requant(want, in_fl_t, want_fl, bool(k)), wt, np.zeros(64, np.int32), 1, 0))
+        r = net.add(cs[0], cs[1], relu=False)                  # both products have fraclen 8
+        want, _ = oracle.add_align(ys[0], ys[1], 8, 8)
     net.output(r, as_float=False)
     net.finalize(N)
     plan = net.describe()
+    if tail == 'two_formats':
+        assert any('i8=2' in l for l in plan.splitlines() if 'wstat_dual' in l or 'wstat_res' in l), plan
     if identity:
         assert 'conv1x1_wstat_res:' in plan, plan
     else:
