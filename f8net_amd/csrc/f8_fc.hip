@@ -1,0 +1,75 @@
+// f8_fc.hip — the classifier: integer nn.Linear + the `.float()` of IntModel.forward in one launch (gfx950).
+//
+// `self.classifier(x)` of /root/reference/models/fix_resnet.py:381-383 (int_fc, fix_quant_ops.py:1165-1195) followed by the conversion
+// of the int32 logits to the caller's float32 / int32 [N][classes] buffer was two launches (a 64x64 conv_igemm tile grid + output_kernel,
+// 10-13 + 6 us, both latency-bound: 2 MB of cold weights behind a handful of workgroups).  Here the K loop is split ACROSS the waves so
+// that every byte is requested in the first microsecond: a workgroup owns 32 images x 32 classes, wave w the K slice [w K/8, (w+1) K/8):
+// its weight fragments (MFMA-fragment order, host: pack_frag_weights) and its lanes' feature bytes are ALL requested at once (no LDS
+// staging, no ring), multiplied, and the eight partial 32 x 32 sums meet through LDS (integer adds, order-free and exact); each wave
+// then finishes two of the sixteen accumulator registers: + bias, straight to the caller's buffer.
+#include "f8_device.h"
+
+namespace f8 {
+
+template <int K>
+__global__ void __launch_bounds__(512) fc_dense_kernel(const ConvArgs a, void* const out, const int classes, const int as_float) {
+    constexpr int NK = K / 32, NKW = NK / 8;             // K32 steps, steps per wave
+    static_assert(NK % 8 == 0, "eight K slices");
+    __shared__ int part[8][16][64];                      // [wave][accumulator register][lane]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.x * 32;                      // first image of the workgroup
+    const int ct = blockIdx.y;                           // class tile of the workgroup
+    const int m = m0 + l31;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+    const v4i* const wp = (const v4i*)a.w + ((size_t)ct * NK + (size_t)wave * NKW) * 64 + lane;      // [tile][K32 step][lane][16 B]
+    v4i wf[NKW], xf[NKW];
+#pragma unroll
+    for (int s = 0; s < NKW; ++s) {
+        wf[s] = wp[(size_t)s * 64];
+        // B operand: image l31, K bytes [32 step + 16 lh, +16); images beyond M read zeros through the range check
+        xf[s] = __builtin_amdgcn_raw_buffer_load_b128(rx, m < a.M ? (unsigned)(m * K + (wave * NKW + s) * 32 + lh * 16) : kOOB, 0, 0);
+    }
+    v16i acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0;
+#pragma unroll
+    for (int s = 0; s < NKW; ++s) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[s], xf[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc[r];
+    __syncthreads();
+    // wave w finishes registers 2w, 2w+1: register r of lane (l31, lh) = class 8 (r / 4) + 4 lh + r % 4 of image l31
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int r = wave * 2 + rr;
+        unsigned sum = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) sum += (unsigned)part[w][r][lane];
+        const int c = ct * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+        if (m < a.M && c < classes) {
+            const int v = (int)(sum + (unsigned)a.bias[c]);
+            if (as_float) ((float*)out)[(size_t)m * classes + c] = (float)v;
+            else ((int*)out)[(size_t)m * classes + c] = v;
+        }
+    }
+}
+
+// K = padded input features (bytes per row)
+bool fc_dense_supported(int ck, int coutP) { return (ck == 512 || ck == 1024 || ck == 1280 || ck == 2048) && coutP % 32 == 0; }
+
+template <int K>
+static hipError_t launch_fc_t(const ConvArgs& a, void* out, int classes, int as_float, hipStream_t s) {
+    hipLaunchKernelGGL((fc_dense_kernel<K>), dim3((a.M + 31) / 32, a.coutP / 32), dim3(512), 0, s, a, out, classes, as_float);
+    return hipGetLastError();
+}
+
+hipError_t launch_fc_dense(const ConvArgs& a, void* out, int classes, int as_float, hipStream_t s) {
+    if (a.CK == 512) return launch_fc_t<512>(a, out, classes, as_float, s);
+    if (a.CK == 1024) return launch_fc_t<1024>(a, out, classes, as_float, s);
+    if (a.CK == 1280) return launch_fc_t<1280>(a, out, classes, as_float, s);
+    if (a.CK == 2048) return launch_fc_t<2048>(a, out, classes, as_float, s);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace f8

@@ -16,6 +16,7 @@ struct Options {
     int fuse_dual = 1;           // dual-GEMM downsample join
     int fuse_ds = 1;             // stage-opening block at unchanged resolution in one launch
     int fuse_opener = 1;         // stage-opening block with a stride-2 3x3 in one launch
+    int fuse_fc = 1;             // the classifier writes the caller's logits buffer itself (no output launch)
     int fuse_stem = 1;           // stem conv + max-pool in one launch
     int fuse_input = 1;          // ... which also reads the raw network input (no input launch, no haloed NHWC4 copy)
     int wstat = 1;               // weight-stationary 1x1 kernel (f8_wstat.hip) where a launch gives every workgroup >= wstat_min_tiles pixel tiles
@@ -225,6 +226,9 @@ hipError_t launch_fused_p12(const FusedArgs& a, hipStream_t s);
 // 1x1 conv with the weights streamed into registers (f8_wreg.hip); ConvArgs::w = the fragment-order image of the weights
 bool conv1x1_wreg_supported(int ck, int coutP);
 hipError_t launch_conv1x1_wreg(const ConvArgs& a, hipStream_t s);
+// classifier: integer linear + int32 -> float32 / int32 [N][classes] into the caller's buffer (f8_fc.hip); ConvArgs::w = fragment order
+bool fc_dense_supported(int ck, int coutP);
+hipError_t launch_fc_dense(const ConvArgs& a, void* out, int classes, int as_float, hipStream_t s);
 // 3x3 / stride 2 / pad 1 with the input patch in LDS and the weights streamed into registers (f8_s2conv.hip); ConvArgs::w = fragment order
 bool conv3x3s2_wreg_supported(int ck, int HO, int WO, int coutP);
 hipError_t launch_conv3x3s2_wreg(const ConvArgs& a, hipStream_t s);

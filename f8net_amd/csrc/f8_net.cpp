@@ -209,6 +209,7 @@ static const OptKey kOptKeys[] = {
     {"fuse_dual", "F8_FUSE_DUAL", &Options::fuse_dual, 0, 1, true},
     {"fuse_ds", "F8_FUSE_DS", &Options::fuse_ds, 0, 1, true},
     {"fuse_opener", "F8_FUSE_OPENER", &Options::fuse_opener, 0, 1, true},
+    {"fuse_fc", "F8_FUSE_FC", &Options::fuse_fc, 0, 1, true},
     {"fuse_stem", "F8_FUSE_STEM", &Options::fuse_stem, 0, 1, true},
     {"fuse_input", "F8_FUSE_INPUT", &Options::fuse_input, 0, 1, true},
     {"fuse_ir", "F8_FUSE_IR", &Options::fuse_ir, 0, 2, true},
@@ -838,8 +839,12 @@ int f8_net_finalize(f8_net* net, int max_batch) {
     {
         Tensor& O = T[net->out_t];
         const Node& p = ND[O.prod];
-        (void)p;
-        add_form(O, FORM_I32, 0, 0);
+        // the classifier (a linear / 1x1 conv on a 1x1 map that nothing else reads) writes the caller's buffer itself: no int32 form
+        const Tensor& ps = T[p.a >= 0 ? p.a : net->out_t];
+        O.dense_out = opt.fuse_fc && (p.kind == N_LINEAR || p.kind == N_CONV) && p.cd.kernel == 1 && p.cd.stride == 1 && p.cd.pad == 0 && p.cd.groups == 1 &&
+                      O.H == 1 && O.W == 1 && ps.H == 1 && ps.W == 1 && O.consumers.empty() && p.fused_add < 0 && p.absorbed_by < 0 &&
+                      fc_dense_supported(ps.Cs, round_up(p.cd.cout, 32));
+        if (!O.dense_out) add_form(O, FORM_I32, 0, 0);
     }
     for (int i = nn - 1; i >= 0; --i) {
         Node& nd = ND[i];
@@ -1166,6 +1171,13 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 st.bytes_const = nd.depthwise ? (double)s.Cs * 13 : (double)nd.coutP * (nd.ktot + 4);
                 if (nd.dual >= 0) st.bytes_const += (double)ND[nd.dual].coutP * (ND[nd.dual].ktot + 4);
                 label_conv_step(net, st, nd);
+                if (st.dense) {                          // the classifier: logits straight into the caller's buffer (f8_fc.hip)
+                    pack_frag_weights(net, nd);
+                    st.name = "linear_dense:" + tname(net, nd.out);
+                    char kb[64];
+                    snprintf(kb, sizeof kb, "f8::fc_dense_kernel<%d>", nd.ck);
+                    st.kernel = kb;
+                }
                 // 1x1 convs (plain, with the residual join, or as the dual GEMM of a stage-opening block) whose weight slice per wave
                 // fits the register file: weight-stationary kernel, when a launch gives every workgroup a few pixel tiles to walk
                 if (opt.wstat && !nd.depthwise && !nd.stem && d.kernel == 1 && d.pad == 0 && d.groups == 1 && !st.dense) {
@@ -1528,7 +1540,10 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
                 a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1;
             }
             fill_out(&a.out32, a.q);
-            if (nd.s2w) { a.w = (const int8_t*)(net->d_w + nd.wf_off); e = launch_conv3x3s2_wreg(a, s); }
+            if (st.dense) {
+                a.w = (const int8_t*)(net->d_w + nd.wf_off);
+                e = launch_fc_dense(a, (char*)output + (size_t)n0 * oT.C * 4, oT.C, net->out_float, s);
+            } else if (nd.s2w) { a.w = (const int8_t*)(net->d_w + nd.wf_off); e = launch_conv3x3s2_wreg(a, s); }
             else if (nd.wstat) {
                 a.w = (const int8_t*)(net->d_w + nd.wf_off);
                 if (nd.dual >= 0) a.w2 = (const int8_t*)(net->d_w + net->nodes[nd.dual].wf_off);
@@ -1732,7 +1747,7 @@ int f8_net_autotune(f8_net* net, int N, void* stream) {
     for (auto& st : net->steps) {
         if (st.kind != S_CONV) continue;
         Node& nd = net->nodes[st.node];
-        if (nd.p3_R > 0 || nd.wreg || nd.wstat || nd.s2w) continue;
+        if (nd.p3_R > 0 || nd.wreg || nd.wstat || nd.s2w || st.dense) continue;
         const ConvTile keep = nd.tile;
         ConvTile best = keep; float best_ms = 1e30f;
         for (int c = 0; c < 4; ++c) {

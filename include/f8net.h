@@ -219,7 +219,7 @@ int f8_net_set_input_ready(f8_net* net, void* event);
  * chunk56) and otherwise the measured best; two handles in one process may differ.  Keys that decide the plan must be set
  * before f8_net_finalize (F8_ERR_STATE afterwards); scheduling keys may change between runs.
  *   planning  : split (1..4 concurrent sub-batches = arena copies), fuse_blocks, fuse_stages (bit mask, -1 = auto), fuse_dual,
- *               fuse_ds, fuse_opener, fuse_stem, fuse_input (the fused stem launch reads the caller's NCHW buffer itself), fuse_ir (1 = where it wins, 2 = every block), fuse_p12 (7x7 block: first two
+ *               fuse_ds, fuse_opener, fuse_fc (the classifier writes the caller's logits buffer itself), fuse_stem, fuse_input (the fused stem launch reads the caller's NCHW buffer itself), fuse_ir (1 = where it wins, 2 = every block), fuse_p12 (7x7 block: first two
  *               convs in one launch), wstat (weight-stationary 1x1 kernel: plain, dual-GEMM and residual-join instances) with
  *               wstat_min_tiles (pixel tiles per workgroup a launch must offer; 0 = always) and wstat_fast (0 = general epilogue), wreg (weights-streamed 1x1 kernel for the
  *               512 -> 256 / 1024 -> 512 reductions of smaller launches),
