@@ -149,7 +149,8 @@ __global__ void __launch_bounds__(512) conv3x3s2_wreg_kernel(const ConvArgs a, c
 
 // 3x3 / stride 2 / pad 1, int8 outputs only: the instances (input bytes per pixel, output map, output channels)
 bool conv3x3s2_wreg_supported(int ck, int HO, int WO, int coutP) {
-    return (ck == 512 && HO == 7 && WO == 7 && coutP == 512) || (ck == 256 && HO == 14 && WO == 14 && coutP == 256);
+    return (ck == 512 && HO == 7 && WO == 7 && coutP == 512) || (ck == 256 && HO == 14 && WO == 14 && coutP == 256) ||
+           (ck == 256 && HO == 7 && WO == 7 && coutP == 512);      // ResNet-18 stage_3_layer_0.body.0
 }
 
 template <int CIN, int HO, int WO, int COUT>
@@ -170,6 +171,7 @@ hipError_t launch_conv3x3s2_wreg(const ConvArgs& a, hipStream_t s) {
     if (a.out32 || a.res || a.x2) return hipErrorInvalidValue;
     if (a.CK == 512 && HO == 7 && a.Q == 7 && a.coutP == 512) return launch_s2_t<512, 7, 7, 512>(a, N, s);
     if (a.CK == 256 && HO == 14 && a.Q == 14 && a.coutP == 256) return launch_s2_t<256, 14, 14, 256>(a, N, s);
+    if (a.CK == 256 && HO == 7 && a.Q == 7 && a.coutP == 512) return launch_s2_t<256, 7, 7, 512>(a, N, s);
     return hipErrorInvalidValue;
 }
 
