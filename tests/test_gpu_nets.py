@@ -185,3 +185,28 @@ def test_autotuned_plan_is_bit_identical(dev, golden_dir):
     changed = net.autotune(4, dev)
     assert changed >= 0 and (changed == 0) == (net.describe() == before)
     np.testing.assert_array_equal(net.run(torch.from_numpy(x).to(dev)).cpu().numpy(), g['s1234_hw224_n1/logits'])
+
+
+def test_late_stage_kernels_equal_the_tile_per_workgroup_plan_at_every_batch_size(dev):
+    """The bench plan (128 images per launch, two batches in flight) runs the late stages on the operand-stationary kernels of
+    DESIGN 4.9 and the classifier / stem on their fused forms; the same net planned with all of them OFF runs conv_igemm_kernel there.
+    Both must give the same logits for ANY image count the 128-image plan is asked to run: one image (fewer pixel tiles than
+    workgroups), counts that leave the last workgroup group / pixel tile ragged, the full batch."""
+    from f8net_amd.net import build_net
+    spec = topology.get('resnet50', normalize=True)
+    params = synth.make_params(spec, seed=1234, fraclens=topology.R50_NVIDIA_FRACLENS)
+    x, _ = synth.make_input(spec, params, 128, 224, seed=5)
+    xd = torch.from_numpy(x).to(dev)
+    big = build_net(spec, params, max_batch=128, hw=224, options={'whole_batch_launches': 1})
+    big.set_pipelined(2)
+    plan = big.describe()
+    for name in ('conv1x1_wstat:', 'conv1x1_wstat_dual:', 'conv1x1_wstat_res:', 'conv3x3s2_wreg:', 'fused_p12:', 'linear_dense:', 'read by the stem launch'):
+        assert name in plan, plan
+    off = {'wstat': 0, 's2wreg': 0, 'fuse_p12': 0, 'wreg': 0, 'fuse_fc': 0, 'fuse_input': 0}
+    ref = build_net(spec, params, max_batch=128, hw=224, options=off)
+    assert not any(k in ref.describe() for k in ('wstat', 'wreg', 'p12', 'linear_dense'))
+    full = ref.run(xd).cpu().numpy()
+    for k in (1, 2, 3, 31, 33, 100, 127, 128):
+        got = big.run(xd[:k].contiguous()).cpu().numpy()
+        np.testing.assert_array_equal(got, full[:k])
+    big.set_pipelined(False)
