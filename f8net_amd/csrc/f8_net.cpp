@@ -1926,6 +1926,10 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
             (void)hipEventElapsedTime(&t, net->events[q - 1], net->events[q]);
             ms[owner[q]] += t;
         }
+        // a step that launched nothing (the input step when the stem launch reads the caller's buffer) has no duration: the two
+        // events around it are ~5 us apart on their own
+        for (int i = 0; i < ns; ++i)
+            if (net->steps[i].kind == S_INPUT && net->steps[i].raw_input && !(net->in_u8 && net->in_u8_nhwc)) ms[i] = 0.f;
         return F8_OK;
     }
     auto ensure_aux = [&]() -> int {
