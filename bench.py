@@ -260,6 +260,8 @@ def main():
                 print(f'{i:3d} {name:58s} {m*1e3:8.1f} us {b/1e6:8.1f} MB {b/m/1e6 if m else 0:7.0f} GB/s '
                       f'{o/m/1e9 if m else 0:7.0f} TOP/s', file=sys.stderr)
             for k, e in sorted(by_kernel.items(), key=lambda kv: -kv[1]['ms']):
+                if e['ms'] <= 0:         # a step that launches nothing (the input step when the stem launch reads the caller's buffer)
+                    continue
                 print(f'  {e["ms"]*1e3:8.1f} us {100*e["ms"]/total_ms:5.1f}% x{e["launches"]:2d}  '
                       f'{e["bytes"]/e["ms"]/1e6:7.0f} GB/s  {k}', file=sys.stderr)
         headline = args.arch == 'resnet50' and BS == 128
