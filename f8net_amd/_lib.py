@@ -75,6 +75,7 @@ SYMBOLS = [
     ('f8_net_set_option', _i, [_vp, ctypes.c_char_p, _i]),
     ('f8_net_get_option', _i, [_vp, ctypes.c_char_p, ctypes.POINTER(_i)]),
     ('f8_net_set_input_ready', _i, [_vp, _vp]),
+    ('f8_net_check', _i, [_vp]),
 ]
 
 

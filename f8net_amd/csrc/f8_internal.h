@@ -24,6 +24,8 @@ struct Options {
     int wstat_fast = 1;          // 0: always the general epilogue (requant in either direction, explicit ReLU floor)
     int s2wreg = 1;              // stride-2 3x3 convs of the stage-2 / stage-3 openers on conv3x3s2_wreg_kernel (f8_s2conv.hip)
     int wreg = 1;                // late 1x1 convs on conv1x1_wreg_kernel (weights straight to registers, f8_wreg.hip)
+    int fuse_chain = 1;          // all consecutive bottleneck blocks of a stage in ONE launch, int32 residual stream in registers (f8_chain.hip)
+    int chain_timeout_ms = 2000; // bound of its halo-exchange spins
     int fuse_p12 = 1;            // 7x7 identity blocks: body.0 + body.2 in one launch, split over a workgroup pair per image (f8_p12.hip)
     int fuse_ir = 1;             // MobileNet-V2 inverted residual (expand -> depthwise -> project) in one launch: 1 = where it wins, 2 = always
     int patch3x3 = 1;            // LDS-patch 3x3 kernel
@@ -160,6 +162,33 @@ struct FusedArgs {
     int32_t stg;                           // Options::opener_stg
 };
 
+// One launch for ALL consecutive bottleneck blocks of a ResNet stage (f8_chain.hip): the int32 residual stream of a tile stays in
+// registers from block to block.  Weight pointers are the MFMA-fragment-order images (pack_frag_weights).
+struct ChainBlk {
+    const int8_t* w0; const int8_t* w2; const int8_t* w4; const int8_t* wsc;     // wsc / bsc: stage-opening block only (1x1 shortcut conv)
+    const int32_t* b0; const int32_t* b2; const int32_t* b4; const int32_t* bsc;  // offset-corrected, single class
+    int32_t nq, loq, hiq; uint32_t xorq;   // requant block input (int32 stream) -> body.0's input format
+    int32_t n1, lo1, hi1; uint32_t xor1;   // requant body.0 output -> body.2 input format
+    int32_t n2, lo2, hi2; uint32_t xor2;   // requant body.2 output -> body.4 input format
+    int32_t relu_a, relu_b, relu1;         // ReLU after body.0 / body.2 / the join
+    int32_t acc_shl, res_shl;              // residual join: (conv << acc_shl) + (other << res_shl)
+};
+constexpr int kChainMaxBlocks = 6;
+struct ChainArgs {
+    ChainBlk blk[kChainMaxBlocks]; int32_t nblk;
+    const int32_t* xr;                     // first block an identity block: the stage's int32 stream (I32T) — its int8 form is computed in the launch
+    const int8_t* x8in;                    // first block a stage-opening block: its int8 NHWC input [N*H*W][CIN0] in body.0's / the shortcut's format
+    int32_t N, NG;                         // images; image groups resident at once (grid = NG * tiles per image)
+    int32_t* out32; QuantOut q[2];         // forms of the last block's output
+    uint32_t* sync;                        // [0] ticket, [16 + workgroup] halo flag; zeroed before every launch
+    uint32_t* err;                         // sticky error word (a halo spin timed out): read by f8_net_check
+    int8_t* xchg;                          // halo rows between vertically adjacent tiles: [workgroup][parity][side][W * MID]
+    uint32_t timeout_ticks;                // bound of every spin (100 MHz wall clock)
+    void* trace;
+};
+constexpr int kChainSyncWords = 16 + 256;
+constexpr size_t kChainXchgBytes = (size_t)256 * 2 * 2 * 3584;
+
 // One launch for a MobileNet-V2 inverted-residual block: 1x1 expand -> depthwise 3x3 -> 1x1 project [+ int32 residual] (f8_ir.hip).
 struct IRArgs {
     const int8_t* x8;                      // block input, int8 NHWC [N*H*W][CIN_S] in the expand conv's input format
@@ -220,6 +249,11 @@ bool fused_ds_supported(int C, int MID, int COUT, int H, int W, int* R);
 // stage-opening block with a stride-2 3x3 (f8_opener.hip); H, W = input map
 bool fused_opener_supported(int C, int MID, int COUT, int H, int W, int* R);
 hipError_t launch_fused_opener(const FusedArgs& a, hipStream_t s);
+// all consecutive bottleneck blocks of a stage in one launch, residual stream in registers (f8_chain.hip).  cin0 != C: the first
+// block is the stage-opening block at unchanged resolution (1x1 shortcut conv from cin0 channels).
+bool chain_supported(int C, int MID, int H, int W, int cin0);
+int chain_tiles_per_img(int H, int W);
+hipError_t launch_chain(const ChainArgs& a, int C, int MID, int H, int W, int cin0, hipStream_t s);
 // 1x1 -> 3x3 of a 7x7 bottleneck block in one launch (f8_p12.hip); FusedArgs: x8, w0 / b0, w2 / b2, requant 1, q[] = the int8 outputs
 bool fused_p12_supported(int C, int MID, int H, int W);
 hipError_t launch_fused_p12(const FusedArgs& a, hipStream_t s);

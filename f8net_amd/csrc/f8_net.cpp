@@ -83,6 +83,8 @@ struct Node {
     bool wreg = false;                   // 1x1 conv on conv1x1_wreg_kernel (f8_wreg.hip)
     bool s2w = false;                    // 3x3 / stride 2 conv on conv3x3s2_wreg_kernel (f8_s2conv.hip)
     bool wstat = false;                  // 1x1 conv / dual GEMM / residual join on conv1x1_wstat_kernel (f8_wstat.hip)
+    int chain_into = -1;                 // host conv of a bottleneck block that runs inside a stage-chain launch: the host of the chain's LAST block
+    std::vector<int> chain;              // host of the last block of a chain: the hosts of all its blocks, in order (f8_chain.hip)
     int p12_a = -1;                      // 3x3 conv hosting "1x1 -> 3x3 in one launch" (f8_p12.hip): its 1x1 producer
     int ir_a = -1, ir_b = -1, ir_R = 0, ir_G = 0;   // project conv of a fused inverted-residual block: its expand / depthwise convs, tile
     int dual = -1;                     // 1x1 conv hosting a join whose other operand is ANOTHER 1x1 conv (node id): one dual-GEMM launch
@@ -94,7 +96,7 @@ struct Node {
     size_t rc_off = 0, cc_off = 0; int ncc = 0;      // border-class tables (0 = single class)
     ConvTile tile{};
 };
-enum StepKind { S_INPUT, S_CONV, S_DW, S_ADD, S_MAXPOOL, S_AVGPOOL, S_REQUANT, S_OUTPUT, S_FUSED, S_STEMPOOL, S_IR, S_P12 };
+enum StepKind { S_INPUT, S_CONV, S_DW, S_ADD, S_MAXPOOL, S_AVGPOOL, S_REQUANT, S_OUTPUT, S_FUSED, S_STEMPOOL, S_IR, S_P12, S_CHAIN };
 struct OutSel { int t = -1; int f32 = -1; int f8[2] = {-1, -1}; };
 struct Step {
     int kind; int node;
@@ -129,6 +131,7 @@ struct f8_net {
     size_t stem_zero_off = 0, stem_zero_bytes = 0; int stem_zero_val = 0;   // halo = biased zero
     // device
     char* d_arena = nullptr; char* d_w = nullptr; bool uploaded = false;
+    char* d_chain = nullptr; size_t chain_stride = 0;   // per arena copy: sync words + halo exchange rows of the stage-chain launches
     hipEvent_t* events = nullptr; int n_events = 0;
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t aux_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t lag_ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -214,6 +217,8 @@ static const OptKey kOptKeys[] = {
     {"fuse_input", "F8_FUSE_INPUT", &Options::fuse_input, 0, 1, true},
     {"fuse_ir", "F8_FUSE_IR", &Options::fuse_ir, 0, 2, true},
     {"fuse_p12", "F8_FUSE_P12", &Options::fuse_p12, 0, 1, true},
+    {"fuse_chain", "F8_FUSE_CHAIN", &Options::fuse_chain, 0, 1, true},
+    {"chain_timeout_ms", "F8_CHAIN_TIMEOUT_MS", &Options::chain_timeout_ms, 1, 1 << 20, false},
     {"wreg", "F8_WREG", &Options::wreg, 0, 1, true},
     {"s2wreg", "F8_S2WREG", &Options::s2wreg, 0, 1, true},
     {"wstat", "F8_WSTAT", &Options::wstat, 0, 1, true},
@@ -345,6 +350,20 @@ int f8_net_get_option(const f8_net* net, const char* key, int* value) {
     *value = net->opt.*(k->slot);
     return F8_OK;
 }
+int f8_net_check(f8_net* net) {
+    if (!net || !net->uploaded) return fail(F8_ERR_STATE, "f8_net_check: not uploaded");
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return hip_fail(e, "f8_net_check: hipDeviceSynchronize");
+    for (int p = 0; net->d_chain && p < net->n_copies; ++p) {
+        uint32_t w = 0;
+        if ((e = hipMemcpy(&w, net->d_chain + (size_t)p * net->chain_stride + 2048, 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "f8_net_check: hipMemcpy");
+        if (w) {
+            (void)hipMemset(net->d_chain + (size_t)p * net->chain_stride + 2048, 0, 4);
+            return fail(F8_ERR_HIP, "f8_net_check: a stage-chain launch gave up waiting for a neighbouring tile (code 0x%x, arena copy %d): its outputs are invalid", w, p);
+        }
+    }
+    return F8_OK;
+}
 int f8_net_set_input_ready(f8_net* net, void* event) {
     if (!net) return fail(F8_ERR_INVALID, "f8_net_set_input_ready: null net");
     net->input_ready = (hipEvent_t)event;
@@ -355,6 +374,7 @@ void f8_net_destroy(f8_net* net) {
     if (!net) return;
     if (net->d_arena) (void)hipFree(net->d_arena);
     if (net->d_w) (void)hipFree(net->d_w);
+    if (net->d_chain) (void)hipFree(net->d_chain);
     if (net->events) {
         for (int i = 0; i < net->n_events; ++i) (void)hipEventDestroy(net->events[i]);
         delete[] net->events;
@@ -738,7 +758,8 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         const int C = a0.cd.cin, MID = a0.cd.cout;
         if (c.cd.cout != C || b.cd.cin != MID || b.cd.cout != MID || c.cd.cin != MID) continue;
         int R = 0;
-        if (!fused_bottleneck_supported(C, MID, x.H, x.W, opt.whole_batch_launches ? max_batch : std::max(1, max_batch / opt.split), opt.fuse_stages, &R)) {
+        const bool chainable = opt.fuse_chain && a0.cd.quant_input && chain_supported(C, MID, x.H, x.W, C);   // pass 1f decides; R = 0: no stand-alone launch
+        if (!fused_bottleneck_supported(C, MID, x.H, x.W, opt.whole_batch_launches ? max_batch : std::max(1, max_batch / opt.split), opt.fuse_stages, &R) && !chainable) {
             // no whole-block instance (the 7x7 maps of stage 3): body.0 + body.2 as one launch, the residual-carrying 1x1 stays
             if (opt.fuse_p12 && fused_p12_supported(C, MID, x.H, x.W) && a0.cd.relu && b.cd.relu && tb.consumers.size() == 1) {
                 a0.absorbed_by = tb.prod; b.p12_a = ta.prod; b.no_classes = true;
@@ -795,6 +816,68 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         a0.absorbed_by = i; b.absorbed_by = i; b.no_classes = true;
         h.fbd_a = ta.prod; h.fbd_b = tb.prod; h.fb_R = R; h.fbd_s2 = bs == 2;
     }
+
+    // ---- 1f. stage chains: consecutive bottleneck blocks at one resolution whose block-to-block tensors are read by nobody else
+    //          -> ONE launch for all of them, the int32 residual stream stays in registers (f8_chain.hip).  A chain may start with
+    //          the stage-opening block at unchanged resolution (1d) and continues through identity blocks (1b).
+    if (opt.fuse_chain && fuse_blocks) {
+        struct Blk { int host, in_t, out_t, C, MID, H, W, cin0; bool ds; };
+        auto block_of = [&](int i, Blk* bk) -> bool {
+            const Node& h = ND[i];
+            if (h.kind != N_CONV || h.fused_add < 0 || h.chain_into >= 0) return false;
+            if (h.fb_a >= 0) {
+                const Node& a0 = ND[h.fb_a]; const Tensor& x = T[a0.a];
+                *bk = Blk{i, a0.a, ND[h.fused_add].out, a0.cd.cin, a0.cd.cout, x.H, x.W, a0.cd.cin, false};
+                return true;
+            }
+            if (h.fbd_a >= 0 && !h.fbd_s2) {
+                const Node& a0 = ND[h.fbd_a]; const Tensor& x = T[h.a];
+                *bk = Blk{i, h.a, ND[h.fused_add].out, h.cd.cout, a0.cd.cout, x.H, x.W, a0.cd.cin, true};
+                return true;
+            }
+            return false;
+        };
+        for (int i = 0; i < nn; ++i) {
+            Blk first;
+            if (!block_of(i, &first) || !chain_supported(first.C, first.MID, first.H, first.W, first.cin0)) continue;
+            std::vector<int> hosts{first.host};
+            Blk cur = first;
+            while ((int)hosts.size() < kChainMaxBlocks && cur.out_t != net->out_t) {
+                const Tensor& y = T[cur.out_t];
+                if (y.consumers.size() != 2) break;
+                int next = -1;
+                for (int j = cur.host + 1; j < nn && next < 0; ++j) {
+                    Blk nb;
+                    if (block_of(j, &nb) && !nb.ds && nb.in_t == cur.out_t) next = j;
+                }
+                if (next < 0) break;
+                Blk nb; block_of(next, &nb);
+                if (nb.C != first.C || nb.MID != first.MID || nb.H != first.H || nb.W != first.W) break;
+                const int c0 = y.consumers[0], c1 = y.consumers[1], want0 = ND[next].fb_a, want1 = ND[next].fused_add;
+                if (!((c0 == want0 && c1 == want1) || (c0 == want1 && c1 == want0))) break;
+                hosts.push_back(next); cur = nb;
+            }
+            if (hosts.size() < 2) continue;
+            const int last = hosts.back();
+            for (int h : hosts) ND[h].chain_into = last;
+            ND[last].chain = hosts;
+        }
+        // identity blocks that only the chain kernel could run and that did not end up in a chain: back to separate launches
+        for (int i = 0; i < nn; ++i) {
+            Node& c = ND[i];
+            if (c.kind == N_CONV && c.fb_a >= 0 && c.fb_R == 0 && c.chain_into < 0) {
+                ND[c.fb_a].absorbed_by = -1; ND[c.fb_b].absorbed_by = -1; ND[c.fb_b].no_classes = false;
+                c.fb_a = c.fb_b = -1;
+            }
+        }
+    }
+    // position of a block (by its host conv) inside its chain, -1: not chained
+    auto chain_pos = [&](int host) -> int {
+        if (host < 0 || ND[host].chain_into < 0) return -1;
+        const std::vector<int>& ch = ND[ND[host].chain_into].chain;
+        for (size_t k = 0; k < ch.size(); ++k) if (ch[k] == host) return (int)k;
+        return -1;
+    };
 
     // ---- 1e. MobileNet-V2 inverted residual: 1x1 expand (ReLU) -> depthwise 3x3 (ReLU) -> 1x1 project [+ residual with the
     //          block input], intermediates read by nobody else  ->  one launch (f8_ir.hip), the expanded tensors stay in LDS
@@ -856,11 +939,18 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 nd.depthwise = nd.cd.groups != 1;
                 if ((nd.absorbed_by >= 0 && ND[nd.absorbed_by].fbd_b == i) || (nd.dual_host >= 0 && ND[nd.dual_host].fbd_a >= 0)) break;   // DS: in LDS
                 if (nd.p12_a >= 0) break;                    // the 1x1's output lives in LDS inside the launch
+                {   // stage chain (f8_chain.hip): the tensors between its blocks exist in no form at all; an identity first block
+                    // reads only the int32 form of the stage input (its int8 copy is made in the launch)
+                    const int host = nd.absorbed_by >= 0 && ND[nd.absorbed_by].fb_a == i ? nd.absorbed_by : -1;   // nd = body.0 of an identity block
+                    const int pos = chain_pos(host);
+                    if (pos > 0) break;
+                    if (pos == 0) { add_form(s, FORM_I32, 0, 0); break; }
+                }
                 if (nd.fb_a >= 0 || (nd.absorbed_by >= 0 && ND[nd.absorbed_by].fb_b == i) || nd.ir_a >= 0 ||
                     (nd.absorbed_by >= 0 && ND[nd.absorbed_by].ir_b == i)) {
                     // source lives in LDS inside the fused launch: no HBM form.  (The block's first conv
                     // still reads the block input from HBM and falls through to the generic case.)
-                    if (nd.fused_add >= 0) {
+                    if (nd.fused_add >= 0 && chain_pos(i) <= 0) {
                         const Node& ad = ND[nd.fused_add];
                         const int other = (ad.a == nd.out) ? ad.b : ad.a;
                         add_form(T[other], FORM_I32, 0, 0);
@@ -939,6 +1029,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         Node& nd = ND[i];
         if (nd.kind == N_ADD && nd.fused_into >= 0) continue;
         if (nd.kind == N_CONV && (nd.absorbed_by >= 0 || nd.dual_host >= 0)) continue;
+        if (nd.kind == N_CONV && nd.chain_into >= 0 && nd.chain_into != i) continue;      // runs inside the chain launch of a later block
         if (nd.kind == N_MAXPOOL && nd.sp_conv >= 0) continue;
         Step st; st.node = i;
         std::vector<int> extra;
@@ -978,6 +1069,46 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     st.bytes_const = (double)nd.coutP * (nd.ktot + 4);
                     st.name = "stem7x7s2+maxpool3x3s2:" + tname(net, nd.out) + "+" + tname(net, pl.out);
                     st.kernel = "f8::stem_pool_kernel";
+                    break;
+                }
+                if (nd.chain_into == i) {
+                    // ---- stage chain: nd is the host conv of its LAST block
+                    const std::vector<int> ch = nd.chain;
+                    Node& hf = ND[ch[0]];
+                    const bool ds = hf.fbd_a >= 0;
+                    Tensor& x = T[ds ? hf.a : ND[hf.fb_a].a];
+                    st.kind = S_CHAIN;
+                    st.src_t = ds ? hf.a : ND[hf.fb_a].a;
+                    if (ds) { int n0 = 0; consumer_format(x, ND[hf.fbd_a].cd, &n0, "finalize"); st.src_f = find_form(x, FORM_I8, n0, ND[hf.fbd_a].cd.input_signed ? 1 : 0); }
+                    else st.src_f = find_form(x, FORM_I32, 0, 0);
+                    double ops = 0, wbytes = 0;
+                    for (int hi : ch) {
+                        Node& hh = ND[hi];
+                        const bool hds = hh.fbd_a >= 0;
+                        Node* cv[4] = {&ND[hds ? hh.fbd_a : hh.fb_a], &ND[hds ? hh.fbd_b : hh.fb_b], hds ? &ND[hh.dual] : &hh, hds ? &hh : nullptr};
+                        for (Node* c : cv) {
+                            if (!c) continue;
+                            pack_conv_weights(net, *c, T[c->a], T[c->out]);
+                            pack_frag_weights(net, *c);
+                            const double px = (double)T[c->out].H * T[c->out].W;
+                            ops += 2.0 * px * c->cd.cin * c->cd.cout * c->cd.kernel * c->cd.kernel;
+                            wbytes += (double)c->coutP * (c->ktot + 4);
+                        }
+                    }
+                    out_t = ND[nd.fused_add].out;
+                    select_outputs(net, out_t, &st.out, &extra);
+                    Tensor& o = T[out_t];
+                    const double px = (double)x.H * x.W;
+                    double b = px * x.Cs * (ds ? 1 : 4);                            // the stage input, once
+                    if (st.out.f32 >= 0) b += px * o.Cs * 4;
+                    for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += px * o.Cs;
+                    st.ops_per_img = ops; st.bytes_per_img = b; st.bytes_const = wbytes;
+                    const Node& a0 = ND[ds ? hf.fbd_a : hf.fb_a];
+                    st.name = "stage_chain_x" + std::to_string(ch.size()) + (ds ? "_ds:" : ":") + tname(net, a0.out) + ".." + tname(net, nd.out);
+                    char kb[160];
+                    const int C = o.C, MID = a0.cd.cout;
+                    snprintf(kb, sizeof kb, "f8::chain_kernel<%d, %d, %d, %d, 4, %d, %s>", C, MID, x.W, x.H, a0.cd.cin, MID == 64 ? "2, 4" : "4, 3");   // keep in sync with launch_chain
+                    st.kernel = kb;
                     break;
                 }
                 if (nd.fbd_a >= 0) {
@@ -1465,6 +1596,12 @@ int f8_net_upload(f8_net* net) {
     if ((e = hipMalloc((void**)&net->d_w, std::max<size_t>(net->wblob.size(), 256))) != hipSuccess) return hip_fail(e, "hipMalloc(weights)");
     if (!net->wblob.empty() && (e = hipMemcpy(net->d_w, net->wblob.data(), net->wblob.size(), hipMemcpyHostToDevice)) != hipSuccess)
         return hip_fail(e, "hipMemcpy(weights)");
+    for (const Step& st : net->steps)
+        if (st.kind == S_CHAIN && !net->d_chain) {
+            net->chain_stride = round_up_z(4096 + kChainXchgBytes, 4096);
+            if ((e = hipMalloc((void**)&net->d_chain, net->chain_stride * parts_cap)) != hipSuccess) return hip_fail(e, "hipMalloc(chain scratch)");
+            if ((e = hipMemset(net->d_chain, 0, net->chain_stride * parts_cap)) != hipSuccess) return hip_fail(e, "hipMemset(chain scratch)");
+        }
     for (int p = 0; p < parts_cap; ++p)
         if (net->stem_zero_bytes && (e = hipMemset(net->d_arena + p * net->arena_stride + net->stem_zero_off, net->stem_zero_val, net->stem_zero_bytes)) != hipSuccess)
             return hip_fail(e, "hipMemset(stem halo)");
@@ -1625,6 +1762,50 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1;
             fill_out(&a.out32, a.q);
             e = launch_fused_bottleneck(a, s);
+            break;
+        }
+        case S_CHAIN: {
+            const std::vector<int>& ch = nd.chain;
+            ChainArgs a{};
+            a.nblk = (int)ch.size();
+            auto fmt = [&](const Node& cons, const Tensor& src, int32_t* n, int32_t* lo, int32_t* hi, uint32_t* x_or) {
+                int nn = 0; consumer_format(src, cons.cd, &nn, "run");
+                *n = nn; *lo = cons.cd.input_signed ? -127 : 0; *hi = cons.cd.input_signed ? 127 : 255;
+                *x_or = cons.cd.input_signed ? 0u : 0x80808080u;
+            };
+            for (int k = 0; k < a.nblk; ++k) {
+                const Node& hh = net->nodes[ch[k]];
+                const bool hds = hh.fbd_a >= 0;
+                const Node& na = net->nodes[hds ? hh.fbd_a : hh.fb_a]; const Node& nb = net->nodes[hds ? hh.fbd_b : hh.fb_b];
+                const Node& ng = hds ? net->nodes[hh.dual] : hh;
+                ChainBlk& B = a.blk[k];
+                B.w0 = (const int8_t*)(net->d_w + na.wf_off); B.w2 = (const int8_t*)(net->d_w + nb.wf_off); B.w4 = (const int8_t*)(net->d_w + ng.wf_off);
+                B.b0 = (const int32_t*)(net->d_w + na.b_off); B.b2 = (const int32_t*)(net->d_w + nb.b_off); B.b4 = (const int32_t*)(net->d_w + ng.b_off);
+                if (hds) { B.wsc = (const int8_t*)(net->d_w + hh.wf_off); B.bsc = (const int32_t*)(net->d_w + hh.b_off); }
+                const Tensor& xin = T[na.a];
+                fmt(na, xin, &B.nq, &B.loq, &B.hiq, &B.xorq);
+                fmt(nb, T[nb.a], &B.n1, &B.lo1, &B.hi1, &B.xor1);
+                fmt(ng, T[ng.a], &B.n2, &B.lo2, &B.hi2, &B.xor2);
+                B.relu_a = na.cd.relu; B.relu_b = nb.cd.relu; B.relu1 = net->nodes[hh.fused_add].relu;
+                // identity: (body.4 << acc_shl) + (block input << res_shl); opening block: (shortcut << acc_shl) + (body.4 << res_shl)
+                const int dfl = T[hh.out].fl - (hds ? T[ng.out].fl : xin.fl);
+                B.acc_shl = dfl < 0 ? -dfl : 0; B.res_shl = dfl > 0 ? dfl : 0;
+            }
+            const Node& hf = net->nodes[ch[0]];
+            const bool ds = hf.fbd_a >= 0;
+            const Tensor& x = T[st.src_t]; const Form& xF = x.forms[st.src_f];
+            if (ds) a.x8in = (const int8_t*)fp(xF); else a.xr = (const int32_t*)fp(xF);
+            const Node& a0 = net->nodes[ds ? hf.fbd_a : hf.fb_a];
+            const int C = T[st.out.t].C, MID = a0.cd.cout;
+            const int tiles = chain_tiles_per_img(x.H, x.W);
+            a.N = N; a.NG = std::max(1, std::min(N, (net->num_cu > 0 ? std::min(net->num_cu, 256) : 256) / tiles));
+            fill_out(&a.out32, a.q);
+            if (!net->d_chain) return fail(F8_ERR_STATE, "f8_net_run: chain scratch missing");
+            a.sync = (uint32_t*)(net->d_chain + (size_t)part * net->chain_stride);
+            a.err = a.sync + 512;
+            a.xchg = (int8_t*)(net->d_chain + (size_t)part * net->chain_stride + 4096);
+            a.timeout_ticks = (uint32_t)std::min<long long>((long long)net->opt.chain_timeout_ms * 100000ll, 0x7fffffffll);
+            e = launch_chain(a, C, MID, x.H, x.W, a0.cd.cin, s);
             break;
         }
         case S_P12: {

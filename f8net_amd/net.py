@@ -183,6 +183,11 @@ class F8Net:
             check(self._L.f8_net_run(self._h, x.data_ptr(), out.data_ptr(), N, ctypes.c_void_p(stream)))
         return out
 
+    def check(self):
+        """Synchronise the device and raise if a kernel of an earlier run reported a failure (f8_net_check)."""
+        check(self._L.f8_net_check(self._h))
+        return self
+
     def autotune(self, N, device=None):
         """Measured tile selection for runs of N images (f8_net_autotune).  Returns the number of launches re-tiled."""
         import torch

@@ -215,11 +215,17 @@ int f8_net_set_pipelined(f8_net* net, int on);
  * One-shot: consumed by the next run. */
 int f8_net_set_input_ready(f8_net* net, void* event);
 
+/* Blocks until the device is idle and reports failures that happened INSIDE kernels of earlier runs of this handle: the
+ * stage-chain launches (option fuse_chain) exchange halo rows between workgroups and bound every wait (chain_timeout_ms); a
+ * workgroup whose neighbour never arrives sets an error word and leaves, and the run's outputs are then invalid.  F8_OK, or
+ * F8_ERR_HIP with the code in f8_last_error (the word is cleared).  Never needed for correctness of a healthy run. */
+int f8_net_check(f8_net* net);
+
 /* Per-handle tuning options.  A new handle takes its defaults from the environment (F8_<KEY IN CAPITALS>; F8_CHUNK for
  * chunk56) and otherwise the measured best; two handles in one process may differ.  Keys that decide the plan must be set
  * before f8_net_finalize (F8_ERR_STATE afterwards); scheduling keys may change between runs.
  *   planning  : split (1..4 concurrent sub-batches = arena copies), fuse_blocks, fuse_stages (bit mask, -1 = auto), fuse_dual,
- *               fuse_ds, fuse_opener, fuse_fc (the classifier writes the caller's logits buffer itself), fuse_stem, fuse_input (the fused stem launch reads the caller's NCHW buffer itself), fuse_ir (1 = where it wins, 2 = every block), fuse_p12 (7x7 block: first two
+ *               fuse_ds, fuse_opener, fuse_fc (the classifier writes the caller's logits buffer itself), fuse_stem, fuse_input (the fused stem launch reads the caller's NCHW buffer itself), fuse_ir (1 = where it wins, 2 = every block), fuse_chain (all consecutive bottleneck blocks of a stage in one launch, the int32 residual stream in registers), fuse_p12 (7x7 block: first two
  *               convs in one launch), wstat (weight-stationary 1x1 kernel: plain, dual-GEMM and residual-join instances) with
  *               wstat_min_tiles (pixel tiles per workgroup a launch must offer; 0 = always) and wstat_fast (0 = general epilogue), wreg (weights-streamed 1x1 kernel for the
  *               512 -> 256 / 1024 -> 512 reductions of smaller launches),
@@ -227,7 +233,8 @@ int f8_net_set_input_ready(f8_net* net, void* event);
  *               f8_net_set_pipelined(2))
  *   scheduling: chunk56 / chunk28 / chunk14 (images per chunk of the fused blocks; -1 = derived from chunk_budget_mb, 0 = whole
  *               batch), chunk_budget_mb (memory-side cache a chunk's int32 stream may occupy), chunk_ds, chunk_opener,
- *               split_streams, graph, stagger, stagger_pipelined, stem_wpc, check_device, pipeline_depth (2..4 runs in flight)
+ *               split_streams, graph, stagger, stagger_pipelined, stem_wpc, check_device, pipeline_depth (2..4 runs in flight),
+ *               chain_timeout_ms (bound of a stage-chain launch's halo waits)
  * F8_ERR_INVALID for an unknown key or a value outside the key's range. */
 int f8_net_set_option(f8_net* net, const char* key, int value);
 int f8_net_get_option(const f8_net* net, const char* key, int* value);
