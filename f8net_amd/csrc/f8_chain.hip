@@ -37,57 +37,76 @@ struct ChainCfg {
     static constexpr int T = (H + R - 1) / R;                  // tiles (workgroups) per image
     static constexpr int PX = R * W, NPT = (PX + 31) / 32, ROWS = NPT * 32;
     static constexpr int PW = W + 2, PR = R + 2;
-    static constexpr int X8_BYTES = ROWS * C;
-    static constexpr int PATCH_BYTES = (PR * PW * MID + 255) / 256 * 256;
-    static constexpr int MID2_BYTES = ROWS * MID;
-    static constexpr int XIN_BYTES = CIN0 != C ? ROWS * CIN0 : 0;
+    // LDS rows are PADDED by 16 bytes instead of XOR-swizzled: the 16 lanes of a ds_read_b128 service group read consecutive rows
+    // at one K offset, a row stride of 16 (mod 256) bytes spreads them over all 64 banks, and every address of the unrolled K loops
+    // is ONE per-lane base register plus an immediate
+    static constexpr int XS = C + 16, MS = MID + 16, IS = CIN0 + 16;
+    static constexpr int X8_BYTES = ROWS * XS;
+    static constexpr int PATCH_BYTES = (PR * PW * MS + 255) / 256 * 256;
+    static constexpr int MID2_BYTES = ROWS * MS;
+    static constexpr int XIN_BYTES = CIN0 != C ? ROWS * IS : 0;
+    static constexpr int BIAS_INTS = 2 * MID + C;              // per block: b0 | b2 | b4
+    static constexpr int BIAS_BYTES = (kChainMaxBlocks * BIAS_INTS + (CIN0 != C ? C : 0)) * 4;   // + bsc of the stage-opening block
     static constexpr int MISC_BYTES = 256;
-    static constexpr int LDS_BYTES = X8_BYTES + PATCH_BYTES + MID2_BYTES + XIN_BYTES + MISC_BYTES;
+    static constexpr int LDS_BYTES = X8_BYTES + PATCH_BYTES + MID2_BYTES + XIN_BYTES + BIAS_BYTES + MISC_BYTES;
     static constexpr int ROWB = W * MID;                       // one exchanged row of mid1
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(X8_BYTES < 65536 + 4096 && PATCH_BYTES < 65536 && MID2_BYTES < 65536, "immediate offsets");
     static_assert(ROWB / 16 <= 256 && (size_t)256 * 4 * ROWB <= kChainXchgBytes, "one 16-byte piece of a halo row per thread of a half workgroup");
 };
 
 // 16 accumulator values of one 32x32 tile (this lane: one pixel, channels 8g + 4 lh + e) -> this lane's 16 bytes of the int8 row:
-// channels [16 lh, 16 lh + 16) of the tile (two v_permlane32_swap put a lane's four dwords side by side)
+// channels [16 lh, 16 lh + 16) of the tile (two v_permlane32_swap put a lane's four dwords side by side).
+// FAST: n > 0 is known (4-operation requant, f8_device.h); otherwise either direction.
+template <bool FAST>
 __device__ __forceinline__ v4i quant_tile16(const v16i& y, int n, int lo, int hi, unsigned x_or) {
     unsigned d[4];
+    const unsigned half = FAST ? (1u << (n - 1)) : 0u;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-        d[g] = pack4(requant1(y[4 * g + 0], n, lo, hi), requant1(y[4 * g + 1], n, lo, hi), requant1(y[4 * g + 2], n, lo, hi), requant1(y[4 * g + 3], n, lo, hi)) ^ x_or;
+    for (int g = 0; g < 4; ++g) {
+        int q[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] = FAST ? requant_shr(y[4 * g + e], n, half, 0u, lo, hi) : requant1(y[4 * g + e], n, lo, hi);
+        d[g] = pack4(q[0], q[1], q[2], q[3]) ^ x_or;
+    }
     auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
     auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
     const v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
     return o;
 }
 
-template <int C, int MID, int W, int H, int R, int CIN0, int NB, int NBUF>
+// a scalar the optimiser may not look through (keeps run-time rotated addresses from being precomputed for every unrolled step)
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+s"(v)); return v; }
+
+// FAST: every block has ReLU after body.0 / body.2 / the join, every int8 format of the chain is unsigned with a right shift, and the
+// stream itself is never shifted (res_shl == 0) — true for the real fraclen tables; the generic instance takes everything else.
+// ROT: rotate the K order per (workgroup, wave) in coarse groups (L2-bound instance: all workgroups stream the same weights).
+template <int C, int MID, int W, int H, int R, int CIN0, int NB, int NBUF, bool FAST, bool ROT>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 chain_kernel(const ChainArgs a) {
     using Cfg = ChainCfg<C, MID, W, H, R, CIN0>;
     constexpr bool DS0 = CIN0 != C;
-    constexpr int T = Cfg::T, PX = Cfg::PX, NPT = Cfg::NPT, PW = Cfg::PW, ROWB = Cfg::ROWB;
+    constexpr int T = Cfg::T, NPT = Cfg::NPT, PW = Cfg::PW, ROWB = Cfg::ROWB, BIAS_INTS = Cfg::BIAS_INTS;
+    constexpr int XS = Cfg::XS, MS = Cfg::MS, IS = Cfg::IS;
     constexpr int CT = C / 32, CM = MID / 32, CTW = CT / 8;
     static_assert(CT % 8 == 0 && (CM == 2 || CM == 4 || CM == 8), "8 waves: whole channel tiles per wave in P3, whole pixel-tile groups in P1 / P2");
     constexpr int PG = 8 / CM;                                  // pixel-tile groups in P1 / P2
     constexpr int NPW = (NPT + PG - 1) / PG;                    // pixel tiles per wave there
-    constexpr int NK1 = C / 32, NK2 = 9 * CM, KK = CM;          // K32 steps of body.0 / body.2 / body.4
-    constexpr int NPAIR = (NPT + 1) / 2;
+    constexpr int NK1 = C / 32, NK2 = 9 * CM, KK = CM, KS = CIN0 / 32;   // K32 steps of body.0 / body.2 / body.4 / the opening block's shortcut
+    constexpr bool WSTAT = NPT > 2;                             // P3: this wave's weights stay in registers for all pixel tiles (else streamed, two tiles at a time)
     static_assert(NB <= CM && CM % NB == 0 && NK1 % NB == 0, "a batch of K steps stays inside one 3x3 tap / one weight tile");
-    static_assert(NPT <= 2 || KK == NB, "several pixel pairs per channel tile: the tile's whole K range is one register batch");
-    static_assert((NK1 & (NK1 - 1)) == 0 && (KK & (KK - 1)) == 0, "rotation by masking");
-    static_assert(!DS0 || (CIN0 / 32 == NB), "stage-opening block: its K range is one batch");
-    static_assert(PX <= NPT * 32 && W <= 62, "tile");
+    static_assert(!DS0 || KS % NB == 0, "stage-opening block: whole batches");
+    static_assert(!ROT || (NK1 % 8 == 0 && CM == 8), "rotation: groups of 8 K steps (256 bytes of a row), whole taps");
+    static_assert(WSTAT || NPT == 2, "streamed P3: exactly one pixel pair");
+    static_assert(W <= 62, "tile");
 
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    char* const x8 = lds;                                       // [NPT*32 px][C] int8, body.0's input format of the NEXT P1
-    char* const patch = x8 + Cfg::X8_BYTES;                     // [(R+2)][(W+2)][MID] mid1, border = biased zero
-    char* const mid2 = patch + Cfg::PATCH_BYTES;                // [NPT*32 px][MID]
-    char* const xin = mid2 + Cfg::MID2_BYTES;                   // DS0: [NPT*32 px][CIN0], the stage input tile
-    int* const misc = (int*)(xin + Cfg::XIN_BYTES);
-    using SX = Swz<C>;
-    using SM = Swz<MID>;
-    using SI = Swz<CIN0>;
+    char* const x8 = lds;                                       // [NPT*32 px][XS] int8, body.0's input format of the NEXT P1
+    char* const patch = x8 + Cfg::X8_BYTES;                     // [(R+2)][(W+2)][MS] mid1, border = biased zero
+    char* const mid2 = patch + Cfg::PATCH_BYTES;                // [NPT*32 px][MS]
+    char* const xin = mid2 + Cfg::MID2_BYTES;                   // DS0: [NPT*32 px][IS], the stage input tile
+    int* const bias_lds = (int*)(xin + Cfg::XIN_BYTES);         // every block's b0 | b2 | b4, then bsc of the opening block
+    int* const misc = bias_lds + Cfg::BIAS_BYTES / 4;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;
@@ -95,6 +114,13 @@ chain_kernel(const ChainArgs a) {
 
     // ---- place in the logical grid: a ticket
     if (tid == 0) { misc[0] = (int)__hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); misc[1] = 0; }
+    // ---- biases of every block: once per workgroup, into LDS (a global bias load at the head of a phase costs its whole latency)
+    for (int b = 0; b < a.nblk; ++b) {
+        const ChainBlk& B = a.blk[b];
+        for (int i = tid; i < BIAS_INTS; i += 512)
+            bias_lds[b * BIAS_INTS + i] = i < MID ? B.b0[i] : (i < 2 * MID ? B.b2[i - MID] : B.b4[i - 2 * MID]);
+    }
+    if constexpr (DS0) for (int i = tid; i < C; i += 512) bias_lds[kChainMaxBlocks * BIAS_INTS + i] = a.blk[0].bsc[i];
     __syncthreads();
     const int L = __builtin_amdgcn_readfirstlane(misc[0]);
     const int grp = L / T, ti = L - grp * T;
@@ -102,7 +128,7 @@ chain_kernel(const ChainArgs a) {
     const int rows = (H - p0) < R ? (H - p0) : R;
     const int npx = rows * W;
     const bool has_up = ti > 0, has_dn = ti < T - 1;
-    const int rot = __builtin_amdgcn_readfirstlane(L * 5 + wave * 3);
+    const int rot = ROT ? __builtin_amdgcn_readfirstlane(L * 5 + wave * 3) : 0;
 
     unsigned* const flags = a.sync + 16;
     const unsigned long long t_limit = (unsigned long long)a.timeout_ticks;
@@ -113,14 +139,51 @@ chain_kernel(const ChainArgs a) {
 #define F8_CT(i)
 #endif
 
-    // P1 / P2 roles
+    // P1 / P2 roles: wave (mt, pg) computes mid channel tile mt for pixel tiles pg + PG j; a missing tile repeats the last one (same bytes twice)
     const int mt = wave & (CM - 1), pg = wave / CM;
-    int p12_pt[NPW];
+    // per-lane LDS bases: everything else is an immediate
+    const unsigned xlane = (unsigned)(l31 * XS + lh * 16), mlane = (unsigned)(l31 * MS + lh * 16), ilane = (unsigned)(l31 * IS + lh * 16);
+    unsigned p12x[NPW], p12m[NPW], p12i[NPW]; int p12_pix[NPW];
 #pragma unroll
-    for (int j = 0; j < NPW; ++j) { const int pt = pg + PG * j; p12_pt[j] = pt < NPT ? pt : NPT - 1; }   // a missing tile repeats the last one (same bytes written twice)
+    for (int j = 0; j < NPW; ++j) {
+        const int pt = (pg + PG * j) < NPT ? (pg + PG * j) : NPT - 1;
+        p12_pix[j] = pt * 32 + l31;
+        p12x[j] = (unsigned)(pt * 32 * XS) + xlane; p12m[j] = (unsigned)(pt * 32 * MS) + mlane; p12i[j] = (unsigned)(pt * 32 * IS) + ilane;
+    }
 
     v16i res[NPT][CTW];                                         // the tile's int32 stream: pixel tile x this wave's channel tiles
+    v4i wbuf[NBUF][NB];                                         // A operands in flight: NBUF batches of NB K32 steps (one 1 KB wave load each)
     unsigned seq = 0;
+
+    // ---- weight streams (fragment order: [tile][K32 step][lane][16 B]).  step -> K index: identity, or rotated in coarse groups.
+    auto k1_of = [&](int g, int nk) { return ROT ? (((g >> 3) + opaque(rot)) & (nk / 8 - 1)) * 8 + (g & 7) : g; };       // body.0: groups of 8 steps
+    auto tap_of = [&](int t) { if (!ROT) return t; int q = t + (int)((unsigned)opaque(rot) % 9u); return q >= 9 ? q - 9 : q; };   // body.2: whole taps
+    auto w1_load = [&](const ChainBlk& B, auto nkc, v4i (&dst)[NB], int bi) {
+        constexpr int NK = decltype(nkc)::value;
+        const v4i* const wp = (const v4i*)B.w0 + (size_t)mt * NK * 64 + lane;
+        const int k0 = k1_of(bi * NB, NK);
+#pragma unroll
+        for (int s = 0; s < NB; ++s) dst[s] = wp[(size_t)(k0 + s) * 64];
+    };
+    auto w1_prime = [&](const ChainBlk& B, auto nkc) {
+        constexpr int NBAT = decltype(nkc)::value / NB;
+        static_for<(NBUF - 1 < NBAT ? NBUF - 1 : NBAT)>([&](auto bc) { constexpr int Bi = decltype(bc)::value; w1_load(B, nkc, wbuf[Bi], Bi); });
+    };
+    constexpr int NBAT2 = NK2 / NB, BPTAP = CM / NB;            // body.2: batches, batches per tap
+    auto w2_load = [&](const ChainBlk& B, v4i (&dst)[NB], int bi) {
+        const v4i* const wp = (const v4i*)B.w2 + (size_t)mt * NK2 * 64 + lane;
+        const int k0 = tap_of(bi / BPTAP) * CM + (bi % BPTAP) * NB;
+#pragma unroll
+        for (int s = 0; s < NB; ++s) dst[s] = wp[(size_t)(k0 + s) * 64];
+    };
+    auto w2_prime = [&](const ChainBlk& B) {
+        static_for<NBUF - 1>([&](auto bc) { constexpr int Bi = decltype(bc)::value; w2_load(B, wbuf[Bi], Bi); });
+    };
+    // the MFMAs of a step must not be scheduled above the LDS reads of the NEXT step that are issued just before them
+    auto pin = [](auto& xf) {
+#pragma unroll
+        for (int j = 0; j < (int)(sizeof(xf) / sizeof(xf[0])); ++j) asm volatile("" : "+v"(xf[j]));
+    };
 
     for (int n = grp; n < a.N; n += a.NG) {
         const int m_tile = (n * H + p0) * W;                    // global pixel index of the tile's first pixel
@@ -145,19 +208,21 @@ chain_kernel(const ChainArgs a) {
                     }
                 }
             }
+            w1_prime(B0, std::integral_constant<int, NK1>{});
 #pragma unroll
             for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
                 for (int i = 0; i < CTW; ++i)
-                    *(v4i*)(x8 + SX::off(pt * 32 + l31, (wave * CTW + i) * 2 + lh)) = quant_tile16(res[pt][i], B0.nq, B0.loq, B0.hiq, B0.xorq);
+                    *(v4i*)(x8 + xlane + pt * 32 * XS + (wave * CTW + i) * 32) = quant_tile16<FAST>(res[pt][i], B0.nq, B0.loq, B0.hiq, B0.xorq);
         } else {
             constexpr int CH = CIN0 / 16;                       // 16-byte chunks per pixel
             for (int idx = tid; idx < NPT * 32 * CH; idx += 512) {
                 const int row = idx / CH, c16 = idx % CH;
                 v4i v = {0, 0, 0, 0};
                 if (row < npx) v = *(const v4i*)(a.x8in + (size_t)(m_tile + row) * CIN0 + c16 * 16);
-                *(v4i*)(xin + SI::off(row, c16)) = v;
+                *(v4i*)(xin + row * IS + c16 * 16) = v;
             }
+            w1_prime(a.blk[0], std::integral_constant<int, KS>{});
         }
         __syncthreads();
         F8_CT(0);
@@ -165,72 +230,66 @@ chain_kernel(const ChainArgs a) {
         for (int b = 0; b < a.nblk; ++b) {
             ++seq;
             const ChainBlk& B = a.blk[b];
+            const int* const bl = bias_lds + b * BIAS_INTS;
             auto block = [&](auto dsc) {
                 constexpr bool DSB = decltype(dsc)::value;      // this block is the stage-opening block (first block of a DS0 chain)
-                constexpr int NK1B = DSB ? CIN0 / 32 : NK1;
-                constexpr int NBAT1 = NK1B / NB;
-                const char* const xsrc = DSB ? xin : x8;
-                using SXB = std::conditional_t<DSB, SI, SX>;
-                constexpr int XROWB = DSB ? CIN0 : C;
+                constexpr int NK1B = DSB ? KS : NK1;
+                constexpr bool ROT1 = ROT && !DSB;
 
-                // ============================ P1: mid1 = requant(relu(W0 . x8 + b0)) -> patch interior
+                // ============================ P1: mid1 = requant(relu(W0 . x8 + b0)) -> patch interior   (its first weight batches are in flight)
                 {
                     {   // the whole patch <- biased zero: border columns, rows outside the image; everything else is overwritten below
                         const v4i zv = {(int)B.xor1, (int)B.xor1, (int)B.xor1, (int)B.xor1};
                         for (int o = tid * 16; o < Cfg::PATCH_BYTES; o += 512 * 16) *(v4i*)(patch + o) = zv;
                     }
                     v16i acc[NPW];
-                    {
-                        v4i bv[4];
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) bv[g] = *(const v4i*)(B.b0 + mt * 32 + 8 * g + 4 * lh);
+                    for (int g = 0; g < 4; ++g) {
+                        const v4i bv = *(const v4i*)(bl + mt * 32 + 8 * g + 4 * lh);
 #pragma unroll
                         for (int j = 0; j < NPW; ++j)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[j][r] = bv[r >> 2][r & 3];
+                            for (int e = 0; e < 4; ++e) acc[j][4 * g + e] = bv[e];
                     }
-                    const v4i* const wp = (const v4i*)B.w0 + (size_t)mt * NK1B * 64 + lane;
-                    unsigned xrow[NPW], xsw[NPW];
+                    constexpr int NBAT1 = NK1B / NB;
+                    const char* const xsrc = DSB ? xin : x8;
+                    auto rd = [&](v4i (&xf)[NPW], auto gc) {
+                        constexpr int G = decltype(gc)::value;
+                        if constexpr (ROT1) {
+                            const unsigned ko = (unsigned)(k1_of(G & ~7, NK1B) * 32 + (G & 7) * 32);
 #pragma unroll
-                    for (int j = 0; j < NPW; ++j) {
-                        const int row = p12_pt[j] * 32 + l31;
-                        xrow[j] = (unsigned)(row * XROWB);
-                        xsw[j] = (unsigned)((lh ^ SXB::f(row)) << 4);
-                    }
-                    const int rotk = rot & (NK1B - 1);
-                    v4i wbuf[NBUF][NB];
-                    auto load_batch = [&](v4i (&dst)[NB], int bi) {
+                            for (int j = 0; j < NPW; ++j) xf[j] = *(const v4i*)(xsrc + p12x[j] + ko);
+                        } else {
 #pragma unroll
-                        for (int s = 0; s < NB; ++s) dst[s] = wp[(size_t)((bi * NB + s + rotk) & (NK1B - 1)) * 64];
-                    };
-                    static_for<(NBUF - 1 < NBAT1 ? NBUF - 1 : NBAT1)>([&](auto bc) { constexpr int Bi = decltype(bc)::value; load_batch(wbuf[Bi], Bi); });
-                    static_for<NBAT1>([&](auto bc) {
-                        constexpr int Bi = decltype(bc)::value;
-                        if constexpr (Bi + NBUF - 1 < NBAT1) load_batch(wbuf[(Bi + NBUF - 1) % NBUF], Bi + NBUF - 1);
-                        int kb = Bi * NB + rotk;
-                        asm volatile("" : "+s"(kb));                // address arithmetic just in time (hoisted out of the block loop it costs hundreds of registers)
-#pragma unroll
-                        for (int s = 0; s < NB; ++s) {
-                            const unsigned k32 = (unsigned)(((kb + s) & (NK1B - 1)) << 5);   // byte offset of the K step = chunk 2k << 4
-#pragma unroll
-                            for (int j = 0; j < NPW; ++j) {
-                                const v4i xf = *(const v4i*)(xsrc + xrow[j] + (k32 ^ xsw[j]));
-                                acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Bi % NBUF][s], xf, acc[j], 0, 0, 0);
-                            }
+                            for (int j = 0; j < NPW; ++j) xf[j] = *(const v4i*)(xsrc + (DSB ? p12i[j] : p12x[j]) + G * 32);
                         }
+                    };
+                    v4i xfa[NPW], xfb[NPW];
+                    rd(xfa, std::integral_constant<int, 0>{});
+                    static_for<NK1B>([&](auto gc) {
+                        constexpr int G = decltype(gc)::value, Bi = G / NB, S = G % NB;
+                        if constexpr (S == 0 && Bi + NBUF - 1 < NBAT1) w1_load(B, std::integral_constant<int, NK1B>{}, wbuf[(Bi + NBUF - 1) % NBUF], Bi + NBUF - 1);
+                        v4i (&cur)[NPW] = (G & 1) ? xfb : xfa;
+                        v4i (&nxt)[NPW] = (G & 1) ? xfa : xfb;
+                        if constexpr (G + 1 < NK1B) rd(nxt, std::integral_constant<int, G + 1>{});
+                        pin(cur);
+#pragma unroll
+                        for (int j = 0; j < NPW; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Bi % NBUF][S], cur[j], acc[j], 0, 0, 0);
                     });
+                    w2_prime(B);                                // body.2's first weight batches travel during the epilogue and the halo exchange
                     __syncthreads();                            // the zero fill is complete
                     const int floor0 = B.relu_a ? 0 : INT32_MIN;
 #pragma unroll
                     for (int j = 0; j < NPW; ++j) {
-                        const int pix = p12_pt[j] * 32 + l31;
+                        const int pix = p12_pix[j];
                         const int pr = pix / W, pc = pix - pr * W;
                         const int ent = (pr + 1) * PW + pc + 1;
-                        v16i y;
+                        if constexpr (!FAST) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) y[r] = max(acc[j][r], floor0);
-                        const v4i o = quant_tile16(y, B.n1, B.lo1, B.hi1, B.xor1);
-                        if (pix < npx) *(v4i*)(patch + SM::off(ent, mt * 2 + lh)) = o;
+                            for (int r = 0; r < 16; ++r) acc[j][r] = max(acc[j][r], floor0);
+                        }
+                        const v4i o = quant_tile16<FAST>(acc[j], B.n1, B.lo1, B.hi1, B.xor1);   // FAST: lo1 == 0 is the ReLU
+                        if (pix < npx) *(v4i*)(patch + ent * MS + mt * 32 + lh * 16) = o;
                     }
                 }
                 F8_CT(1);
@@ -246,7 +305,7 @@ chain_kernel(const ChainArgs a) {
                     const unsigned par = seq & 1u;
                     if (mine) {
                         const int ent = (side == 0 ? 1 : rows) * PW + col + 1;
-                        const v4i v = *(const v4i*)(patch + SM::off(ent, c16));
+                        const v4i v = *(const v4i*)(patch + ent * MS + c16 * 16);
                         __builtin_amdgcn_raw_buffer_store_b128(v, rxc, (unsigned)(((L * 2 + (int)par) * 2 + side) * ROWB + idx * 16), 0, 17);   // sc0 sc1: write-through
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains
@@ -258,7 +317,7 @@ chain_kernel(const ChainArgs a) {
                         const unsigned long long t0 = wall_clock64();
                         bool ok = true;
                         while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
-                            __builtin_amdgcn_s_sleep(4);
+                            __builtin_amdgcn_s_sleep(2);
                             if (wall_clock64() - t0 > t_limit) { ok = false; break; }
                         }
                         if (!ok) { misc[1] = 1; __hip_atomic_store(a.err, 0x100u + (unsigned)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -269,69 +328,89 @@ chain_kernel(const ChainArgs a) {
                         const int nb_wg = side == 0 ? L - 1 : L + 1;            // upper neighbour's BOTTOM row / lower neighbour's TOP row
                         const v4i v = __builtin_amdgcn_raw_buffer_load_b128(rxc, (unsigned)(((nb_wg * 2 + (int)par) * 2 + (1 - side)) * ROWB + idx * 16), 0, 17);
                         const int ent = (side == 0 ? 0 : rows + 1) * PW + col + 1;
-                        *(v4i*)(patch + SM::off(ent, c16)) = v;
+                        *(v4i*)(patch + ent * MS + c16 * 16) = v;
                     }
                     __syncthreads();
                 }
                 F8_CT(2);
 
                 // ============================ P2: mid2 = requant(relu(conv3x3(mid1) + b2)) -> mid2
-                {
-                    constexpr int NBAT2 = NK2 / NB;
-                    v16i acc[NPW];
-                    {
-                        v4i bv[4];
+                // this wave's P3 weights (WSTAT): requested when P2's K loop is over, so they travel during its epilogue
+                constexpr int K0 = DSB ? KS : 0, KT = KK + K0;  // opening block: the shortcut's K steps come first
+                v4i wst[WSTAT ? CTW * KT : 1];
+                auto wst_load = [&]() {
+                    if constexpr (WSTAT) {
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) bv[g] = *(const v4i*)(B.b2 + mt * 32 + 8 * g + 4 * lh);
+                        for (int i = 0; i < CTW; ++i) {
+                            const int ct = wave * CTW + i;
+                            if constexpr (DSB) {
+                                const v4i* const wps = (const v4i*)B.wsc + (size_t)ct * KS * 64 + lane;
+#pragma unroll
+                                for (int k = 0; k < KS; ++k) wst[i * KT + k] = wps[(size_t)k * 64];
+                            }
+                            const v4i* const wp = (const v4i*)B.w4 + (size_t)ct * KK * 64 + lane;
+#pragma unroll
+                            for (int k = 0; k < KK; ++k) wst[i * KT + K0 + k] = wp[(size_t)k * 64];
+                        }
+                    }
+                };
+                auto w3_load = [&](v4i (&dst)[NB], int qi) {      // streamed P3: batch qi of this wave's CTW consecutive channel tiles
+                    const v4i* const wp = (const v4i*)B.w4 + (size_t)(wave * CTW) * KK * 64 + lane;
+#pragma unroll
+                    for (int s = 0; s < NB; ++s) dst[s] = wp[(size_t)(qi * NB + s) * 64];
+                };
+                {
+                    v16i acc[NPW];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const v4i bv = *(const v4i*)(bl + MID + mt * 32 + 8 * g + 4 * lh);
 #pragma unroll
                         for (int j = 0; j < NPW; ++j)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[j][r] = bv[r >> 2][r & 3];
+                            for (int e = 0; e < 4; ++e) acc[j][4 * g + e] = bv[e];
                     }
-                    int bpx[NPW];                               // patch entry of tap (0, 0) of this lane's output pixel
+                    unsigned bpb[NPW];                          // LDS offset of tap (0, 0) of this lane's output pixel
 #pragma unroll
                     for (int j = 0; j < NPW; ++j) {
-                        const int pix = p12_pt[j] * 32 + l31, oc = pix < npx ? pix : npx - 1;   // padding lanes read a valid pixel, result unused
+                        const int pix = p12_pix[j], oc = pix < npx ? pix : npx - 1;   // padding lanes read a valid pixel, result unused
                         const int orow = oc / W, ocol = oc - orow * W;
-                        bpx[j] = orow * PW + ocol;
+                        bpb[j] = (unsigned)((orow * PW + ocol) * MS + lh * 16);
                     }
-                    const v4i* const wp = (const v4i*)B.w2 + (size_t)mt * NK2 * 64 + lane;
-                    const int rotb = (int)((unsigned)rot % (unsigned)NBAT2);
-                    auto kof = [&](int bi) { int q = bi + rotb; if (q >= NBAT2) q -= NBAT2; return q * NB; };   // first K step of batch bi
-                    v4i wbuf[NBUF][NB];
-                    auto load_batch = [&](v4i (&dst)[NB], int bi) {
-                        const int k0 = kof(bi);
+                    auto rd = [&](v4i (&xf)[NPW], auto gc) {
+                        constexpr int G = decltype(gc)::value, TAP = G / CM, CI = G % CM;
+                        if constexpr (ROT) {
+                            const int tp = tap_of(TAP);
+                            const int tr = tp / 3, ts = tp - tr * 3;
+                            const unsigned eo = (unsigned)((tr * PW + ts) * MS + CI * 32);
 #pragma unroll
-                        for (int s = 0; s < NB; ++s) dst[s] = wp[(size_t)(k0 + s) * 64];
-                    };
-                    static_for<NBUF - 1>([&](auto bc) { constexpr int Bi = decltype(bc)::value; load_batch(wbuf[Bi], Bi); });
-                    static_for<NBAT2>([&](auto bc) {
-                        constexpr int Bi = decltype(bc)::value;
-                        if constexpr (Bi + NBUF - 1 < NBAT2) load_batch(wbuf[(Bi + NBUF - 1) % NBUF], Bi + NBUF - 1);
-                        int k0 = kof(Bi);
-                        asm volatile("" : "+s"(k0));
-                        const int tap = k0 / CM, c0 = k0 - tap * CM;
-                        const int tr = tap / 3, ts = tap - tr * 3;
-                        const int eoff = tr * PW + ts;
+                            for (int j = 0; j < NPW; ++j) xf[j] = *(const v4i*)(patch + bpb[j] + eo);
+                        } else {
 #pragma unroll
-                        for (int j = 0; j < NPW; ++j) {
-                            const int ent = bpx[j] + eoff;
-                            const unsigned ebase = (unsigned)(ent * MID);
-                            const unsigned esw = (unsigned)((lh ^ SM::f(ent)) << 4);
-#pragma unroll
-                            for (int s = 0; s < NB; ++s) {
-                                const v4i xf = *(const v4i*)(patch + ebase + ((unsigned)((c0 + s) << 5) ^ esw));
-                                acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Bi % NBUF][s], xf, acc[j], 0, 0, 0);
-                            }
+                            for (int j = 0; j < NPW; ++j) xf[j] = *(const v4i*)(patch + bpb[j] + ((TAP / 3) * PW + TAP % 3) * MS + CI * 32);
                         }
+                    };
+                    v4i xfa[NPW], xfb[NPW];
+                    rd(xfa, std::integral_constant<int, 0>{});
+                    static_for<NK2>([&](auto gc) {
+                        constexpr int G = decltype(gc)::value, Bi = G / NB, S = G % NB;
+                        if constexpr (S == 0 && Bi + NBUF - 1 < NBAT2) w2_load(B, wbuf[(Bi + NBUF - 1) % NBUF], Bi + NBUF - 1);
+                        v4i (&cur)[NPW] = (G & 1) ? xfb : xfa;
+                        v4i (&nxt)[NPW] = (G & 1) ? xfa : xfb;
+                        if constexpr (G + 1 < NK2) rd(nxt, std::integral_constant<int, G + 1>{});
+                        pin(cur);
+#pragma unroll
+                        for (int j = 0; j < NPW; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Bi % NBUF][S], cur[j], acc[j], 0, 0, 0);
                     });
+                    if constexpr (WSTAT) wst_load();
+                    else static_for<NBUF - 1>([&](auto bc) { constexpr int Qi = decltype(bc)::value; w3_load(wbuf[Qi], Qi); });
                     const int floor0 = B.relu_b ? 0 : INT32_MIN;
 #pragma unroll
                     for (int j = 0; j < NPW; ++j) {
-                        v16i y;
+                        if constexpr (!FAST) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) y[r] = max(acc[j][r], floor0);
-                        *(v4i*)(mid2 + SM::off(p12_pt[j] * 32 + l31, mt * 2 + lh)) = quant_tile16(y, B.n2, B.lo2, B.hi2, B.xor2);
+                            for (int r = 0; r < 16; ++r) acc[j][r] = max(acc[j][r], floor0);
+                        }
+                        *(v4i*)(mid2 + p12m[j] + mt * 32) = quant_tile16<FAST>(acc[j], B.n2, B.lo2, B.hi2, B.xor2);
                     }
                 }
                 F8_CT(3);
@@ -341,120 +420,113 @@ chain_kernel(const ChainArgs a) {
                 {
                     const bool last = b + 1 == a.nblk;
                     // format of the int8 copy in LDS: the next block's body.0 input, or the first int8 form of the stage output
-                    const int nq = last ? a.q[0].n : a.blk[last ? b : b + 1].nq, loq = last ? a.q[0].lo : a.blk[last ? b : b + 1].loq;
-                    const int hiq = last ? a.q[0].hi : a.blk[last ? b : b + 1].hiq;
-                    const unsigned xorq = last ? a.q[0].bias_xor : a.blk[last ? b : b + 1].xorq;
+                    const ChainBlk& BN = a.blk[last ? b : b + 1];
+                    const int nq = last ? a.q[0].n : BN.nq, loq = last ? a.q[0].lo : BN.loq, hiq = last ? a.q[0].hi : BN.hiq;
+                    const unsigned xorq = last ? a.q[0].bias_xor : BN.xorq;
                     const int floor1 = B.relu1 ? 0 : -2147483647;   // the join's clamp_(min=-(2^31-1)) and the ReLU floor are one max
-                    constexpr int NBAT4 = KK / NB;
-                    constexpr int NQ = CTW * NBAT4;             // batches of this wave's weight stream (its channel tiles are consecutive)
-                    const v4i* const wp = (const v4i*)B.w4 + (size_t)(wave * CTW) * KK * 64 + lane;
-                    const int rotk = rot & (KK - 1);
-                    v4i wbuf[NBUF][NB];
-                    auto load_batch = [&](v4i (&dst)[NB], int qi) {            // qi = tile i * NBAT4 + batch
-                        const int i = qi / NBAT4, bi = qi - i * NBAT4;
-#pragma unroll
-                        for (int s = 0; s < NB; ++s) dst[s] = wp[(size_t)(i * KK + ((bi * NB + s + rotk) & (KK - 1))) * 64];
-                    };
-                    static_for<(NBUF - 1 < NQ ? NBUF - 1 : NQ)>([&](auto bc) { constexpr int Qi = decltype(bc)::value; load_batch(wbuf[Qi], Qi); });
-                    v16i acc[2];
-                    // one pixel pair of channel tile I is complete: join, clamp, new stream, its int8 copy
-                    auto finish = [&](auto ic, auto ppc, const v16i (&acs)[2]) {
-                        constexpr int I = decltype(ic)::value, pp = decltype(ppc)::value;
+                    // channel tile I of pixel tile PT is complete in `acc`: join, clamp, new stream, its int8 copy
+                    auto finish = [&](auto ptc, auto ic, const v16i& acc) {
+                        constexpr int PT = decltype(ptc)::value, I = decltype(ic)::value;
                         const int ct = wave * CTW + I;
+                        const int pix = PT * 32 + l31;
+                        v16i& rr = res[PT][I];
 #pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) {
-                            const int pt = pp * 2 + jj;
-                            if (pt >= NPT) continue;
-                            const int pix = pt * 32 + l31;
+                        for (int r = 0; r < 16; ++r) {
+                            // identity: (body.4 << acc_shl) + (stream << res_shl); opening block: (shortcut << acc_shl) + (body.4 << res_shl)
+                            const unsigned v = DSB ? (unsigned)rr[r] : (unsigned)acc[r], o = DSB ? (unsigned)acc[r] : (unsigned)rr[r];
+                            if constexpr (FAST && !DSB) rr[r] = max((int)((v << B.acc_shl) + o), 0);
+                            else rr[r] = max((int)((v << B.acc_shl) + (o << B.res_shl)), floor1);
+                        }
+                        if (!last || a.q[0].ptr) *(v4i*)(x8 + xlane + PT * 32 * XS + ct * 32) = quant_tile16<FAST>(rr, nq, loq, hiq, xorq);
+                        if (last && pix < npx) {
+                            const int m = m_tile + pix;
+                            if (a.out32) {
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                unsigned v = (unsigned)acc[jj][r], o;
-                                if constexpr (DSB) { o = v; v = (unsigned)acs[jj][r]; }   // the shortcut conv hosts the join (planner's convention)
-                                else o = (unsigned)res[pt][I][r];
-                                res[pt][I][r] = max((int)((v << B.acc_shl) + (o << B.res_shl)), floor1);
+                                for (int g = 0; g < 4; ++g) {
+                                    const v4i o = {rr[4 * g], rr[4 * g + 1], rr[4 * g + 2], rr[4 * g + 3]};
+                                    *(v4i*)(a.out32 + i32t_index(m, ct * 32 + 8 * g + 4 * lh, C)) = o;
+                                }
                             }
-                            if (!last || a.q[0].ptr) *(v4i*)(x8 + SX::off(pix, ct * 2 + lh)) = quant_tile16(res[pt][I], nq, loq, hiq, xorq);
-                            if (last && pix < npx) {
-                                const int m = m_tile + pix;
-                                if (a.out32) {
+                            if (a.q[1].ptr)
+                                *(v4i*)(a.q[1].ptr + (size_t)m * C + ct * 32 + 16 * lh) = quant_tile16<false>(rr, a.q[1].n, a.q[1].lo, a.q[1].hi, a.q[1].bias_xor);
+                        }
+                    };
+                    auto bias_init = [&](v16i& acc, int ct) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const v4i bv = *(const v4i*)(bl + 2 * MID + ct * 32 + 8 * g + 4 * lh);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[4 * g + e] = bv[e];
+                        }
+                    };
+                    if constexpr (WSTAT) {
+                        // one pixel tile at a time; the wave's weights (CTW x KT fragments) stay in registers; B fragments one step ahead
+                        constexpr int NST = NPT * CTW * KT;
+                        auto rd = [&](v4i& xf, auto gc) {
+                            constexpr int G = decltype(gc)::value, PT = G / (CTW * KT), KI = G % KT;
+                            if constexpr (KI >= K0) xf = *(const v4i*)(mid2 + mlane + PT * 32 * MS + (KI - K0) * 32);
+                            else xf = *(const v4i*)(xin + ilane + PT * 32 * IS + KI * 32);
+                        };
+                        v4i xfa, xfb;
+                        v16i acc;
+                        rd(xfa, std::integral_constant<int, 0>{});
+                        static_for<NST>([&](auto gc) {
+                            constexpr int G = decltype(gc)::value, PT = G / (CTW * KT), I = (G / KT) % CTW, KI = G % KT;
+                            const int ct = wave * CTW + I;
+                            if constexpr (KI == 0) {
+                                bias_init(acc, ct);
+                                if constexpr (DSB) {    // the shortcut product accumulates straight into the stream registers (they are born here)
 #pragma unroll
                                     for (int g = 0; g < 4; ++g) {
-                                        const v4i o = {res[pt][I][4 * g], res[pt][I][4 * g + 1], res[pt][I][4 * g + 2], res[pt][I][4 * g + 3]};
-                                        *(v4i*)(a.out32 + i32t_index(m, ct * 32 + 8 * g + 4 * lh, C)) = o;
+                                        const v4i bs = *(const v4i*)(bias_lds + kChainMaxBlocks * BIAS_INTS + ct * 32 + 8 * g + 4 * lh);
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) res[PT][I][4 * g + e] = bs[e];
                                     }
                                 }
-                                if (a.q[1].ptr)
-                                    *(v4i*)(a.q[1].ptr + (size_t)m * C + ct * 32 + 16 * lh) = quant_tile16(res[pt][I], a.q[1].n, a.q[1].lo, a.q[1].hi, a.q[1].bias_xor);
                             }
-                        }
-                    };
-                    static_for<NQ>([&](auto qc) {
-                        constexpr int Qi = decltype(qc)::value;
-                        constexpr int I = Qi / NBAT4, Bi = Qi % NBAT4;
-                        const int ct = wave * CTW + I;
-                        if constexpr (Qi + NBUF - 1 < NQ) load_batch(wbuf[(Qi + NBUF - 1) % NBUF], Qi + NBUF - 1);
-                        v4i bv[4];
-                        if constexpr (Bi == 0) {
-#pragma unroll
-                            for (int g = 0; g < 4; ++g) bv[g] = *(const v4i*)(B.b4 + ct * 32 + 8 * g + 4 * lh);
-                        }
-                        if constexpr (NBAT4 > 1) {
-                            // NPT <= 2: one pixel pair, its accumulators live across the tile's batches
-                            if constexpr (Bi == 0) {
-#pragma unroll
-                                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                                    for (int r = 0; r < 16; ++r) acc[jj][r] = bv[r >> 2][r & 3];
-                            }
-                            int kb = Bi * NB + rotk;
-                            asm volatile("" : "+s"(kb));
-#pragma unroll
-                            for (int s = 0; s < NB; ++s) {
-                                const int k = (kb + s) & (KK - 1);
-#pragma unroll
-                                for (int jj = 0; jj < 2; ++jj) {
-                                    if (jj >= NPT) continue;
-                                    const v4i xf = *(const v4i*)(mid2 + SM::off(jj * 32 + l31, k * 2 + lh));
-                                    acc[jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Qi % NBUF][s], xf, acc[jj], 0, 0, 0);
+                            v4i& cur = (G & 1) ? xfb : xfa;
+                            v4i& nxt = (G & 1) ? xfa : xfb;
+                            if constexpr (G + 1 < NST) rd(nxt, std::integral_constant<int, G + 1>{});
+                            asm volatile("" : "+v"(cur));
+                            if constexpr (KI >= K0) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wst[I * KT + KI], cur, acc, 0, 0, 0);
+                            else res[PT][I] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wst[I * KT + KI], cur, res[PT][I], 0, 0, 0);
+                            if constexpr (KI == KT - 1) {
+                                if constexpr (PT == NPT - 1 && I == CTW - 1) {   // the block's last weight use: the next block's body.0 starts to travel
+                                    if (!last) w1_prime(BN, std::integral_constant<int, NK1>{});
                                 }
+                                finish(std::integral_constant<int, PT>{}, std::integral_constant<int, I>{}, acc);
                             }
-                            if constexpr (Bi == NBAT4 - 1) { const v16i none[2] = {}; finish(std::integral_constant<int, I>{}, std::integral_constant<int, 0>{}, none); }
-                        } else {
-                            // the tile's whole K range is this batch: every pixel pair in turn
-                            v4i wsf[DSB ? NB : 1]; v4i bs[4];
-                            if constexpr (DSB) {
-                                const v4i* const wps = (const v4i*)B.wsc + (size_t)ct * (CIN0 / 32) * 64 + lane;
-#pragma unroll
-                                for (int s = 0; s < NB; ++s) wsf[s] = wps[(size_t)s * 64];
-#pragma unroll
-                                for (int g = 0; g < 4; ++g) bs[g] = *(const v4i*)(B.bsc + ct * 32 + 8 * g + 4 * lh);
+                        });
+                    } else {
+                        // both pixel tiles at once, this wave's CTW channel tiles in turn, weights streamed (read once)
+                        static_assert(WSTAT || !DSB, "streamed P3 has no opening-block form");
+                        constexpr int NQ = CTW * KK / NB, NST = CTW * KK;
+                        auto rd = [&](v4i (&xf)[2], auto gc) {
+                            constexpr int KI = decltype(gc)::value % KK;
+                            xf[0] = *(const v4i*)(mid2 + mlane + KI * 32);
+                            xf[1] = *(const v4i*)(mid2 + mlane + 32 * MS + KI * 32);
+                        };
+                        v4i xfa[2], xfb[2];
+                        v16i acc[2];
+                        rd(xfa, std::integral_constant<int, 0>{});
+                        static_for<NST>([&](auto gc) {
+                            constexpr int G = decltype(gc)::value, I = G / KK, KI = G % KK, Qi = G / NB, S = G % NB;
+                            const int ct = wave * CTW + I;
+                            if constexpr (S == 0 && Qi + NBUF - 1 < NQ) w3_load(wbuf[(Qi + NBUF - 1) % NBUF], Qi + NBUF - 1);
+                            if constexpr (KI == 0) { bias_init(acc[0], ct); acc[1] = acc[0]; }
+                            v4i (&cur)[2] = (G & 1) ? xfb : xfa;
+                            v4i (&nxt)[2] = (G & 1) ? xfa : xfb;
+                            if constexpr (G + 1 < NST) rd(nxt, std::integral_constant<int, G + 1>{});
+                            pin(cur);
+                            acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Qi % NBUF][S], cur[0], acc[0], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Qi % NBUF][S], cur[1], acc[1], 0, 0, 0);
+                            if constexpr (KI == KK - 1) {
+                                if constexpr (I == CTW - 1) { if (!last) w1_prime(BN, std::integral_constant<int, NK1>{}); }
+                                finish(std::integral_constant<int, 0>{}, std::integral_constant<int, I>{}, acc[0]);
+                                finish(std::integral_constant<int, 1>{}, std::integral_constant<int, I>{}, acc[1]);
                             }
-                            static_for<NPAIR>([&](auto ppc) {
-                                constexpr int pp = decltype(ppc)::value;
-                                v16i acs[2];
-#pragma unroll
-                                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                                    for (int r = 0; r < 16; ++r) { acc[jj][r] = bv[r >> 2][r & 3]; if constexpr (DSB) acs[jj][r] = bs[r >> 2][r & 3]; else acs[jj][r] = 0; }
-#pragma unroll
-                                for (int s = 0; s < NB; ++s) {
-                                    const int k = (s + rotk) & (KK - 1);
-#pragma unroll
-                                    for (int jj = 0; jj < 2; ++jj) {
-                                        const int pt = pp * 2 + jj;
-                                        if (pt >= NPT) continue;
-                                        const v4i xf = *(const v4i*)(mid2 + SM::off(pt * 32 + l31, k * 2 + lh));
-                                        acc[jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Qi % NBUF][s], xf, acc[jj], 0, 0, 0);
-                                        if constexpr (DSB) {
-                                            const v4i xs = *(const v4i*)(xin + SI::off(pt * 32 + l31, s * 2 + lh));
-                                            acs[jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wsf[s], xs, acs[jj], 0, 0, 0);
-                                        }
-                                    }
-                                }
-                                finish(std::integral_constant<int, I>{}, ppc, acs);
-                            });
-                        }
-                    });
+                        });
+                    }
                 }
                 F8_CT(4);
                 __syncthreads();                                // x8 is complete (the next block's P1 reads it); mid2 may be rewritten
@@ -471,7 +543,7 @@ chain_kernel(const ChainArgs a) {
             constexpr int CH = C / 16;
             for (int idx = tid; idx < npx * CH; idx += 512) {
                 const int row = idx / CH, c16 = idx % CH;
-                const v4i v = *(const v4i*)(x8 + SX::off(row, c16));
+                const v4i v = *(const v4i*)(x8 + row * XS + c16 * 16);
                 *(v4i*)(a.q[0].ptr + (size_t)(m_tile + row) * C + c16 * 16) = v;
             }
         }
@@ -495,12 +567,12 @@ bool chain_supported(int C, int MID, int H, int W, int cin0) {
 }
 int chain_tiles_per_img(int H, int W) { (void)W; return (H + 3) / 4; }
 
-template <int C, int MID, int W, int H, int R, int CIN0, int NB, int NBUF>
+template <int C, int MID, int W, int H, int R, int CIN0, int NB, int NBUF, bool FAST, bool ROT>
 static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t s) {
     using Cfg = ChainCfg<C, MID, W, H, R, CIN0>;
     static unsigned long long attr_done = 0; int attr_dev = -1;
     if (!dyn_lds_opted_in(&attr_done, &attr_dev)) {
-        hipError_t e = hipFuncSetAttribute((const void*)chain_kernel<C, MID, W, H, R, CIN0, NB, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)chain_kernel<C, MID, W, H, R, CIN0, NB, NBUF, FAST, ROT>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
         if (attr_dev >= 0) attr_done |= 1ull << attr_dev;
     }
@@ -514,7 +586,7 @@ static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t s) {
     ChainArgs b = a;
     const bool tracing = (count++ == want);
     if (tracing) { if (!tbuf) (void)hipMalloc((void**)&tbuf, (size_t)1 << 16); (void)hipMemsetAsync(tbuf, 0, (size_t)grid * 64, s); b.trace = tbuf; }
-    hipLaunchKernelGGL((chain_kernel<C, MID, W, H, R, CIN0, NB, NBUF>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, b);
+    hipLaunchKernelGGL((chain_kernel<C, MID, W, H, R, CIN0, NB, NBUF, FAST, ROT>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, b);
     if (tracing) {
         (void)hipStreamSynchronize(s);
         unsigned long long hb[256 * 8];
@@ -526,17 +598,35 @@ static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t s) {
     }
     return hipGetLastError();
 #else
-    hipLaunchKernelGGL((chain_kernel<C, MID, W, H, R, CIN0, NB, NBUF>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((chain_kernel<C, MID, W, H, R, CIN0, NB, NBUF, FAST, ROT>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, a);
     return hipGetLastError();
 #endif
 }
 
+// FAST instance: see chain_kernel
+bool chain_fast(const ChainArgs& a) {
+    for (int k = 0; k < a.nblk; ++k) {
+        const ChainBlk& B = a.blk[k];
+        if (!(B.relu_a && B.relu_b && B.relu1 && B.n1 > 0 && B.n2 > 0 && B.nq > 0 && B.lo1 == 0 && B.lo2 == 0 && B.loq == 0)) return false;
+        if (B.wsc == nullptr && B.res_shl != 0) return false;
+    }
+    if (a.q[0].ptr && !(a.q[0].n > 0 && a.q[0].lo == 0)) return false;
+    return true;
+}
+
 hipError_t launch_chain(const ChainArgs& a, int C, int MID, int H, int W, int cin0, hipStream_t s) {
     if (a.nblk < 1 || a.nblk > kChainMaxBlocks) return hipErrorInvalidValue;
-    if (C == 256 && MID == 64 && H == 56 && W == 56 && cin0 == 64) return launch_chain_t<256, 64, 56, 56, 4, 64, 2, 4>(a, s);
-    if (C == 256 && MID == 64 && H == 56 && W == 56 && cin0 == 256) return launch_chain_t<256, 64, 56, 56, 4, 256, 2, 4>(a, s);
-    if (C == 512 && MID == 128 && H == 28 && W == 28 && cin0 == 512) return launch_chain_t<512, 128, 28, 28, 4, 512, 4, 3>(a, s);
-    if (C == 1024 && MID == 256 && H == 14 && W == 14 && cin0 == 1024) return launch_chain_t<1024, 256, 14, 14, 4, 1024, 4, 3>(a, s);
+    const bool fast = chain_fast(a);
+#define F8_CHAIN_INST(...) (fast ? launch_chain_t<__VA_ARGS__, true, F8_CHAIN_ROT>(a, s) : launch_chain_t<__VA_ARGS__, false, F8_CHAIN_ROT>(a, s))
+#define F8_CHAIN_ROT false
+    if (C == 256 && MID == 64 && H == 56 && W == 56 && cin0 == 64) return F8_CHAIN_INST(256, 64, 56, 56, 4, 64, 2, 3);
+    if (C == 256 && MID == 64 && H == 56 && W == 56 && cin0 == 256) return F8_CHAIN_INST(256, 64, 56, 56, 4, 256, 2, 3);
+    if (C == 512 && MID == 128 && H == 28 && W == 28 && cin0 == 512) return F8_CHAIN_INST(512, 128, 28, 28, 4, 512, 2, 3);
+#undef F8_CHAIN_ROT
+#define F8_CHAIN_ROT true
+    if (C == 1024 && MID == 256 && H == 14 && W == 14 && cin0 == 1024) return F8_CHAIN_INST(1024, 256, 14, 14, 4, 1024, 2, 4);
+#undef F8_CHAIN_ROT
+#undef F8_CHAIN_INST
     return hipErrorInvalidValue;
 }
 

@@ -83,7 +83,8 @@ def test_run_without_gpu_fails_loudly():
                                                        ('mobilenet_v2', 39, 0, 0)])
 def test_plan_fuses_requant_relu_residual(arch, launches, fused, dual):
     spec = topology.get(arch)
-    net = build_net(spec, synth.make_params(spec, 1), max_batch=8, hw=224)
+    # one launch per block (the stage-chain launches of f8_chain.hip have their own plan test below)
+    net = build_net(spec, synth.make_params(spec, 1), max_batch=8, hw=224, options={'fuse_chain': 0})
     plan = net.describe()
     assert net.num_launches == launches, plan
     # ResNets: the head (stem conv + max-pool) is one launch, whatever forms (int32 / int8) the pool output needs
@@ -111,9 +112,32 @@ def test_plan_fuses_requant_relu_residual(arch, launches, fused, dual):
     assert net.weight_bytes > 0 and net.arena_bytes > 0
 
 
+def test_plan_runs_each_stage_as_one_chain_launch():
+    """Default ResNet-50 plan: the bottleneck blocks of stages 0-2 that follow one another at one resolution are ONE launch per
+    stage (f8_chain.hip): the int32 residual stream exists in HBM only where a chain starts with an identity block (its input),
+    never between blocks, and a chain writes int8 forms only when nothing downstream needs 32 bits."""
+    spec = topology.get('resnet50', normalize=True)
+    for mb in (128, 4):
+        net = build_net(spec, synth.make_params(spec, 1234, topology.R50_NVIDIA_FRACLENS), max_batch=mb, hw=224)
+        lines = net.describe().splitlines()
+        chains = [l for l in lines if 'stage_chain_x' in l]
+        assert [l.split()[1].split(':')[0] for l in chains] == ['stage_chain_x3_ds', 'stage_chain_x3', 'stage_chain_x5'], net.describe()
+        assert all('i32=0' in l and 'i8=1' in l for l in chains)          # the next stage's opening block reads int8 only
+        assert not any('fused_bottleneck' in l for l in lines)
+        assert 'stage_0_layer_0.body.0..stage_0_layer_2.body.4' in chains[0] and 'stage_2_layer_1.body.0..stage_2_layer_5.body.4' in chains[2]
+        # the stage-1 opener (stride 2) stays its own launch and hands the chain the int32 stream only (no int8 copy)
+        opener = [l for l in lines if 'fused_opener_s2' in l]
+        assert len(opener) == 1 and 'i32=1 i8=0' in opener[0]
+    assert net.num_launches <= 21
+    # ResNet-18 / MobileNets have no bottleneck blocks: nothing changes for them
+    for arch in ('resnet18', 'mobilenet_v2'):
+        sp = topology.get(arch)
+        assert 'stage_chain' not in build_net(sp, synth.make_params(sp, 1), max_batch=8, hw=224).describe()
+
+
 def test_plan_keeps_int32_only_where_semantics_need_it():
     spec = topology.get('resnet50', normalize=True)
-    net = build_net(spec, synth.make_params(spec, 1234, topology.R50_NVIDIA_FRACLENS), max_batch=128, hw=224)
+    net = build_net(spec, synth.make_params(spec, 1234, topology.R50_NVIDIA_FRACLENS), max_batch=128, hw=224, options={'fuse_chain': 0})
     lines = net.describe().splitlines()
     body0 = [l for l in lines if '.body.0 ' in l or '.body.2 ' in l]
     assert body0 and all('i32=0' in l for l in body0)          # inside a block: int8 only
@@ -131,7 +155,7 @@ def test_plan_keeps_int32_only_where_semantics_need_it():
     assert sum('fused_opener_s2' in l for l in lines) == 1
     # the five 14x14 identity blocks are fused too at this batch (64 images per launch = 128 workgroups), not at bs 32
     assert sum('fused_bottleneck' in l and 'stage_2' in l for l in lines) == 5
-    small = build_net(spec, synth.make_params(spec, 1234, topology.R50_NVIDIA_FRACLENS), max_batch=32, hw=224)
+    small = build_net(spec, synth.make_params(spec, 1234, topology.R50_NVIDIA_FRACLENS), max_batch=32, hw=224, options={'fuse_chain': 0})
     assert small.num_launches == 36 and not any('fused_bottleneck' in l and 'stage_2' in l for l in small.describe().splitlines())
     # the 1x1 convs around the stage-2 / stage-3 opening blocks and the closing 1x1 of the 7x7 blocks run weight-stationary (f8_wstat.hip)
     # when a launch gives every workgroup at least two pixel tiles; smaller launches keep the tile-per-workgroup kernels

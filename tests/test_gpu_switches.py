@@ -43,7 +43,7 @@ print('OK')
 
 SWITCHES = ['F8_FUSE_BLOCKS=0', 'F8_FUSE_STAGES=0', 'F8_FUSE_STAGES=7', 'F8_FUSE_DS=0', 'F8_FUSE_DUAL=0', 'F8_FUSE_STEM=0',
             'F8_PATCH3X3=0', 'F8_SPLIT=1', 'F8_SPLIT=3', 'F8_SPLIT_STREAMS=0', 'F8_GRAPH=1', 'F8_BK128=1', 'F8_DEEP_NK=1',
-            'F8_DUAL_WIDE=0', 'F8_CHUNK=0', 'F8_CHUNK=1', 'F8_CHUNK28=0', 'F8_CHUNK28=2', 'F8_BN=32', 'F8_BM=64', 'F8_RES_BN=128', 'F8_DW_DOT4=0', 'F8_STAGGER=0', 'F8_STEM_WPC=1']
+            'F8_DUAL_WIDE=0', 'F8_CHUNK=0', 'F8_CHUNK=1', 'F8_CHUNK28=0', 'F8_CHUNK28=2', 'F8_BN=32', 'F8_BM=64', 'F8_RES_BN=128', 'F8_DW_DOT4=0', 'F8_STAGGER=0', 'F8_STEM_WPC=1', 'F8_FUSE_CHAIN=0']
 
 
 @pytest.mark.parametrize('switch', SWITCHES)
@@ -88,8 +88,60 @@ def test_chunked_execution_is_bit_exact_with_ragged_chunks():
     """F8_CHUNK / F8_CHUNK28 = 2, F8_CHUNK14 = 8 on a 9-image batch at 224x224: the 56x56 / 28x28 fused blocks run as 2+2+2+2+1
     images, the 14x14 ones as 8+1 (pipelining mode 2 and the profiled pass)."""
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''), F8_CHUNK='2', F8_CHUNK28='2',
-               F8_CHUNK14='8', F8_FUSE_STAGES='7')
+               F8_CHUNK14='8', F8_FUSE_STAGES='7', F8_FUSE_CHAIN='0')
     r = subprocess.run([sys.executable, '-c', CHUNK_CHILD], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().startswith('OK'), f'{r.stdout[-500:]}\n{r.stderr[-1500:]}'
     _, split_launches, alt_launches, planned = r.stdout.split()
     assert int(alt_launches) > int(planned)          # chunks add launches where one stream runs the whole batch
+
+
+# Round-2 / round-3 planning and scheduling keys at a size where their kernels ARE planned (224x224, 8 images): per-handle options,
+# one process.  Each entry: options of one handle; results must equal the oracle bit for bit and the plan must change as stated.
+OPTION_SETS = [
+    ({}, 'stage_chain_x5'),
+    ({'fuse_chain': 0}, 'fused_bottleneck_R'),
+    ({'fuse_chain': 0, 'fuse_stages': 7}, 'fused_bottleneck_R7'),
+    ({'fuse_chain': 0, 'fuse_ds': 0}, '_dual:'),
+    ({'wstat': 0}, None), ({'wstat_min_tiles': 0}, 'wstat'), ({'s2wreg': 0}, None), ({'wreg': 0}, None), ({'fuse_p12': 0}, None),
+    ({'fuse_opener': 0}, None), ({'opener_stg': 0}, 'fused_opener_s2'), ({'fuse_fc': 0}, 'output'), ({'fuse_input': 0}, None),
+    ({'wstat_fast': 0}, None), ({'split': 3, 'pipeline_depth': 3}, None),
+]
+
+
+def test_options_keep_results_bit_exact_at_full_resolution():
+    import numpy as np
+    import torch
+    from f8net_amd import synth, topology
+    from f8net_amd.net import build_net
+    from oracle import oracle
+    oracle.build()
+    spec = topology.get('resnet50', normalize=True)
+    params = synth.make_params(spec, seed=99, fraclens=topology.R50_NVIDIA_FRACLENS)
+    x, x_fl = synth.make_input(spec, params, 8, 224, seed=6)
+    want = oracle.net_forward(spec, params, x, x_fl)
+    xd = torch.from_numpy(x).cuda()
+    plans = set()
+    for opts, marker in OPTION_SETS:
+        net = build_net(spec, params, max_batch=8, hw=224, options=dict(opts, whole_batch_launches=1))
+        plan = net.describe()
+        plans.add(plan)
+        if marker:
+            assert marker in plan, (opts, plan)
+        got = net.run(xd).cpu().numpy()
+        net.check()
+        assert np.array_equal(got, want), opts
+        net.set_pipelined(2)
+        outs = [torch.empty((8, 1000), dtype=torch.float32, device='cuda') for _ in range(3)]
+        for rep in range(5):
+            net.run(xd, out=outs[rep % 3])
+        torch.cuda.synchronize()
+        net.check()
+        assert all(np.array_equal(o.cpu().numpy(), want) for o in outs), opts
+    assert len(plans) >= 9          # the keys really change the plan at this size
+    mb = topology.get('mobilenet_v2')
+    pm = synth.make_params(mb, seed=98, fraclens=topology.MBV2_LOG_FRACLENS)
+    xm, xm_fl = synth.make_input(mb, pm, 8, 224, seed=6)
+    wantm = oracle.net_forward(mb, pm, xm, xm_fl)
+    for fi in (0, 1, 2):
+        net = build_net(mb, pm, max_batch=8, hw=224, options={'fuse_ir': fi})
+        assert np.array_equal(net.run(torch.from_numpy(xm).cuda()).cpu().numpy(), wantm), fi

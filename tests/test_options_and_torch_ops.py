@@ -45,9 +45,10 @@ def test_planning_options_change_the_plan(monkeypatch):
         return net.finalize(128).describe()
 
     base = plan()
-    assert 'fused_opener_s2' in base and 'fused_bottleneck_ds' in base
+    assert 'fused_opener_s2' in base and 'stage_chain_x3_ds' in base and 'fused_bottleneck' not in base
+    assert 'fused_bottleneck_ds' in plan(fuse_chain=0) and 'stage_chain' not in plan(fuse_chain=0)
     assert 'fused_opener_s2' not in plan(fuse_opener=0)
-    assert 'fused_bottleneck' not in plan(fuse_blocks=0)
+    assert 'fused_bottleneck' not in plan(fuse_blocks=0) and 'stage_chain' not in plan(fuse_blocks=0)
     assert '_dual:' not in plan(fuse_blocks=0, fuse_dual=0)
     # the environment only seeds the defaults of NEW handles
     monkeypatch.setenv('F8_FUSE_OPENER', '0')
