@@ -133,7 +133,7 @@ chain_kernel(const ChainArgs a) {
     unsigned* const flags = a.sync + 16;
     const unsigned long long t_limit = (unsigned long long)a.timeout_ticks;
 #ifdef F8_TRACE
-    unsigned long long tt[8] = {}; unsigned long long t_prev = __builtin_readcyclecounter();
+    unsigned long long tt[16] = {}; unsigned long long t_prev = __builtin_readcyclecounter();
 #define F8_CT(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); tt[i] += now_ - t_prev; t_prev = now_; } while (0)
 #else
 #define F8_CT(i)
@@ -158,26 +158,30 @@ chain_kernel(const ChainArgs a) {
     // ---- weight streams (fragment order: [tile][K32 step][lane][16 B]).  step -> K index: identity, or rotated in coarse groups.
     auto k1_of = [&](int g, int nk) { return ROT ? (((g >> 3) + opaque(rot)) & (nk / 8 - 1)) * 8 + (g & 7) : g; };       // body.0: groups of 8 steps
     auto tap_of = [&](int t) { if (!ROT) return t; int q = t + (int)((unsigned)opaque(rot) % 9u); return q >= 9 ? q - 9 : q; };   // body.2: whole taps
-    auto w1_load = [&](const ChainBlk& B, auto nkc, v4i (&dst)[NB], int bi) {
+    // A-operand loads: uniform base (+ a SCALAR step offset, kept scalar by `opaque`: as a constant it gets folded into a per-step
+    // per-lane offset register that is hoisted out of the block loop and spilled) + ONE per-lane offset register per stream
+    auto ldw = [](const int8_t* base, int soff, unsigned voff) { return *(const v4i*)(base + opaque(soff) + voff); };
+    const unsigned wl16 = (unsigned)(lane * 16);
+    const unsigned w2off = (unsigned)(mt * NK2 * 1024) + wl16, w3off = (unsigned)(wave * CTW * KK * 1024) + wl16;
+    auto w1_load = [&](const int8_t* w0, auto nkc, v4i (&dst)[NB], int bi) {
         constexpr int NK = decltype(nkc)::value;
-        const v4i* const wp = (const v4i*)B.w0 + (size_t)mt * NK * 64 + lane;
+        const unsigned w1off = (unsigned)(mt * NK * 1024) + wl16;
         const int k0 = k1_of(bi * NB, NK);
 #pragma unroll
-        for (int s = 0; s < NB; ++s) dst[s] = wp[(size_t)(k0 + s) * 64];
+        for (int s = 0; s < NB; ++s) dst[s] = ldw(w0, (k0 + s) * 1024, w1off);
     };
-    auto w1_prime = [&](const ChainBlk& B, auto nkc) {
+    auto w1_prime = [&](const int8_t* w0, auto nkc) {
         constexpr int NBAT = decltype(nkc)::value / NB;
-        static_for<(NBUF - 1 < NBAT ? NBUF - 1 : NBAT)>([&](auto bc) { constexpr int Bi = decltype(bc)::value; w1_load(B, nkc, wbuf[Bi], Bi); });
+        static_for<(NBUF - 1 < NBAT ? NBUF - 1 : NBAT)>([&](auto bc) { constexpr int Bi = decltype(bc)::value; w1_load(w0, nkc, wbuf[Bi], Bi); });
     };
     constexpr int NBAT2 = NK2 / NB, BPTAP = CM / NB;            // body.2: batches, batches per tap
-    auto w2_load = [&](const ChainBlk& B, v4i (&dst)[NB], int bi) {
-        const v4i* const wp = (const v4i*)B.w2 + (size_t)mt * NK2 * 64 + lane;
+    auto w2_load = [&](const int8_t* w2, v4i (&dst)[NB], int bi) {
         const int k0 = tap_of(bi / BPTAP) * CM + (bi % BPTAP) * NB;
 #pragma unroll
-        for (int s = 0; s < NB; ++s) dst[s] = wp[(size_t)(k0 + s) * 64];
+        for (int s = 0; s < NB; ++s) dst[s] = ldw(w2, (k0 + s) * 1024, w2off);
     };
-    auto w2_prime = [&](const ChainBlk& B) {
-        static_for<NBUF - 1>([&](auto bc) { constexpr int Bi = decltype(bc)::value; w2_load(B, wbuf[Bi], Bi); });
+    auto w2_prime = [&](const int8_t* w2) {
+        static_for<NBUF - 1>([&](auto bc) { constexpr int Bi = decltype(bc)::value; w2_load(w2, wbuf[Bi], Bi); });
     };
     // the MFMAs of a step must not be scheduled above the LDS reads of the NEXT step that are issued just before them
     auto pin = [](auto& xf) {
@@ -193,27 +197,30 @@ chain_kernel(const ChainArgs a) {
         // =====================================================================================
         if constexpr (!DS0) {
             const ChainBlk& B0 = a.blk[0];
+            const __amdgpu_buffer_rsrc_t rxr = __builtin_amdgcn_make_buffer_rsrc((void*)a.xr, 0, (unsigned)(((a.N * H * W + 31) & ~31) * C * 4), 0x00020000);
 #pragma unroll
             for (int pt = 0; pt < NPT; ++pt) {
                 const int pix = pt * 32 + l31;
                 const int mc = m_tile + (pix < npx ? pix : 0);
+                // I32T: block (m >> 5, c >> 5) of 4 KB, inside it [g][lh * 32 + m & 31][4 ch] ints (f8_device.h)
+                const unsigned vo = (unsigned)((mc >> 5) * (C * 128) + lh * 512 + (mc & 31) * 16);
 #pragma unroll
                 for (int i = 0; i < CTW; ++i) {
                     const int ct = wave * CTW + i;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const v4i v = *(const v4i*)(a.xr + i32t_index(mc, ct * 32 + 8 * g + 4 * lh, C));
+                        const v4i v = __builtin_amdgcn_raw_buffer_load_b128(rxr, vo + g * 1024, ct * 4096, 0);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) res[pt][i][4 * g + e] = v[e];
                     }
                 }
             }
-            w1_prime(B0, std::integral_constant<int, NK1>{});
+            w1_prime(B0.w0, std::integral_constant<int, NK1>{});
 #pragma unroll
             for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
                 for (int i = 0; i < CTW; ++i)
-                    *(v4i*)(x8 + xlane + pt * 32 * XS + (wave * CTW + i) * 32) = quant_tile16<FAST>(res[pt][i], B0.nq, B0.loq, B0.hiq, B0.xorq);
+                    *(v4i*)(x8 + xlane + pt * 32 * XS + (wave * CTW + i) * 32) = quant_tile16<FAST>(res[pt][i], B0.nq, FAST ? 0 : B0.loq, FAST ? 255 : B0.hiq, FAST ? 0x80808080u : B0.xorq);
         } else {
             constexpr int CH = CIN0 / 16;                       // 16-byte chunks per pixel
             for (int idx = tid; idx < NPT * 32 * CH; idx += 512) {
@@ -222,7 +229,7 @@ chain_kernel(const ChainArgs a) {
                 if (row < npx) v = *(const v4i*)(a.x8in + (size_t)(m_tile + row) * CIN0 + c16 * 16);
                 *(v4i*)(xin + row * IS + c16 * 16) = v;
             }
-            w1_prime(a.blk[0], std::integral_constant<int, KS>{});
+            w1_prime(a.blk[0].w0, std::integral_constant<int, KS>{});
         }
         __syncthreads();
         F8_CT(0);
@@ -235,11 +242,24 @@ chain_kernel(const ChainArgs a) {
                 constexpr bool DSB = decltype(dsc)::value;      // this block is the stage-opening block (first block of a DS0 chain)
                 constexpr int NK1B = DSB ? KS : NK1;
                 constexpr bool ROT1 = ROT && !DSB;
+                // the block's scalars, read once (FAST: formats are unsigned with a right shift, ReLUs present, the stream unshifted)
+                const bool last = b + 1 == a.nblk;
+                const ChainBlk& BN = a.blk[last ? b : b + 1];
+                const int8_t* const pw0 = B.w0; const int8_t* const pw2 = B.w2; const int8_t* const pw4 = B.w4; const int8_t* const pwsc = B.wsc;
+                const int8_t* const pw0n = BN.w0;
+                const int n1 = B.n1, n2 = B.n2, acc_shl = B.acc_shl, res_shl = B.res_shl;
+                const int lo1 = FAST ? 0 : B.lo1, hi1 = FAST ? 255 : B.hi1, lo2 = FAST ? 0 : B.lo2, hi2 = FAST ? 255 : B.hi2;
+                const unsigned xor1 = FAST ? 0x80808080u : B.xor1, xor2 = FAST ? 0x80808080u : B.xor2;
+                const int relu_a = FAST ? 1 : B.relu_a, relu_b = FAST ? 1 : B.relu_b, relu1 = FAST ? 1 : B.relu1;
+                // format of the int8 copy of the block's output in LDS: the next block's body.0 input, or the first int8 form of the stage output
+                const int nq = last ? a.q[0].n : BN.nq;
+                const int loq = FAST ? 0 : (last ? a.q[0].lo : BN.loq), hiq = FAST ? 255 : (last ? a.q[0].hi : BN.hiq);
+                const unsigned xorq = FAST ? 0x80808080u : (last ? a.q[0].bias_xor : BN.xorq);
 
                 // ============================ P1: mid1 = requant(relu(W0 . x8 + b0)) -> patch interior   (its first weight batches are in flight)
                 {
                     {   // the whole patch <- biased zero: border columns, rows outside the image; everything else is overwritten below
-                        const v4i zv = {(int)B.xor1, (int)B.xor1, (int)B.xor1, (int)B.xor1};
+                        const v4i zv = {(int)xor1, (int)xor1, (int)xor1, (int)xor1};
                         for (int o = tid * 16; o < Cfg::PATCH_BYTES; o += 512 * 16) *(v4i*)(patch + o) = zv;
                     }
                     v16i acc[NPW];
@@ -251,6 +271,7 @@ chain_kernel(const ChainArgs a) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) acc[j][4 * g + e] = bv[e];
                     }
+                    F8_CT(6);
                     constexpr int NBAT1 = NK1B / NB;
                     const char* const xsrc = DSB ? xin : x8;
                     auto rd = [&](v4i (&xf)[NPW], auto gc) {
@@ -268,7 +289,7 @@ chain_kernel(const ChainArgs a) {
                     rd(xfa, std::integral_constant<int, 0>{});
                     static_for<NK1B>([&](auto gc) {
                         constexpr int G = decltype(gc)::value, Bi = G / NB, S = G % NB;
-                        if constexpr (S == 0 && Bi + NBUF - 1 < NBAT1) w1_load(B, std::integral_constant<int, NK1B>{}, wbuf[(Bi + NBUF - 1) % NBUF], Bi + NBUF - 1);
+                        if constexpr (S == 0 && Bi + NBUF - 1 < NBAT1) w1_load(pw0, std::integral_constant<int, NK1B>{}, wbuf[(Bi + NBUF - 1) % NBUF], Bi + NBUF - 1);
                         v4i (&cur)[NPW] = (G & 1) ? xfb : xfa;
                         v4i (&nxt)[NPW] = (G & 1) ? xfa : xfb;
                         if constexpr (G + 1 < NK1B) rd(nxt, std::integral_constant<int, G + 1>{});
@@ -276,9 +297,11 @@ chain_kernel(const ChainArgs a) {
 #pragma unroll
                         for (int j = 0; j < NPW; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Bi % NBUF][S], cur[j], acc[j], 0, 0, 0);
                     });
-                    w2_prime(B);                                // body.2's first weight batches travel during the epilogue and the halo exchange
+                    F8_CT(7);
+                    w2_prime(pw2);                                // body.2's first weight batches travel during the epilogue and the halo exchange
                     __syncthreads();                            // the zero fill is complete
-                    const int floor0 = B.relu_a ? 0 : INT32_MIN;
+                    F8_CT(8);
+                    const int floor0 = relu_a ? 0 : INT32_MIN;
 #pragma unroll
                     for (int j = 0; j < NPW; ++j) {
                         const int pix = p12_pix[j];
@@ -288,12 +311,13 @@ chain_kernel(const ChainArgs a) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) acc[j][r] = max(acc[j][r], floor0);
                         }
-                        const v4i o = quant_tile16<FAST>(acc[j], B.n1, B.lo1, B.hi1, B.xor1);   // FAST: lo1 == 0 is the ReLU
+                        const v4i o = quant_tile16<FAST>(acc[j], n1, lo1, hi1, xor1);   // FAST: lo1 == 0 is the ReLU
                         if (pix < npx) *(v4i*)(patch + ent * MS + mt * 32 + lh * 16) = o;
                     }
                 }
                 F8_CT(1);
                 __syncthreads();                                // the patch interior is complete
+                F8_CT(9);
 
                 // ============================ halo rows: publish mine, fetch the neighbours'
                 if constexpr (T > 1) {
@@ -309,8 +333,10 @@ chain_kernel(const ChainArgs a) {
                         __builtin_amdgcn_raw_buffer_store_b128(v, rxc, (unsigned)(((L * 2 + (int)par) * 2 + side) * ROWB + idx * 16), 0, 17);   // sc0 sc1: write-through
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains
+                    F8_CT(10);
                     __syncthreads();
                     if (tid == 0) __hip_atomic_store(flags + L, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    F8_CT(11);
                     // one lane per neighbour polls its flag
                     if ((tid == 0 && has_up) || (tid == 256 && has_dn)) {
                         unsigned* const f = flags + (tid == 0 ? L - 1 : L + 1);
@@ -322,6 +348,7 @@ chain_kernel(const ChainArgs a) {
                         }
                         if (!ok) { misc[1] = 1; __hip_atomic_store(a.err, 0x100u + (unsigned)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                     }
+                    F8_CT(12);
                     __syncthreads();
                     if (misc[1]) return false;                                  // a neighbour never arrived: give up (uniform)
                     if (mine) {
@@ -344,20 +371,17 @@ chain_kernel(const ChainArgs a) {
                         for (int i = 0; i < CTW; ++i) {
                             const int ct = wave * CTW + i;
                             if constexpr (DSB) {
-                                const v4i* const wps = (const v4i*)B.wsc + (size_t)ct * KS * 64 + lane;
 #pragma unroll
-                                for (int k = 0; k < KS; ++k) wst[i * KT + k] = wps[(size_t)k * 64];
+                                for (int k = 0; k < KS; ++k) wst[i * KT + k] = ldw(pwsc, (i * KS + k) * 1024, (unsigned)(wave * CTW * KS * 1024) + wl16);
                             }
-                            const v4i* const wp = (const v4i*)B.w4 + (size_t)ct * KK * 64 + lane;
 #pragma unroll
-                            for (int k = 0; k < KK; ++k) wst[i * KT + K0 + k] = wp[(size_t)k * 64];
+                            for (int k = 0; k < KK; ++k) wst[i * KT + K0 + k] = ldw(pw4, (i * KK + k) * 1024, w3off);
                         }
                     }
                 };
                 auto w3_load = [&](v4i (&dst)[NB], int qi) {      // streamed P3: batch qi of this wave's CTW consecutive channel tiles
-                    const v4i* const wp = (const v4i*)B.w4 + (size_t)(wave * CTW) * KK * 64 + lane;
 #pragma unroll
-                    for (int s = 0; s < NB; ++s) dst[s] = wp[(size_t)(qi * NB + s) * 64];
+                    for (int s = 0; s < NB; ++s) dst[s] = ldw(pw4, (qi * NB + s) * 1024, w3off);
                 };
                 {
                     v16i acc[NPW];
@@ -393,7 +417,7 @@ chain_kernel(const ChainArgs a) {
                     rd(xfa, std::integral_constant<int, 0>{});
                     static_for<NK2>([&](auto gc) {
                         constexpr int G = decltype(gc)::value, Bi = G / NB, S = G % NB;
-                        if constexpr (S == 0 && Bi + NBUF - 1 < NBAT2) w2_load(B, wbuf[(Bi + NBUF - 1) % NBUF], Bi + NBUF - 1);
+                        if constexpr (S == 0 && Bi + NBUF - 1 < NBAT2) w2_load(pw2, wbuf[(Bi + NBUF - 1) % NBUF], Bi + NBUF - 1);
                         v4i (&cur)[NPW] = (G & 1) ? xfb : xfa;
                         v4i (&nxt)[NPW] = (G & 1) ? xfa : xfb;
                         if constexpr (G + 1 < NK2) rd(nxt, std::integral_constant<int, G + 1>{});
@@ -403,14 +427,14 @@ chain_kernel(const ChainArgs a) {
                     });
                     if constexpr (WSTAT) wst_load();
                     else static_for<NBUF - 1>([&](auto bc) { constexpr int Qi = decltype(bc)::value; w3_load(wbuf[Qi], Qi); });
-                    const int floor0 = B.relu_b ? 0 : INT32_MIN;
+                    const int floor0 = relu_b ? 0 : INT32_MIN;
 #pragma unroll
                     for (int j = 0; j < NPW; ++j) {
                         if constexpr (!FAST) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) acc[j][r] = max(acc[j][r], floor0);
                         }
-                        *(v4i*)(mid2 + p12m[j] + mt * 32) = quant_tile16<FAST>(acc[j], B.n2, B.lo2, B.hi2, B.xor2);
+                        *(v4i*)(mid2 + p12m[j] + mt * 32) = quant_tile16<FAST>(acc[j], n2, lo2, hi2, xor2);
                     }
                 }
                 F8_CT(3);
@@ -418,12 +442,7 @@ chain_kernel(const ChainArgs a) {
 
                 // ============================ P3: stream' = clamp((W4 . mid2 + b4) << sa + (stream << sr)) [ReLU]; x8' = requant(stream')
                 {
-                    const bool last = b + 1 == a.nblk;
-                    // format of the int8 copy in LDS: the next block's body.0 input, or the first int8 form of the stage output
-                    const ChainBlk& BN = a.blk[last ? b : b + 1];
-                    const int nq = last ? a.q[0].n : BN.nq, loq = last ? a.q[0].lo : BN.loq, hiq = last ? a.q[0].hi : BN.hiq;
-                    const unsigned xorq = last ? a.q[0].bias_xor : BN.xorq;
-                    const int floor1 = B.relu1 ? 0 : -2147483647;   // the join's clamp_(min=-(2^31-1)) and the ReLU floor are one max
+                    const int floor1 = relu1 ? 0 : -2147483647;   // the join's clamp_(min=-(2^31-1)) and the ReLU floor are one max
                     // channel tile I of pixel tile PT is complete in `acc`: join, clamp, new stream, its int8 copy
                     auto finish = [&](auto ptc, auto ic, const v16i& acc) {
                         constexpr int PT = decltype(ptc)::value, I = decltype(ic)::value;
@@ -434,21 +453,28 @@ chain_kernel(const ChainArgs a) {
                         for (int r = 0; r < 16; ++r) {
                             // identity: (body.4 << acc_shl) + (stream << res_shl); opening block: (shortcut << acc_shl) + (body.4 << res_shl)
                             const unsigned v = DSB ? (unsigned)rr[r] : (unsigned)acc[r], o = DSB ? (unsigned)acc[r] : (unsigned)rr[r];
-                            if constexpr (FAST && !DSB) rr[r] = max((int)((v << B.acc_shl) + o), 0);
-                            else rr[r] = max((int)((v << B.acc_shl) + (o << B.res_shl)), floor1);
+                            if constexpr (FAST && !DSB) rr[r] = max((int)((v << acc_shl) + o), 0);
+                            else rr[r] = max((int)((v << acc_shl) + (o << res_shl)), floor1);
                         }
                         if (!last || a.q[0].ptr) *(v4i*)(x8 + xlane + PT * 32 * XS + ct * 32) = quant_tile16<FAST>(rr, nq, loq, hiq, xorq);
                         if (last && pix < npx) {
-                            const int m = m_tile + pix;
+                            // (opaque: these addresses are NOT precomputed per pixel tile outside the block loop — 28 registers that spilled)
+                            const int m = opaque(m_tile) + pix;
+                            const unsigned tot = (unsigned)(((a.N * H * W + 31) & ~31) * C);
                             if (a.out32) {
+                                const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)a.out32, 0, tot * 4u, 0x00020000);
+                                const unsigned vo = (unsigned)((m >> 5) * (C * 128) + lh * 512 + (m & 31) * 16);
 #pragma unroll
                                 for (int g = 0; g < 4; ++g) {
                                     const v4i o = {rr[4 * g], rr[4 * g + 1], rr[4 * g + 2], rr[4 * g + 3]};
-                                    *(v4i*)(a.out32 + i32t_index(m, ct * 32 + 8 * g + 4 * lh, C)) = o;
+                                    __builtin_amdgcn_raw_buffer_store_b128(o, ro, vo + g * 1024, ct * 4096, 0);
                                 }
                             }
-                            if (a.q[1].ptr)
-                                *(v4i*)(a.q[1].ptr + (size_t)m * C + ct * 32 + 16 * lh) = quant_tile16<false>(rr, a.q[1].n, a.q[1].lo, a.q[1].hi, a.q[1].bias_xor);
+                            if (a.q[1].ptr) {
+                                const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)a.q[1].ptr, 0, tot, 0x00020000);
+                                __builtin_amdgcn_raw_buffer_store_b128(quant_tile16<false>(rr, a.q[1].n, a.q[1].lo, a.q[1].hi, a.q[1].bias_xor), rq,
+                                                                       (unsigned)(m * C + 16 * lh), ct * 32, 0);
+                            }
                         }
                     };
                     auto bias_init = [&](v16i& acc, int ct) {
@@ -492,7 +518,7 @@ chain_kernel(const ChainArgs a) {
                             else res[PT][I] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wst[I * KT + KI], cur, res[PT][I], 0, 0, 0);
                             if constexpr (KI == KT - 1) {
                                 if constexpr (PT == NPT - 1 && I == CTW - 1) {   // the block's last weight use: the next block's body.0 starts to travel
-                                    if (!last) w1_prime(BN, std::integral_constant<int, NK1>{});
+                                    if (!last) w1_prime(pw0n, std::integral_constant<int, NK1>{});
                                 }
                                 finish(std::integral_constant<int, PT>{}, std::integral_constant<int, I>{}, acc);
                             }
@@ -521,7 +547,7 @@ chain_kernel(const ChainArgs a) {
                             acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Qi % NBUF][S], cur[0], acc[0], 0, 0, 0);
                             acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Qi % NBUF][S], cur[1], acc[1], 0, 0, 0);
                             if constexpr (KI == KK - 1) {
-                                if constexpr (I == CTW - 1) { if (!last) w1_prime(BN, std::integral_constant<int, NK1>{}); }
+                                if constexpr (I == CTW - 1) { if (!last) w1_prime(pw0n, std::integral_constant<int, NK1>{}); }
                                 finish(std::integral_constant<int, 0>{}, std::integral_constant<int, I>{}, acc[0]);
                                 finish(std::integral_constant<int, 1>{}, std::integral_constant<int, I>{}, acc[1]);
                             }
@@ -551,9 +577,9 @@ chain_kernel(const ChainArgs a) {
         F8_CT(5);
     }
 #ifdef F8_TRACE
-    if (a.trace && tid == 0) {
-        unsigned long long* tp = (unsigned long long*)a.trace + (size_t)blockIdx.x * 8;
-        for (int i = 0; i < 6; ++i) tp[i] = tt[i];
+    if (a.trace && lane == 0) {
+        unsigned long long* tp = (unsigned long long*)a.trace + ((size_t)blockIdx.x * 8 + wave) * 16;
+        for (int i = 0; i < 16; ++i) tp[i] = tt[i];
     }
 #endif
 }
@@ -585,16 +611,25 @@ static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t s) {
     static const int want = [] { const char* e = getenv("F8_TRACE_CHAIN"); return e ? atoi(e) : -1; }();
     ChainArgs b = a;
     const bool tracing = (count++ == want);
-    if (tracing) { if (!tbuf) (void)hipMalloc((void**)&tbuf, (size_t)1 << 16); (void)hipMemsetAsync(tbuf, 0, (size_t)grid * 64, s); b.trace = tbuf; }
+    if (tracing) { if (!tbuf) (void)hipMalloc((void**)&tbuf, (size_t)1 << 19); (void)hipMemsetAsync(tbuf, 0, (size_t)grid * 1024, s); b.trace = tbuf; }
     hipLaunchKernelGGL((chain_kernel<C, MID, W, H, R, CIN0, NB, NBUF, FAST, ROT>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, b);
     if (tracing) {
         (void)hipStreamSynchronize(s);
-        unsigned long long hb[256 * 8];
-        (void)hipMemcpy(hb, tbuf, (size_t)grid * 64, hipMemcpyDeviceToHost);
-        double ph[6] = {}; int n = 0;
-        for (int i = 0; i < grid; ++i) { unsigned long long* p = hb + (size_t)i * 8; ++n; for (int k = 0; k < 6; ++k) ph[k] += (double)p[k]; }
+        static unsigned long long hb[256 * 8 * 16];
+        (void)hipMemcpy(hb, tbuf, (size_t)grid * 1024, hipMemcpyDeviceToHost);
+        double ph[16] = {}, pw[8][16] = {}; int n = 0;
+        for (int i = 0; i < grid; ++i) {
+            ++n;
+            for (int w = 0; w < 8; ++w) { unsigned long long* p = hb + ((size_t)i * 8 + w) * 16; for (int k = 0; k < 16; ++k) { pw[w][k] += (double)p[k]; if (w == 0) ph[k] += (double)p[k]; } }
+        }
+
         fprintf(stderr, "[trace chain<%d,%d,%d>] grid %d, %d blocks, N %d: avg cycles per WG (whole launch): load %.0f | P1 %.0f | halo %.0f | P2 %.0f | P3 %.0f | out %.0f\n",
-                C, MID, W, grid, a.nblk, a.N, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n);
+                C, MID, W, grid, a.nblk, a.N, ph[0] / n, (ph[1] + ph[6] + ph[7] + ph[8]) / n, (ph[2] + ph[9] + ph[10] + ph[11] + ph[12]) / n, ph[3] / n, ph[4] / n, ph[5] / n);
+        fprintf(stderr, "    P1: P3-end barrier + zero fill + bias %.0f | K loop %.0f | barrier %.0f | epilogue %.0f    halo: barrier %.0f | publish + drain %.0f | barrier + flag %.0f | poll %.0f | fetch + barrier %.0f\n",
+                ph[6] / n, ph[7] / n, ph[8] / n, ph[1] / n, ph[9] / n, ph[10] / n, ph[11] / n, ph[12] / n, ph[2] / n);
+        for (int w = 0; w < 8; ++w)
+            fprintf(stderr, "    wave %d: P1 wait+zero %.0f K %.0f bar %.0f epi %.0f | halo %.0f | P2 %.0f | P3 %.0f\n", w, pw[w][6] / n, pw[w][7] / n, pw[w][8] / n, pw[w][1] / n,
+                    (pw[w][2] + pw[w][9] + pw[w][10] + pw[w][11] + pw[w][12]) / n, pw[w][3] / n, pw[w][4] / n);
     }
     return hipGetLastError();
 #else
