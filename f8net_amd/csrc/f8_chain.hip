@@ -638,6 +638,17 @@ static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t s) {
 #endif
 }
 
+// K steps per register batch, batches per stream (NB, NBUF) of the 56x56 / 28x28 / 14x14 instances (tuning builds override; measured:
+// deeper batches than these spill — a scratch reload in front of a K loop waits for every weight load in flight — and are slower)
+#ifndef F8_CH_S0
+#define F8_CH_S0 2, 3
+#endif
+#ifndef F8_CH_S1
+#define F8_CH_S1 2, 3
+#endif
+#ifndef F8_CH_S2
+#define F8_CH_S2 2, 4
+#endif
 // FAST instance: see chain_kernel
 bool chain_fast(const ChainArgs& a) {
     for (int k = 0; k < a.nblk; ++k) {
@@ -654,12 +665,16 @@ hipError_t launch_chain(const ChainArgs& a, int C, int MID, int H, int W, int ci
     const bool fast = chain_fast(a);
 #define F8_CHAIN_INST(...) (fast ? launch_chain_t<__VA_ARGS__, true, F8_CHAIN_ROT>(a, s) : launch_chain_t<__VA_ARGS__, false, F8_CHAIN_ROT>(a, s))
 #define F8_CHAIN_ROT false
-    if (C == 256 && MID == 64 && H == 56 && W == 56 && cin0 == 64) return F8_CHAIN_INST(256, 64, 56, 56, 4, 64, 2, 3);
-    if (C == 256 && MID == 64 && H == 56 && W == 56 && cin0 == 256) return F8_CHAIN_INST(256, 64, 56, 56, 4, 256, 2, 3);
-    if (C == 512 && MID == 128 && H == 28 && W == 28 && cin0 == 512) return F8_CHAIN_INST(512, 128, 28, 28, 4, 512, 2, 3);
+    if (C == 256 && MID == 64 && H == 56 && W == 56 && cin0 == 64) return F8_CHAIN_INST(256, 64, 56, 56, 4, 64, F8_CH_S0);
+    if (C == 256 && MID == 64 && H == 56 && W == 56 && cin0 == 256) return F8_CHAIN_INST(256, 64, 56, 56, 4, 256, F8_CH_S0);
+    if (C == 512 && MID == 128 && H == 28 && W == 28 && cin0 == 512) return F8_CHAIN_INST(512, 128, 28, 28, 4, 512, F8_CH_S1);
 #undef F8_CHAIN_ROT
+#ifdef F8_CH_ROT
 #define F8_CHAIN_ROT true
-    if (C == 1024 && MID == 256 && H == 14 && W == 14 && cin0 == 1024) return F8_CHAIN_INST(1024, 256, 14, 14, 4, 1024, 2, 4);
+#else
+#define F8_CHAIN_ROT false      // measured on the 14x14 instance: 466 k cycles per workgroup without the K rotation, 512 k with it
+#endif
+    if (C == 1024 && MID == 256 && H == 14 && W == 14 && cin0 == 1024) return F8_CHAIN_INST(1024, 256, 14, 14, 4, 1024, F8_CH_S2);
 #undef F8_CHAIN_ROT
 #undef F8_CHAIN_INST
     return hipErrorInvalidValue;
