@@ -45,6 +45,7 @@ struct Options {
     int graph = 0;               // hipGraph capture / replay of a run
     int stagger = -1, stagger_pipelined = 2;
     int check_device = 1;        // f8_net_run fails if the current device is not the one the handle was uploaded to
+    int check_input_range = 1;   // int32 inputs that are NARROWED to the head's 8-bit format (no requant) are range-checked on the device; f8_net_check reports
 };
 void options_from_env(Options* o);                       // f8_net.cpp
 int* option_slot(Options* o, const char* key);            // nullptr: unknown key
@@ -133,6 +134,7 @@ struct InArgs {                            // network input: int32 NCHW -> NHWC 
     const uint8_t* xu8; int32_t u8_nhwc;              // uint8 images (f8_net_run_u8): NCHW planes or NHWC pixels, through `lut`
     int16_t lut[3 * 256];                             // lut[c * 256 + byte] = the head-format integer of that pixel value
     uint32_t xor8;                         // 0x80808080 when the int8 consumer format is unsigned (biased storage)
+    uint32_t* err; int32_t chk_lo, chk_hi; // err != nullptr: int32 inputs narrowed to 8 bits are checked against [chk_lo, chk_hi] (sticky error word)
     int8_t* out8;  int32_t Cs8;            // NHWC int8 (Cs8-channel rows), or
     int8_t* stem;  int32_t Hp, Wp, pad;    // zero-haloed NHWC4 for the stem conv
     int32_t* out32; int32_t Cs32;
@@ -224,6 +226,7 @@ struct StemPoolArgs {
     const int32_t* xi; const float* xf; const uint8_t* xu8;
     float scale; int32_t qlo, qhi;
     uint32_t xor8;                         // 0x80808080 when the stem's input format is unsigned (stored biased)
+    uint32_t* err; int32_t chk_lo, chk_hi; // raw_kind 0: values outside [chk_lo, chk_hi] set the sticky error word (err != nullptr)
     int16_t lut[3 * 256];
 };
 

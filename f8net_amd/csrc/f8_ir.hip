@@ -351,11 +351,14 @@ bool fused_ir_config(int cinS, int coutS, int H, int W, int stride, int* R, int*
 
 template <int CIN_S, int COUT_S>
 static hipError_t launch_ir_t(const IRArgs& a, int lds, hipStream_t s) {
-    static int attr_lds = 0;
-    if (lds > attr_lds) {                                   // dynamic LDS above 64 KB must be opted into (per kernel; keep the maximum)
+    // dynamic LDS above 64 KB must be opted into per kernel AND per device (a process may drive several GPUs): keep the maximum per device
+    static int attr_lds[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    if (dev < 0 || lds > attr_lds[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)fused_ir_kernel<CIN_S, COUT_S>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
-        attr_lds = lds;
+        if (dev >= 0) attr_lds[dev] = lds;
     }
     const int grid = a.G > 1 ? (a.N + a.G - 1) / a.G : a.N * a.tiles_per_img;
     hipLaunchKernelGGL((fused_ir_kernel<CIN_S, COUT_S>), dim3(grid), dim3(256), lds, s, a);

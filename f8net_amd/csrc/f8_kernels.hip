@@ -805,6 +805,7 @@ __global__ void __launch_bounds__(256) input_stem4_kernel(const InArgs a) {
 
 __global__ void __launch_bounds__(256) input_kernel(const InArgs a) {
     const size_t total = (size_t)a.N * a.H * a.W;
+    unsigned bad = 0;                                     // an int32 value outside the 8-bit format it is narrowed to
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
         const int w = (int)(idx % a.W);
@@ -816,7 +817,10 @@ __global__ void __launch_bounds__(256) input_kernel(const InArgs a) {
         // fp32 images are quantised on the fly (f8_net_run_f32): the int32 tensor of the reference never exists
         auto ld = [&](int c) -> int {
             if (a.xu8) return a.lut[(c < 3 ? c : 2) * 256 + (a.u8_nhwc ? a.xu8[((((size_t)n * a.H + h) * a.W) + w) * a.C + c] : a.xu8[pix0 + c * plane])];
-            return a.xf ? quant_in(a.xf[pix0 + c * plane], a.scale, a.qlo, a.qhi) : a.x[pix0 + c * plane];
+            if (a.xf) return quant_in(a.xf[pix0 + c * plane], a.scale, a.qlo, a.qhi);
+            const int v = a.x[pix0 + c * plane];
+            bad |= (unsigned)(v - a.chk_lo) > (unsigned)(a.chk_hi - a.chk_lo) ? 1u : 0u;
+            return v;
         };
         if (a.stem) {
             int v[4] = {0, 0, 0, 0};
@@ -834,6 +838,7 @@ __global__ void __launch_bounds__(256) input_kernel(const InArgs a) {
             for (int c = 0; c < a.Cs32; ++c) a.out32[i32t_index(m, c, a.Cs32)] = c < a.C ? ld(c) : 0;
         }
     }
+    if (a.err && bad) atomicOr(a.err, 1u);                // (err is only passed when an 8-bit form is written by plain narrowing)
 }
 
 // Network output: NHWC int32 (row stride Cs) -> NCHW int32 / float32.

@@ -131,6 +131,7 @@ struct f8_net {
     size_t stem_zero_off = 0, stem_zero_bytes = 0; int stem_zero_val = 0;   // halo = biased zero
     // device
     char* d_arena = nullptr; char* d_w = nullptr; bool uploaded = false;
+    uint32_t* d_err = nullptr;         // sticky device error words: [0] an int32 input value outside the head's 8-bit format
     char* d_chain = nullptr; size_t chain_stride = 0;   // per arena copy: sync words + halo exchange rows of the stage-chain launches
     hipEvent_t* events = nullptr; int n_events = 0;
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t aux_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -242,6 +243,7 @@ static const OptKey kOptKeys[] = {
     {"stagger", "F8_STAGGER", &Options::stagger, -1, 1 << 20, false},
     {"stagger_pipelined", "F8_STAGGER_PIPELINED", &Options::stagger_pipelined, 0, 1 << 20, false},
     {"check_device", "F8_CHECK_DEVICE", &Options::check_device, 0, 1, false},
+    {"check_input_range", "F8_CHECK_INPUT_RANGE", &Options::check_input_range, 0, 1, false},
     {"pipeline_depth", "F8_PIPELINE_DEPTH", &Options::pipeline_depth, 2, 4, false},
     {"whole_batch_launches", "F8_WHOLE_BATCH_LAUNCHES", &Options::whole_batch_launches, 0, 1, true},
 };
@@ -354,6 +356,15 @@ int f8_net_check(f8_net* net) {
     if (!net || !net->uploaded) return fail(F8_ERR_STATE, "f8_net_check: not uploaded");
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return hip_fail(e, "f8_net_check: hipDeviceSynchronize");
+    if (net->d_err) {
+        uint32_t w = 0;
+        if ((e = hipMemcpy(&w, net->d_err, 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "f8_net_check: hipMemcpy");
+        if (w) {
+            (void)hipMemset(net->d_err, 0, 4);
+            return fail(F8_ERR_INVALID, "f8_net_check: an int32 network input held values outside the head's 8-bit format (the reference would feed them to the "
+                                        "head conv as they are; this library narrows the input to 8 bits): outputs of that run are invalid.  Option check_input_range = 0 disables the check");
+        }
+    }
     for (int p = 0; net->d_chain && p < net->n_copies; ++p) {
         uint32_t w = 0;
         if ((e = hipMemcpy(&w, net->d_chain + (size_t)p * net->chain_stride + 2048, 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "f8_net_check: hipMemcpy");
@@ -375,6 +386,7 @@ void f8_net_destroy(f8_net* net) {
     if (net->d_arena) (void)hipFree(net->d_arena);
     if (net->d_w) (void)hipFree(net->d_w);
     if (net->d_chain) (void)hipFree(net->d_chain);
+    if (net->d_err) (void)hipFree(net->d_err);
     if (net->events) {
         for (int i = 0; i < net->n_events; ++i) (void)hipEventDestroy(net->events[i]);
         delete[] net->events;
@@ -925,7 +937,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         // the classifier (a linear / 1x1 conv on a 1x1 map that nothing else reads) writes the caller's buffer itself: no int32 form
         const Tensor& ps = T[p.a >= 0 ? p.a : net->out_t];
         O.dense_out = opt.fuse_fc && (p.kind == N_LINEAR || p.kind == N_CONV) && p.cd.kernel == 1 && p.cd.stride == 1 && p.cd.pad == 0 && p.cd.groups == 1 &&
-                      O.H == 1 && O.W == 1 && ps.H == 1 && ps.W == 1 && O.consumers.empty() && p.fused_add < 0 && p.absorbed_by < 0 &&
+                      O.H == 1 && O.W == 1 && ps.H == 1 && ps.W == 1 && O.consumers.empty() && p.fused_add < 0 && p.absorbed_by < 0 && !p.cd.relu &&
                       fc_dense_supported(ps.Cs, round_up(p.cd.cout, 32));
         if (!O.dense_out) add_form(O, FORM_I32, 0, 0);
     }
@@ -1596,6 +1608,8 @@ int f8_net_upload(f8_net* net) {
     if ((e = hipMalloc((void**)&net->d_w, std::max<size_t>(net->wblob.size(), 256))) != hipSuccess) return hip_fail(e, "hipMalloc(weights)");
     if (!net->wblob.empty() && (e = hipMemcpy(net->d_w, net->wblob.data(), net->wblob.size(), hipMemcpyHostToDevice)) != hipSuccess)
         return hip_fail(e, "hipMemcpy(weights)");
+    if ((e = hipMalloc((void**)&net->d_err, 256)) != hipSuccess) return hip_fail(e, "hipMalloc(error words)");
+    if ((e = hipMemset(net->d_err, 0, 256)) != hipSuccess) return hip_fail(e, "hipMemset(error words)");
     for (const Step& st : net->steps)
         if (st.kind == S_CHAIN && !net->d_chain) {
             net->chain_stride = round_up_z(4096 + kChainXchgBytes, 4096);
@@ -1638,6 +1652,10 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
                 if (F.kind == FORM_I8) { if (F.n == 0) { a.out8 = (int8_t*)fp(F); a.Cs8 = o.Cs; if (!F.sgn) a.xor8 = 0x80808080u; } }
                 else if (F.kind == FORM_I32) { a.out32 = (int32_t*)fp(F); a.Cs32 = o.Cs; }
                 else { a.stem = (int8_t*)fp(F); a.Hp = F.Hp; a.Wp = F.Wp; a.pad = F.pad; if (!F.sgn) a.xor8 = 0x80808080u; }
+                // an int32 input that is narrowed to 8 bits without a requant (head format): values outside the format would wrap silently
+                if (net->opt.check_input_range && !net->in_f32 && !net->in_u8 && ((F.kind == FORM_I8 && F.n == 0) || F.kind == FORM_STEM)) {
+                    a.err = net->d_err; a.chk_lo = F.sgn ? -127 : 0; a.chk_hi = F.sgn ? 127 : 255;
+                }
             }
             e = launch_input(a, s);
             break;
@@ -1706,7 +1724,10 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
                 a.rC = sT.C; a.rH = sT.H; a.rW = sT.W; a.xor8 = sF.sgn ? 0u : 0x80808080u;
                 if (net->in_u8) { a.raw_kind = 2; a.xu8 = net->in_u8 + (size_t)n0 * img; memcpy(a.lut, net->in_lut, sizeof a.lut); }
                 else if (net->in_f32) { a.raw_kind = 1; a.xf = net->in_f32 + (size_t)n0 * img; a.scale = net->in_scale; a.qlo = net->in_lo; a.qhi = net->in_hi; }
-                else { a.raw_kind = 0; a.xi = input + (size_t)n0 * img; }
+                else {
+                    a.raw_kind = 0; a.xi = input + (size_t)n0 * img;
+                    if (net->opt.check_input_range) { a.err = net->d_err; a.chk_lo = sF.sgn ? -127 : 0; a.chk_hi = sF.sgn ? 127 : 255; }
+                }
             }
             fill_out(&a.out32, a.q);
             e = launch_stem_pool(a, s);
@@ -2052,6 +2073,10 @@ static int run_steps(f8_net* net, const int32_t* input, void* output, int n0, in
 }
 
 static int run_common(f8_net* net, const int32_t* input, void* output, int N, void* stream, float* ms, int cap) {
+    // the one-shot event is consumed by THIS call whatever happens next: a run that fails validation must not leave it armed for a
+    // later, unrelated run (by then the caller's event may be gone)
+    hipEvent_t in_ready = nullptr;
+    if (net) { in_ready = net->input_ready; net->input_ready = nullptr; }
     if (!net || !net->finalized) return fail(F8_ERR_STATE, "f8_net_run: not finalized");
     if (N < 1 || N > net->max_batch) return fail(F8_ERR_INVALID, "f8_net_run: N=%d outside [1,%d]", N, net->max_batch);
     if (!input || !output) return fail(F8_ERR_INVALID, "f8_net_run: null pointer");
@@ -2063,10 +2088,9 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
             return fail(F8_ERR_STATE, "f8_net_run: current device %d, but this net lives on device %d (hipSetDevice before the call; one handle per device)", dev, net->device);
     }
     hipStream_t s = (hipStream_t)stream;
-    if (net->input_ready) {            // one-shot: the producer of this run's input (f8_net_set_input_ready); every schedule forks from / runs on `s`
-        (void)hipStreamWaitEvent(s, net->input_ready, 0);
+    if (in_ready) {                    // the producer of this run's input (f8_net_set_input_ready); every schedule forks from / runs on `s`
+        (void)hipStreamWaitEvent(s, in_ready, 0);
     }
-    hipEvent_t in_ready = net->input_ready; net->input_ready = nullptr;
     const int ns = (int)net->steps.size();
     int cut[5];
     int parts = split_batch(net, N, cut);

@@ -99,6 +99,7 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemPoolArgs a) {
         (void*)(KIND == 0 ? (const void*)a.xi : KIND == 1 ? (const void*)a.xf : (const void*)a.xu8), 0,
         (unsigned)((size_t)a.N * a.rC * a.rH * a.rW * (KIND == 2 ? 1 : 4)), 0x00020000);
     int rawv[KIND >= 0 ? 12 : 1];
+    unsigned bad = 0;                                    // KIND 0: an int32 input value outside the head's 8-bit format was seen
     unsigned rawok = 0;                                  // bit j: column j of the slot lies inside the image (and so does the row)
     auto load_raw = [&](int t) {
         if constexpr (KIND >= 0) {
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemPoolArgs a) {
                 for (int j = 0; j < 4; ++j) {
                     const int r = rawv[c * 4 + j];
                     int q;
-                    if constexpr (KIND == 0) q = r;
+                    if constexpr (KIND == 0) { q = r; bad |= (unsigned)(r - a.chk_lo) > (unsigned)(a.chk_hi - a.chk_lo) ? 1u : 0u; }
                     else if constexpr (KIND == 1) q = quant_in_stem(__builtin_bit_cast(float, r), a.scale, a.qlo, a.qhi);
                     else q = (int)a.lut[c * 256 + (r & 0xff)];
                     v[c][j] = ((rawok >> j) & 1u) && c < a.rC ? q : 0;
@@ -235,6 +236,9 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemPoolArgs a) {
         }
         // the next iteration's first barrier separates these ct reads from the next epilogue's ct writes
         if constexpr (KIND >= 0) { if (more) store_raw(cur ^ 1); }   // that slot's tile was consumed before this iteration's first barrier
+    }
+    if constexpr (KIND == 0) {                           // the int32 input is NARROWED to the head's 8-bit format: values outside it would wrap silently
+        if (a.err && bad) atomicOr(a.err, 1u);
     }
 }
 

@@ -94,11 +94,26 @@ class IntModel(nn.Module):
         self.classifier = nn.Sequential(F8Linear(spec.fc_in, spec.num_classes, input_symmetric=spec.fc_signed_in))
         self.int_op_only = True
         self._plans = {}
+        self._ptensors = None
         self._pipelined = 0
 
     # -- performance path ------------------------------------------------------------------
     def _param_version(self):
-        return tuple((t._version, t.data_ptr()) for t in self.state_dict(keep_vars=True).values())
+        # Sum of the in-place version counters over a CACHED list of the parameter / buffer tensors: versions only grow, so any
+        # in-place edit changes the sum.  (Walking state_dict() and hashing 216 (version, pointer) pairs per forward cost 0.32 ms —
+        # a fifth of a ResNet-50 step; this is ~15 us.)  The list is rebuilt after load_state_dict / .to() / replan().
+        ts = self._ptensors
+        if ts is None:
+            ts = self._ptensors = tuple(self.state_dict(keep_vars=True).values())
+        v = 0
+        for t in ts:
+            v += t._version
+        return v
+
+    def _apply(self, fn, *args, **kwargs):
+        self._plans = {}
+        self._ptensors = None
+        return super()._apply(fn, *args, **kwargs)
 
     def plan(self, hw: int, max_batch: int, device=None):
         """The planned net for hw x hw inputs on `device` (a handle is bound to one device).  Re-planned when the batch
@@ -118,8 +133,10 @@ class IntModel(nn.Module):
     def replan(self):
         """Drop every cached plan.  Plans are re-built automatically after `load_state_dict` and after in-place edits that bump
         `Tensor._version` (`weight.copy_(...)`, `weight[...] = v`); edits through `.data` have a private version counter and
-        are invisible to that check (fingerprinting 25 M weights on every forward is not an option on this path): call this."""
+        are invisible to that check (fingerprinting 25 M weights on every forward is not an option on this path): call this
+        (also after replacing a parameter OBJECT, e.g. `conv.weight = nn.Parameter(...)`)."""
         self._plans = {}
+        self._ptensors = None
 
     def set_pipelined(self, mode):
         """Let consecutive forwards overlap inside the library (f8_net_set_pipelined; 2 = two whole batches in flight).
@@ -174,6 +191,7 @@ class IntModel(nn.Module):
     def _load_from_state_dict(self, *a, **k):
         super()._load_from_state_dict(*a, **k)
         self._plans = {}
+        self._ptensors = None
 
     # -- parity path: the reference's control flow over op-level kernels ----------------------
     def forward_op_level(self, x):

@@ -21,6 +21,7 @@ conv2d / linear plan a one-node net per (weight tensor, its in-place version, ge
 dispatcher.
 """
 import collections
+import os
 import ctypes
 import weakref
 
@@ -80,10 +81,27 @@ def _add_align_(res, x, res_fl, x_fl):
 
 
 # ------------------------------------------------------------------------------------------ one-node nets (LRU)
+_DETECT_DATA_EDITS = os.environ.get('F8NET_DETECT_DATA_EDITS', '0') == '1'
+
+
+def set_detect_data_edits(on: bool):
+    """Opt into content fingerprints of the op-level plans' parameters.  In-place edits through the parameter itself
+    (`weight.copy_()`, `weight[...] = v` under no_grad) bump `Tensor._version` and re-plan by themselves; `weight.data[...] = v`
+    has a private version counter and is only seen with this switch on (two reductions and a host sync per parameter tensor and
+    call), or after `invalidate_plans()`.  Off by default: the per-call sync serialised the stream on every op-level forward."""
+    global _DETECT_DATA_EDITS
+    _DETECT_DATA_EDITS = bool(on)
+
+
+def invalidate_plans():
+    """Drop every cached op-level plan (after edits the version counters cannot see, e.g. through `.data`)."""
+    _plans.d.clear()
+
+
 def _fingerprint(t):
-    """(sum, position-weighted sum) of an integer tensor: `weight.data[...] = v` edits do NOT bump `Tensor._version` (`.data`
-    has its own counter), so the op-level plans are also keyed by content.  Two small reductions per parameter tensor and call:
-    this is the parity path (one launch chain per reference op), not the planned whole-net path."""
+    """(sum, position-weighted sum) of an integer tensor; only computed when set_detect_data_edits(True)."""
+    if not _DETECT_DATA_EDITS:
+        return ()
     v = t.detach().reshape(-1).to(torch.int64)
     if v.numel() == 0:
         return (0, 0)

@@ -218,7 +218,10 @@ int f8_net_set_input_ready(f8_net* net, void* event);
 /* Blocks until the device is idle and reports failures that happened INSIDE kernels of earlier runs of this handle: the
  * stage-chain launches (option fuse_chain) exchange halo rows between workgroups and bound every wait (chain_timeout_ms); a
  * workgroup whose neighbour never arrives sets an error word and leaves, and the run's outputs are then invalid.  F8_OK, or
- * F8_ERR_HIP with the code in f8_last_error (the word is cleared).  Never needed for correctness of a healthy run. */
+ * F8_ERR_HIP with the code in f8_last_error (the word is cleared).  It also reports (F8_ERR_INVALID) an int32 network input that held
+ * values outside the head's 8-bit format in a run since the last check: f8_net_run NARROWS such an input to 8 bits where the reference
+ * would feed the full int32 to the head conv (fix_train.py:689 only asserts >= 0), so out-of-format values cannot be honoured; the range
+ * is checked inside the input / stem kernel (option check_input_range, default 1).  Never needed for correctness of a healthy run. */
 int f8_net_check(f8_net* net);
 
 /* Per-handle tuning options.  A new handle takes its defaults from the environment (F8_<KEY IN CAPITALS>; F8_CHUNK for
@@ -233,7 +236,7 @@ int f8_net_check(f8_net* net);
  *               f8_net_set_pipelined(2))
  *   scheduling: chunk56 / chunk28 / chunk14 (images per chunk of the fused blocks; -1 = derived from chunk_budget_mb, 0 = whole
  *               batch), chunk_budget_mb (memory-side cache a chunk's int32 stream may occupy), chunk_ds, chunk_opener,
- *               split_streams, graph, stagger, stagger_pipelined, stem_wpc, check_device, pipeline_depth (2..4 runs in flight),
+ *               split_streams, graph, stagger, stagger_pipelined, stem_wpc, check_device, check_input_range, pipeline_depth (2..4 runs in flight),
  *               chain_timeout_ms (bound of a stage-chain launch's halo waits)
  * F8_ERR_INVALID for an unknown key or a value outside the key's range. */
 int f8_net_set_option(f8_net* net, const char* key, int value);

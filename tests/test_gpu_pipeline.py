@@ -176,3 +176,38 @@ def test_float_checkpoint_to_gpu_logits(dev, tmp_path):
     got = model.forward_f32(torch.from_numpy(u).to(dev), normalize=False)
     x_ref, fl = oracle.quantize_input_u8(u)
     np.testing.assert_array_equal(got.cpu().numpy(), oracle.net_forward(spec, params, x_ref, fl))
+
+
+def test_stream_evaluator_matches_oracle_on_host_fed_batches():
+    """f8net_amd/stream_eval.py: host-resident uint8 NHWC batches (pageable numpy AND page-locked tensors, a ragged last batch) -> copy
+    stream -> f8_net_run_u8 under pipelining mode 2 with the input handed over by event -> top-k on the device.  Logits equal the
+    oracle's on the same pixels (fix_train.py:689-692: x_int = the pixel value at fraclen 8), the top-k rates equal numpy's."""
+    import torch
+    from f8net_amd import stream_eval
+    from f8net_amd.net import build_net
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    oracle.build()
+    spec = topology.get('resnet18', num_classes=16)
+    params = synth.make_params(spec, seed=21)
+    B, hw = 4, 64
+    net = build_net(spec, params, max_batch=B, hw=hw)
+    ev = stream_eval.StreamEvaluator(net, normalize=False, topk=(1, 3))
+    rng = np.random.default_rng(5)
+    sizes = [4, 4, 4, 4, 4, 3]
+    imgs = [rng.integers(0, 256, (n, hw, hw, 3), dtype=np.uint8) for n in sizes]
+    labs = [rng.integers(0, 16, (n,)).astype(np.int64) for n in sizes]
+    feed = [(torch.from_numpy(im).pin_memory() if i % 2 else im, lb) for i, (im, lb) in enumerate(zip(imgs, labs))]
+    r = ev.run(feed, keep_logits=True)
+    net.check()
+    assert r['images'] == sum(sizes) and r['img_per_s'] > 0
+    hit1 = hit3 = 0
+    for im, lb, got in zip(imgs, labs, r['logits']):
+        want = oracle.net_forward(spec, params, np.ascontiguousarray(im.transpose(0, 3, 1, 2)).astype(np.int32), 8)
+        np.testing.assert_array_equal(got, want)
+        order = np.argsort(-want, axis=1, kind='stable')
+        hit1 += int((order[:, 0] == lb).sum())
+        hit3 += int((order[:, :3] == lb[:, None]).any(axis=1).sum())
+    assert abs(r['top1'] - hit1 / sum(sizes)) < 1e-12 and abs(r['top3'] - hit3 / sum(sizes)) < 1e-12
+    r2 = ev.run(feed[:2])                       # a second epoch on the same evaluator
+    assert r2['images'] == 8

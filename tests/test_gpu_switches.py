@@ -139,7 +139,7 @@ def test_options_keep_results_bit_exact_at_full_resolution():
         assert all(np.array_equal(o.cpu().numpy(), want) for o in outs), opts
     assert len(plans) >= 9          # the keys really change the plan at this size
     mb = topology.get('mobilenet_v2')
-    pm = synth.make_params(mb, seed=98, fraclens=topology.MBV2_LOG_FRACLENS)
+    pm = synth.reference_params(mb, seed=98)          # the reference log's learned fraclens
     xm, xm_fl = synth.make_input(mb, pm, 8, 224, seed=6)
     wantm = oracle.net_forward(mb, pm, xm, xm_fl)
     for fi in (0, 1, 2):
