@@ -278,12 +278,12 @@ def main():
         stamp = csrc_sha256()
         notes = []
         traffic = mfma = None
-        tj, why = stamped_json('pmc_traffic.json', stamp)    # HBM bytes per launch from separate rocprofv3 --pmc passes
+        tj, why = stamped_json(f'pmc_traffic_{args.arch}_bs{BS}.json', stamp)    # HBM bytes per launch from separate rocprofv3 --pmc passes
         if tj is not None and tj.get('workload') == f'{args.arch}/bs{BS}':
             traffic = tj.get('kernels', {}).get(dom, {}).get('hbm_bytes_per_launch')
         elif why:
             notes.append(why)
-        mj, why = stamped_json('pmc_mfma.json', stamp)       # INT8-MFMA busy cycles per kernel (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES)
+        mj, why = stamped_json(f'pmc_mfma_{args.arch}_bs{BS}.json', stamp)       # INT8-MFMA busy cycles per kernel (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES)
         if mj is not None and mj.get('workload') == f'{args.arch}/bs{BS}':
             mk = mj.get('kernels', {}).get(dom)
             mfma = {'counter': 'SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 256 CU x 4 SIMD), rocprofv3 --pmc',

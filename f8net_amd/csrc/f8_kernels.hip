@@ -760,6 +760,7 @@ __global__ void __launch_bounds__(256) input_stem4_kernel(const InArgs a) {
     const int C = CT ? CT : a.C;
     const size_t total = (size_t)a.N * a.H * W4;
     const size_t plane = (size_t)a.H * a.W;
+    unsigned bad = 0;                                     // KIND 0: an int32 value outside the 8-bit format it is narrowed to
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int w = (int)(idx % W4) * 4;
         size_t t = idx / W4;
@@ -791,7 +792,7 @@ __global__ void __launch_bounds__(256) input_stem4_kernel(const InArgs a) {
             } else {
                 const v4i x = __builtin_nontemporal_load((const v4i*)(a.x + pix0 + c * plane));
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[c][j] = x[j];
+                for (int j = 0; j < 4; ++j) { v[c][j] = x[j]; bad |= (unsigned)(x[j] - a.chk_lo) > (unsigned)(a.chk_hi - a.chk_lo) ? 1u : 0u; }
             }
         }
         v4i o;
@@ -801,6 +802,7 @@ __global__ void __launch_bounds__(256) input_stem4_kernel(const InArgs a) {
         if ((((size_t)dst) & 15) == 0) *(v4i*)dst = o;                 // the halo may leave rows 4-byte aligned only
         else { ((int*)dst)[0] = o[0]; ((int*)dst)[1] = o[1]; ((int*)dst)[2] = o[2]; ((int*)dst)[3] = o[3]; }
     }
+    if constexpr (KIND == 0) { if (a.err && bad) atomicOr(a.err, 1u); }
 }
 
 __global__ void __launch_bounds__(256) input_kernel(const InArgs a) {

@@ -95,6 +95,7 @@ class IntModel(nn.Module):
         self.int_op_only = True
         self._plans = {}
         self._ptensors = None
+        self._head_fl = None
         self._pipelined = 0
 
     # -- performance path ------------------------------------------------------------------
@@ -110,9 +111,18 @@ class IntModel(nn.Module):
             v += t._version
         return v
 
+    def _head_fraclen(self):
+        # `head.input_fraclen.item()` on a device buffer is a device -> host synchronisation on EVERY forward (it serialised the
+        # pipelined schedule: 94 k vs 109 k img/s); the value is cached per parameter version
+        ver = self._param_version()
+        if self._head_fl is None or self._head_fl[0] != ver:
+            self._head_fl = (ver, int(self.head[0].input_fraclen.item()))
+        return self._head_fl[1]
+
     def _apply(self, fn, *args, **kwargs):
         self._plans = {}
         self._ptensors = None
+        self._head_fl = None
         return super()._apply(fn, *args, **kwargs)
 
     def plan(self, hw: int, max_batch: int, device=None):
@@ -156,7 +166,7 @@ class IntModel(nn.Module):
     def forward(self, x, out=None, input_ready=None):
         if not hasattr(x, 'output_fraclen'):
             raise ValueError('IntModel.forward: input must carry `output_fraclen` (fix_train.py:687,692)')
-        head_fl = int(self.head[0].input_fraclen.item())
+        head_fl = self._head_fraclen()
         if x.output_fraclen != head_fl:
             raise ValueError(f'input output_fraclen {x.output_fraclen} != head.input_fraclen {head_fl}')
         assert x.shape[2] == x.shape[3], 'square inputs'

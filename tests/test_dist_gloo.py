@@ -74,3 +74,78 @@ def test_shard_bounds():
             assert cuts[0][0] == 0 and cuts[-1][1] == n
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in cuts) - min(h - l for l, h in cuts) <= 1
+
+
+def _discipline_worker(rank, world, port, lagged, depth, q):
+    """PipelinedShardedForward under ASYNCHRONOUS collectives whose completion is deliberately late: every all-gather is a real
+    gloo async op wrapped in a handle that (a) marks its buffer pair busy from launch until wait() returns and (b) sleeps before it
+    completes.  The per-rank forward checks, at SUBMISSION time, what f8_net_set_pipelined's contract demands of the caller:
+    the pair it writes is free, and — lagged schedules — so is the pair the NEXT run will write (one call of slack)."""
+    sys.path.insert(0, ROOT)
+    import time
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from f8net_amd import dist as f8dist
+    f8dist.init_from_env(backend='gloo')
+    classes, n_local, steps = 7, 3, 9
+    busy, violations, launched = {}, [], []
+
+    class DelayedWork:
+        def __init__(self, work, key, delay):
+            self.work, self.key, self.delay = work, key, delay
+            busy[key] = True
+
+        def wait(self):
+            time.sleep(self.delay)                      # the collective "is still running" while the caller moves on
+            self.work.wait()
+            busy[self.key] = False
+
+    real = dist.all_gather_into_tensor
+
+    def slow_all_gather(out, inp, group=None, async_op=False):
+        assert async_op
+        launched.append(inp.data_ptr())
+        return DelayedWork(real(out, inp, group=group, async_op=True), inp.data_ptr(), 0.02 * (1 + (len(launched) + rank) % 3))
+
+    f8dist.dist.all_gather_into_tensor = slow_all_gather
+    pf = None
+
+    def local(x, out):
+        k = [t.data_ptr() for t in pf.local].index(out.data_ptr())
+        if busy.get(out.data_ptr()):
+            violations.append(('written while its collective is in flight', pf.i, k))
+        if lagged and busy.get(pf.local[(k + 1) % pf.depth].data_ptr()):
+            violations.append(('next run\'s pair not free one call ahead', pf.i, k))
+        out.copy_(x[:, :classes] * (rank + 1))
+
+    pf = f8dist.PipelinedShardedForward(local, classes, n_local, torch.device('cpu'), lagged=lagged, depth=depth)
+    outs = []
+    for i in range(steps):
+        x = torch.full((n_local, classes), float(i + 1))
+        outs.append((pf(x), i))
+    pf.finish()
+    assert not any(busy.values()) and len(launched) == steps
+    for o, i in outs[-depth:]:                           # earlier pairs have been reused
+        want = torch.cat([torch.full((n_local, classes), float((i + 1) * (r + 1))) for r in range(world)])
+        assert torch.equal(o, want), (i, o)
+    if rank == 0:
+        q.put(violations)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('lagged,depth', [(True, 2), (True, 3), (False, 2)])
+def test_pipelined_buffer_discipline_with_late_async_collectives(lagged, depth):
+    """bench.py's loop (PipelinedShardedForward, lagged under f8_net_set_pipelined, depth = pipeline_depth) against collectives
+    that complete late: no buffer pair is rewritten, or promised to the next run, while its all-gather is still in flight
+    (VERDICT r2 #9: proven on gloo before RCCL first meets it)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29650 + depth + (10 if lagged else 0)
+    procs = [ctx.Process(target=_discipline_worker, args=(r, 2, port, lagged, depth, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    violations = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert violations == []

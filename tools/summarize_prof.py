@@ -5,7 +5,7 @@
       -> profiles/rocprof_r02_kernel_stats.md   (rocprofv3 --kernel-trace --stats summary)
       -> profiles/rocprof_r02_pmc.md            (FETCH_SIZE / WRITE_SIZE per kernel, separate passes)
       -> profiles/rocprof_r02_mfma.md           (INT8 MFMA instructions / busy cycles per kernel)
-      --main: also profiles/pmc_traffic.json and profiles/pmc_mfma.json, which bench.py reads for roofline.traffic /
+      always: profiles/pmc_traffic_<arch>_bs<N>.json and pmc_mfma_<arch>_bs<N>.json, which bench.py reads for roofline.traffic /
               roofline.mfma — both carry the sha256 of the kernel sources that were profiled and the workload; bench.py drops
               them when either does not match the build it runs.
 
@@ -101,14 +101,13 @@ def main():
             for k, e in sorted(mf.items(), key=lambda kv: -kv[1].get('GRBM_GUI_ACTIVE_sum', 0)):
                 f.write(f"| `{k}` | {e['launches']} | {e.get('SQ_INSTS_VALU_MFMA_I8', 0):.4g} | {e.get('SQ_VALU_MFMA_BUSY_CYCLES', 0):.4g} | "
                         f"{e.get('GRBM_GUI_ACTIVE', 0):.4g} | {100 * e['mfma_busy_frac']:.2f} % |\n")
-        if is_main:
+        if True:                                             # one stamped file per workload (bench.py picks the one of its --arch / --bs)
             json.dump({'csrc_sha256': stamp, 'workload': workload, 'tag': tag, 'whole_net_mfma_busy_frac': round(tb / ta, 5) if ta else None,
                        'whole_net_mfma_insts_per_img': round(ti / passes / bs, 1),
                        'kernels': {k: {kk: vv for kk, vv in e.items() if not kk.endswith('_sum')} for k, e in mf.items()}},
-                      open(os.path.join(out, 'pmc_mfma.json'), 'w'), indent=1, sort_keys=True)
-    if is_main:
-        json.dump({'csrc_sha256': stamp, 'workload': workload, 'tag': tag, 'kernels': {k: v for k, v in traffic.items() if k.startswith('f8::')}},
-                  open(os.path.join(out, 'pmc_traffic.json'), 'w'), indent=1, sort_keys=True)
+                      open(os.path.join(out, f'pmc_mfma_{arch}_bs{bs}.json'), 'w'), indent=1, sort_keys=True)
+    json.dump({'csrc_sha256': stamp, 'workload': workload, 'tag': tag, 'kernels': {k: v for k, v in traffic.items() if k.startswith('f8::')}},
+              open(os.path.join(out, f'pmc_traffic_{arch}_bs{bs}.json'), 'w'), indent=1, sort_keys=True)
     line = os.path.join(src, 'bench_line.json')
     if os.path.exists(line):
         txt = open(line).read().strip()
