@@ -108,9 +108,26 @@ chain_kernel(const ChainArgs a) {
     int* const bias_lds = (int*)(xin + Cfg::XIN_BYTES);         // every block's b0 | b2 | b4, then bsc of the opening block
     int* const misc = bias_lds + Cfg::BIAS_BYTES / 4;
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;
-    const int l31 = lane & 31, lh = lane >> 5;
+    // Per-lane constants (lane, its pixel row and K half, LDS bases ...) are RE-DERIVED at the top of every phase from an opaque copy
+    // of the thread id: kept live across the whole kernel next to the 112-128 stream registers they are what the allocator spills,
+    // and a scratch reload (`s_waitcnt vmcnt(0)` behind it) in every tile epilogue cost the 56x56 instance a third of its P3.
+#define F8_LANES                                                                                                                        \
+    int tq_ = tid; asm volatile("" : "+v"(tq_));                                                                                        \
+    const int lane = tq_ & 63, l31 = lane & 31, lh = lane >> 5;                                                                         \
+    const unsigned wl16 = (unsigned)(lane * 16);                                                                                        \
+    const unsigned xlane = (unsigned)(l31 * XS + lh * 16), mlane = (unsigned)(l31 * MS + lh * 16), ilane = (unsigned)(l31 * IS + lh * 16); \
+    (void)wl16; (void)xlane; (void)mlane; (void)ilane
+#define F8_LANES_P12                                                                                                                    \
+    F8_LANES;                                                                                                                           \
+    unsigned p12x[NPW], p12m[NPW], p12i[NPW]; int p12_pix[NPW];                                                                          \
+    _Pragma("unroll") for (int j = 0; j < NPW; ++j) {                                                                                    \
+        const int pt = (pg + PG * j) < NPT ? (pg + PG * j) : NPT - 1;                                                                    \
+        p12_pix[j] = pt * 32 + l31;                                                                                                     \
+        p12x[j] = (unsigned)(pt * 32 * XS) + xlane; p12m[j] = (unsigned)(pt * 32 * MS) + mlane; p12i[j] = (unsigned)(pt * 32 * IS) + ilane; \
+    }                                                                                                                                   \
+    (void)p12x; (void)p12m; (void)p12i; (void)p12_pix
 
     // ---- place in the logical grid: a ticket
     if (tid == 0) { misc[0] = (int)__hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); misc[1] = 0; }
@@ -141,16 +158,6 @@ chain_kernel(const ChainArgs a) {
 
     // P1 / P2 roles: wave (mt, pg) computes mid channel tile mt for pixel tiles pg + PG j; a missing tile repeats the last one (same bytes twice)
     const int mt = wave & (CM - 1), pg = wave / CM;
-    // per-lane LDS bases: everything else is an immediate
-    const unsigned xlane = (unsigned)(l31 * XS + lh * 16), mlane = (unsigned)(l31 * MS + lh * 16), ilane = (unsigned)(l31 * IS + lh * 16);
-    unsigned p12x[NPW], p12m[NPW], p12i[NPW]; int p12_pix[NPW];
-#pragma unroll
-    for (int j = 0; j < NPW; ++j) {
-        const int pt = (pg + PG * j) < NPT ? (pg + PG * j) : NPT - 1;
-        p12_pix[j] = pt * 32 + l31;
-        p12x[j] = (unsigned)(pt * 32 * XS) + xlane; p12m[j] = (unsigned)(pt * 32 * MS) + mlane; p12i[j] = (unsigned)(pt * 32 * IS) + ilane;
-    }
-
     v16i res[NPT][CTW];                                         // the tile's int32 stream: pixel tile x this wave's channel tiles
     v4i wbuf[NBUF][NB];                                         // A operands in flight: NBUF batches of NB K32 steps (one 1 KB wave load each)
     unsigned seq = 0;
@@ -161,27 +168,25 @@ chain_kernel(const ChainArgs a) {
     // A-operand loads: uniform base (+ a SCALAR step offset, kept scalar by `opaque`: as a constant it gets folded into a per-step
     // per-lane offset register that is hoisted out of the block loop and spilled) + ONE per-lane offset register per stream
     auto ldw = [](const int8_t* base, int soff, unsigned voff) { return *(const v4i*)(base + opaque(soff) + voff); };
-    const unsigned wl16 = (unsigned)(lane * 16);
-    const unsigned w2off = (unsigned)(mt * NK2 * 1024) + wl16, w3off = (unsigned)(wave * CTW * KK * 1024) + wl16;
-    auto w1_load = [&](const int8_t* w0, auto nkc, v4i (&dst)[NB], int bi) {
+    auto w1_load = [&](const int8_t* w0, auto nkc, v4i (&dst)[NB], int bi, unsigned wl) {
         constexpr int NK = decltype(nkc)::value;
-        const unsigned w1off = (unsigned)(mt * NK * 1024) + wl16;
+        const unsigned w1off = (unsigned)(mt * NK * 1024) + wl;
         const int k0 = k1_of(bi * NB, NK);
 #pragma unroll
         for (int s = 0; s < NB; ++s) dst[s] = ldw(w0, (k0 + s) * 1024, w1off);
     };
-    auto w1_prime = [&](const int8_t* w0, auto nkc) {
+    auto w1_prime = [&](const int8_t* w0, auto nkc, unsigned wl) {
         constexpr int NBAT = decltype(nkc)::value / NB;
-        static_for<(NBUF - 1 < NBAT ? NBUF - 1 : NBAT)>([&](auto bc) { constexpr int Bi = decltype(bc)::value; w1_load(w0, nkc, wbuf[Bi], Bi); });
+        static_for<(NBUF - 1 < NBAT ? NBUF - 1 : NBAT)>([&](auto bc) { constexpr int Bi = decltype(bc)::value; w1_load(w0, nkc, wbuf[Bi], Bi, wl); });
     };
     constexpr int NBAT2 = NK2 / NB, BPTAP = CM / NB;            // body.2: batches, batches per tap
-    auto w2_load = [&](const int8_t* w2, v4i (&dst)[NB], int bi) {
+    auto w2_load = [&](const int8_t* w2, v4i (&dst)[NB], int bi, unsigned wl) {
         const int k0 = tap_of(bi / BPTAP) * CM + (bi % BPTAP) * NB;
 #pragma unroll
-        for (int s = 0; s < NB; ++s) dst[s] = ldw(w2, (k0 + s) * 1024, w2off);
+        for (int s = 0; s < NB; ++s) dst[s] = ldw(w2, (k0 + s) * 1024, (unsigned)(mt * NK2 * 1024) + wl);
     };
-    auto w2_prime = [&](const int8_t* w2) {
-        static_for<NBUF - 1>([&](auto bc) { constexpr int Bi = decltype(bc)::value; w2_load(w2, wbuf[Bi], Bi); });
+    auto w2_prime = [&](const int8_t* w2, unsigned wl) {
+        static_for<NBUF - 1>([&](auto bc) { constexpr int Bi = decltype(bc)::value; w2_load(w2, wbuf[Bi], Bi, wl); });
     };
     // the MFMAs of a step must not be scheduled above the LDS reads of the NEXT step that are issued just before them
     auto pin = [](auto& xf) {
@@ -196,6 +201,7 @@ chain_kernel(const ChainArgs a) {
         // stage input -> registers (identity first block) / LDS (stage-opening first block)
         // =====================================================================================
         if constexpr (!DS0) {
+            F8_LANES;
             const ChainBlk& B0 = a.blk[0];
             const __amdgpu_buffer_rsrc_t rxr = __builtin_amdgcn_make_buffer_rsrc((void*)a.xr, 0, (unsigned)(((a.N * H * W + 31) & ~31) * C * 4), 0x00020000);
 #pragma unroll
@@ -215,7 +221,7 @@ chain_kernel(const ChainArgs a) {
                     }
                 }
             }
-            w1_prime(B0.w0, std::integral_constant<int, NK1>{});
+            w1_prime(B0.w0, std::integral_constant<int, NK1>{}, wl16);
 #pragma unroll
             for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
@@ -229,7 +235,7 @@ chain_kernel(const ChainArgs a) {
                 if (row < npx) v = *(const v4i*)(a.x8in + (size_t)(m_tile + row) * CIN0 + c16 * 16);
                 *(v4i*)(xin + row * IS + c16 * 16) = v;
             }
-            w1_prime(a.blk[0].w0, std::integral_constant<int, KS>{});
+            { F8_LANES; w1_prime(a.blk[0].w0, std::integral_constant<int, KS>{}, wl16); }
         }
         __syncthreads();
         F8_CT(0);
@@ -258,6 +264,7 @@ chain_kernel(const ChainArgs a) {
 
                 // ============================ P1: mid1 = requant(relu(W0 . x8 + b0)) -> patch interior   (its first weight batches are in flight)
                 {
+                    F8_LANES_P12;
                     {   // the whole patch <- biased zero: border columns, rows outside the image; everything else is overwritten below
                         const v4i zv = {(int)xor1, (int)xor1, (int)xor1, (int)xor1};
                         for (int o = tid * 16; o < Cfg::PATCH_BYTES; o += 512 * 16) *(v4i*)(patch + o) = zv;
@@ -289,7 +296,7 @@ chain_kernel(const ChainArgs a) {
                     rd(xfa, std::integral_constant<int, 0>{});
                     static_for<NK1B>([&](auto gc) {
                         constexpr int G = decltype(gc)::value, Bi = G / NB, S = G % NB;
-                        if constexpr (S == 0 && Bi + NBUF - 1 < NBAT1) w1_load(pw0, std::integral_constant<int, NK1B>{}, wbuf[(Bi + NBUF - 1) % NBUF], Bi + NBUF - 1);
+                        if constexpr (S == 0 && Bi + NBUF - 1 < NBAT1) w1_load(pw0, std::integral_constant<int, NK1B>{}, wbuf[(Bi + NBUF - 1) % NBUF], Bi + NBUF - 1, wl16);
                         v4i (&cur)[NPW] = (G & 1) ? xfb : xfa;
                         v4i (&nxt)[NPW] = (G & 1) ? xfa : xfb;
                         if constexpr (G + 1 < NK1B) rd(nxt, std::integral_constant<int, G + 1>{});
@@ -298,7 +305,7 @@ chain_kernel(const ChainArgs a) {
                         for (int j = 0; j < NPW; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Bi % NBUF][S], cur[j], acc[j], 0, 0, 0);
                     });
                     F8_CT(7);
-                    w2_prime(pw2);                                // body.2's first weight batches travel during the epilogue and the halo exchange
+                    w2_prime(pw2, wl16);                                // body.2's first weight batches travel during the epilogue and the halo exchange
                     __syncthreads();                            // the zero fill is complete
                     F8_CT(8);
                     const int floor0 = relu_a ? 0 : INT32_MIN;
@@ -365,25 +372,26 @@ chain_kernel(const ChainArgs a) {
                 // this wave's P3 weights (WSTAT): requested when P2's K loop is over, so they travel during its epilogue
                 constexpr int K0 = DSB ? KS : 0, KT = KK + K0;  // opening block: the shortcut's K steps come first
                 v4i wst[WSTAT ? CTW * KT : 1];
-                auto wst_load = [&]() {
+                auto wst_load = [&](unsigned wl) {
                     if constexpr (WSTAT) {
 #pragma unroll
                         for (int i = 0; i < CTW; ++i) {
                             const int ct = wave * CTW + i;
                             if constexpr (DSB) {
 #pragma unroll
-                                for (int k = 0; k < KS; ++k) wst[i * KT + k] = ldw(pwsc, (i * KS + k) * 1024, (unsigned)(wave * CTW * KS * 1024) + wl16);
+                                for (int k = 0; k < KS; ++k) wst[i * KT + k] = ldw(pwsc, (i * KS + k) * 1024, (unsigned)(wave * CTW * KS * 1024) + wl);
                             }
 #pragma unroll
-                            for (int k = 0; k < KK; ++k) wst[i * KT + K0 + k] = ldw(pw4, (i * KK + k) * 1024, w3off);
+                            for (int k = 0; k < KK; ++k) wst[i * KT + K0 + k] = ldw(pw4, (i * KK + k) * 1024, (unsigned)(wave * CTW * KK * 1024) + wl);
                         }
                     }
                 };
-                auto w3_load = [&](v4i (&dst)[NB], int qi) {      // streamed P3: batch qi of this wave's CTW consecutive channel tiles
+                auto w3_load = [&](v4i (&dst)[NB], int qi, unsigned wl) {      // streamed P3: batch qi of this wave's CTW consecutive channel tiles
 #pragma unroll
-                    for (int s = 0; s < NB; ++s) dst[s] = ldw(pw4, (qi * NB + s) * 1024, w3off);
+                    for (int s = 0; s < NB; ++s) dst[s] = ldw(pw4, (qi * NB + s) * 1024, (unsigned)(wave * CTW * KK * 1024) + wl);
                 };
                 {
+                    F8_LANES_P12;
                     v16i acc[NPW];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -417,7 +425,7 @@ chain_kernel(const ChainArgs a) {
                     rd(xfa, std::integral_constant<int, 0>{});
                     static_for<NK2>([&](auto gc) {
                         constexpr int G = decltype(gc)::value, Bi = G / NB, S = G % NB;
-                        if constexpr (S == 0 && Bi + NBUF - 1 < NBAT2) w2_load(pw2, wbuf[(Bi + NBUF - 1) % NBUF], Bi + NBUF - 1);
+                        if constexpr (S == 0 && Bi + NBUF - 1 < NBAT2) w2_load(pw2, wbuf[(Bi + NBUF - 1) % NBUF], Bi + NBUF - 1, wl16);
                         v4i (&cur)[NPW] = (G & 1) ? xfb : xfa;
                         v4i (&nxt)[NPW] = (G & 1) ? xfa : xfb;
                         if constexpr (G + 1 < NK2) rd(nxt, std::integral_constant<int, G + 1>{});
@@ -425,8 +433,8 @@ chain_kernel(const ChainArgs a) {
 #pragma unroll
                         for (int j = 0; j < NPW; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Bi % NBUF][S], cur[j], acc[j], 0, 0, 0);
                     });
-                    if constexpr (WSTAT) wst_load();
-                    else static_for<NBUF - 1>([&](auto bc) { constexpr int Qi = decltype(bc)::value; w3_load(wbuf[Qi], Qi); });
+                    if constexpr (WSTAT) wst_load(wl16);
+                    else static_for<NBUF - 1>([&](auto bc) { constexpr int Qi = decltype(bc)::value; w3_load(wbuf[Qi], Qi, wl16); });
                     const int floor0 = relu_b ? 0 : INT32_MIN;
 #pragma unroll
                     for (int j = 0; j < NPW; ++j) {
@@ -442,6 +450,7 @@ chain_kernel(const ChainArgs a) {
 
                 // ============================ P3: stream' = clamp((W4 . mid2 + b4) << sa + (stream << sr)) [ReLU]; x8' = requant(stream')
                 {
+                    F8_LANES;
                     const int floor1 = relu1 ? 0 : -2147483647;   // the join's clamp_(min=-(2^31-1)) and the ReLU floor are one max
                     // channel tile I of pixel tile PT is complete in `acc`: join, clamp, new stream, its int8 copy
                     auto finish = [&](auto ptc, auto ic, const v16i& acc) {
@@ -518,7 +527,7 @@ chain_kernel(const ChainArgs a) {
                             else res[PT][I] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wst[I * KT + KI], cur, res[PT][I], 0, 0, 0);
                             if constexpr (KI == KT - 1) {
                                 if constexpr (PT == NPT - 1 && I == CTW - 1) {   // the block's last weight use: the next block's body.0 starts to travel
-                                    if (!last) w1_prime(pw0n, std::integral_constant<int, NK1>{});
+                                    if (!last) w1_prime(pw0n, std::integral_constant<int, NK1>{}, wl16);
                                 }
                                 finish(std::integral_constant<int, PT>{}, std::integral_constant<int, I>{}, acc);
                             }
@@ -538,7 +547,7 @@ chain_kernel(const ChainArgs a) {
                         static_for<NST>([&](auto gc) {
                             constexpr int G = decltype(gc)::value, I = G / KK, KI = G % KK, Qi = G / NB, S = G % NB;
                             const int ct = wave * CTW + I;
-                            if constexpr (S == 0 && Qi + NBUF - 1 < NQ) w3_load(wbuf[(Qi + NBUF - 1) % NBUF], Qi + NBUF - 1);
+                            if constexpr (S == 0 && Qi + NBUF - 1 < NQ) w3_load(wbuf[(Qi + NBUF - 1) % NBUF], Qi + NBUF - 1, wl16);
                             if constexpr (KI == 0) { bias_init(acc[0], ct); acc[1] = acc[0]; }
                             v4i (&cur)[2] = (G & 1) ? xfb : xfa;
                             v4i (&nxt)[2] = (G & 1) ? xfa : xfb;
@@ -547,7 +556,7 @@ chain_kernel(const ChainArgs a) {
                             acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Qi % NBUF][S], cur[0], acc[0], 0, 0, 0);
                             acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Qi % NBUF][S], cur[1], acc[1], 0, 0, 0);
                             if constexpr (KI == KK - 1) {
-                                if constexpr (I == CTW - 1) { if (!last) w1_prime(pw0n, std::integral_constant<int, NK1>{}); }
+                                if constexpr (I == CTW - 1) { if (!last) w1_prime(pw0n, std::integral_constant<int, NK1>{}, wl16); }
                                 finish(std::integral_constant<int, 0>{}, std::integral_constant<int, I>{}, acc[0]);
                                 finish(std::integral_constant<int, 1>{}, std::integral_constant<int, I>{}, acc[1]);
                             }
@@ -577,7 +586,7 @@ chain_kernel(const ChainArgs a) {
         F8_CT(5);
     }
 #ifdef F8_TRACE
-    if (a.trace && lane == 0) {
+    if (a.trace && (tid & 63) == 0) {
         unsigned long long* tp = (unsigned long long*)a.trace + ((size_t)blockIdx.x * 8 + wave) * 16;
         for (int i = 0; i < 16; ++i) tp[i] = tt[i];
     }

@@ -2,7 +2,7 @@
 # Run on the GPU box (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes for bench.py.
 #   tools/profile.sh <tag> [bench args, e.g. --arch mobilenet_v2 --bs 128]
 # Output under gpurun_out/prof_<tag>/ ; summaries are post-processed by tools/summarize_prof.py (which also checks the stamp).
-TAG=${1:-r02}; shift
+TAG=${1:-r03}; shift
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT

@@ -3,7 +3,7 @@
 #   gpurun --timeout 3000 -- 'bash tools/refresh_profiles.sh r02'
 # then copy gpurun_out/refresh_<tag>/* into profiles/ (tools/refresh_profiles.sh does not write there itself: gpurun only merges
 # gpurun_out/ back).
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/refresh_$TAG
 mkdir -p $OUT
