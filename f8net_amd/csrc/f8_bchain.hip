@@ -1,0 +1,413 @@
+// f8_bchain.hip — consecutive ResNet BasicBlocks of one stage in one launch; the int32 residual stream never leaves the chip.
+//
+// IntBlock.forward of /root/reference/models/fix_resnet.py:26-54,77 for BasicBlock identity blocks (ResNet-18 / 34:
+// fix_resnet.py:125-221):   x --3x3, ReLU--> mid --3x3--> + x (aligned, wrapping add, clamp) --ReLU--> y,   every
+// int_op_only_fix_quant (fix_quant_ops.py:90-114) in place, applied to every identity block of the stage in turn.
+//
+// Same idea as f8_chain.hip (the bottleneck stages of ResNet-50): a workgroup owns a tile of R rows x full width of one image and
+// keeps the tile's int32 stream in REGISTERS from block to block; HBM sees the stage input once (int32) and the stage output once.
+// A BasicBlock has TWO 3x3 convolutions, so a tile swaps halo rows with its vertical neighbours twice per block (the int8 input of
+// the first conv, then `mid`), by the same placement-independent protocol (write-through stores, drain, barrier, flag; one lane
+// polls; sc0 sc1 loads; tickets; bounded spins).  Unlike the bottleneck chains the stream is small here (64 of 256 registers), which
+// leaves room for the overlap those kernels could not afford: the 3x3's K loop starts with its CENTRE-ROW taps, which read no halo
+// row, and the neighbours' rows are only waited for in front of the first tap that needs them — the exchange runs under a third of
+// the K loop.
+//
+// 512 threads = 8 waves; wave (ct, pg) computes output channel tile ct for pixel tiles pg, pg + PG, ... (4 of them in every
+// instance) in BOTH convs, and owns the same tiles of the stream.  Weights travel L2 -> registers in MFMA-fragment order
+// (pack_frag_weights), B operands come from two LDS patches (rows padded by 16 bytes: one base register + immediates), no barrier
+// inside a K loop apart from the halo hand-over.
+#include "f8_device.h"
+#include <cstdio>
+#include <cstdlib>
+
+namespace f8 {
+
+template <int C, int W, int H, int R>
+struct BChainCfg {
+    static constexpr int T = (H + R - 1) / R;
+    static constexpr int PX = R * W, NPT = (PX + 31) / 32;
+    static constexpr int PW = W + 2, PR = R + 2, CS = C + 16;          // patch entry stride: padded, see f8_chain.hip
+    static constexpr int PATCH_BYTES = (PR * PW * CS + 255) / 256 * 256;
+    static constexpr int BIAS_BYTES = kBChainMaxBlocks * 2 * C * 4;
+    static constexpr int LDS_BYTES = 2 * PATCH_BYTES + BIAS_BYTES + 256;
+    static constexpr int ROWB = W * C;
+    static_assert(LDS_BYTES <= 160 * 1024 && PATCH_BYTES < 65536, "LDS / immediate offsets");
+    static_assert(ROWB / 16 <= 256 && (size_t)256 * 4 * ROWB <= kChainXchgBytes, "one 16-byte piece of a halo row per thread of a half workgroup");
+};
+
+template <bool FAST, class Y>
+__device__ __forceinline__ v4i bquant_tile16(const Y& y, int n, int lo, int hi, unsigned x_or) {
+    unsigned d[4];
+    const unsigned half = FAST ? (1u << (n - 1)) : 0u;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        int q[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] = FAST ? requant_shr(y[4 * g + e], n, half, 0u, lo, hi) : requant1(y[4 * g + e], n, lo, hi);
+        d[g] = pack4(q[0], q[1], q[2], q[3]) ^ x_or;
+    }
+    auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+    auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+    const v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
+    return o;
+}
+__device__ __forceinline__ int bopaque(int v) { asm volatile("" : "+s"(v)); return v; }
+
+// FAST: ReLU after the first conv and after the join, every int8 format of the chain unsigned with a right shift, the stream never shifted
+template <int C, int W, int H, int R, int NB, int NBUF, bool FAST>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+bchain_kernel(const BChainArgs a) {
+    using Cfg = BChainCfg<C, W, H, R>;
+    constexpr int T = Cfg::T, NPT = Cfg::NPT, PW = Cfg::PW, CS = Cfg::CS, ROWB = Cfg::ROWB;
+    constexpr int CT = C / 32, PG = 8 / CT, NPW = (NPT + PG - 1) / PG;
+    constexpr int NK = 9 * CT, NBAT = NK / NB, BPTAP = CT / NB;
+    static_assert(CT == 2 || CT == 4 || CT == 8, "8 waves = CT channel tiles x PG pixel-tile groups");
+    static_assert(NB <= CT && CT % NB == 0, "a batch of K steps stays inside one tap");
+    static_assert(NPW <= 4, "stream + accumulators in registers");
+
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* const patchX = lds;                                   // [(R+2)][(W+2)][CS]: int8 copy of the stream in the first conv's input format, with halo
+    char* const patchM = lds + Cfg::PATCH_BYTES;                // the same for `mid`
+    int* const bias_lds = (int*)(lds + 2 * Cfg::PATCH_BYTES);   // per block: ba | bb
+    int* const misc = bias_lds + Cfg::BIAS_BYTES / 4;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;
+    const int ct = wave & (CT - 1), pg = wave / CT;
+
+    if (tid == 0) { misc[0] = (int)__hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); misc[1] = 0; }
+    for (int b = 0; b < a.nblk; ++b) {
+        const BChainBlk& B = a.blk[b];
+        for (int i = tid; i < 2 * C; i += 512) bias_lds[b * 2 * C + i] = i < C ? B.ba[i] : B.bb[i - C];
+    }
+    __syncthreads();
+    const int L = __builtin_amdgcn_readfirstlane(misc[0]);
+    const int grp = L / T, ti = L - grp * T;
+    const int p0 = ti * R;
+    const int rows = (H - p0) < R ? (H - p0) : R;
+    const int npx = rows * W;
+    const bool has_up = ti > 0, has_dn = ti < T - 1;
+    unsigned* const flags = a.sync + 16;
+    const unsigned long long t_limit = (unsigned long long)a.timeout_ticks;
+#ifdef F8_TRACE
+    unsigned long long tt[8] = {}; unsigned long long t_prev = __builtin_readcyclecounter();
+#define F8_BT(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); tt[i] += now_ - t_prev; t_prev = now_; } while (0)
+#else
+#define F8_BT(i)
+#endif
+
+    // per-lane constants, re-derived where they are used (see f8_chain.hip)
+#define F8_BLANES                                                                                                   \
+    int tq_ = tid; asm volatile("" : "+v"(tq_));                                                                    \
+    const int lane = tq_ & 63, l31 = lane & 31, lh = lane >> 5;                                                     \
+    int bpix[NPW];                                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < NPW; ++j) { const int pt = (pg + PG * j) < NPT ? (pg + PG * j) : NPT - 1; bpix[j] = pt * 32 + l31; } \
+    (void)lane; (void)lh; (void)bpix
+
+    int res[NPW][16];                                           // the stream: this wave's channel tile x its pixel tiles (a missing tile repeats the last one)
+    v4i wbuf[NBUF][NB];
+    unsigned seq = 0;
+    bool failed = false;
+
+    auto ldw = [](const int8_t* base, int soff, unsigned voff) { return *(const v4i*)(base + bopaque(soff) + voff); };
+    auto tap_at = [](int t) constexpr { return t < 3 ? t + 3 : (t < 6 ? t - 3 : t); };       // centre row first: it reads no halo row
+    auto w_load = [&](const int8_t* w, v4i (&dst)[NB], int bi, unsigned wl) {
+        const int k0 = tap_at(bi / BPTAP) * CT + (bi % BPTAP) * NB;
+#pragma unroll
+        for (int s = 0; s < NB; ++s) dst[s] = ldw(w, (k0 + s) * 1024, (unsigned)(ct * NK * 1024) + wl);
+    };
+    auto w_prime = [&](const int8_t* w, unsigned wl) {
+        static_for<NBUF - 1>([&](auto bc) { constexpr int Bi = decltype(bc)::value; w_load(w, wbuf[Bi], Bi, wl); });
+    };
+
+    // ---- halo rows of `patch`: publish this tile's first / last row
+    auto publish = [&](char* patch) {
+        if constexpr (T > 1) {
+            ++seq;
+            constexpr int RCH = ROWB / 16, CPE = C / 16;
+            const __amdgpu_buffer_rsrc_t rxc = __builtin_amdgcn_make_buffer_rsrc((void*)a.xchg, 0, (unsigned)kChainXchgBytes, 0x00020000);
+            const int side = tid >> 8, idx = tid & 255;
+            const bool mine = idx < RCH && (side == 0 ? has_up : has_dn);
+            if (mine) {
+                const int col = idx / CPE, c16 = idx % CPE;
+                const int ent = (side == 0 ? 1 : rows) * PW + col + 1;
+                const v4i v = *(const v4i*)(patch + ent * CS + c16 * 16);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rxc, (unsigned)(((L * 2 + (int)(seq & 1u)) * 2 + side) * ROWB + idx * 16), 0, 17);   // sc0 sc1
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flags + L, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    // ... and fetch the neighbours' rows into the patch's halo rows (called inside the K loop, after the centre-row taps)
+    auto consume = [&](char* patch) {
+        if constexpr (T > 1) {
+            constexpr int RCH = ROWB / 16, CPE = C / 16;
+            int t2 = tid; asm volatile("" : "+v"(t2));
+            if ((t2 == 0 && has_up) || (t2 == 256 && has_dn)) {
+                unsigned* const f = flags + (t2 == 0 ? L - 1 : L + 1);
+                const unsigned long long t0 = wall_clock64();
+                bool ok = true;
+                while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (wall_clock64() - t0 > t_limit) { ok = false; break; }
+                }
+                if (!ok) { misc[1] = 1; __hip_atomic_store(a.err, 0x200u + (unsigned)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            }
+            __syncthreads();
+            if (misc[1]) failed = true;
+            const int side = t2 >> 8, idx = t2 & 255;
+            if (idx < RCH && (side == 0 ? has_up : has_dn)) {
+                const __amdgpu_buffer_rsrc_t rxc = __builtin_amdgcn_make_buffer_rsrc((void*)a.xchg, 0, (unsigned)kChainXchgBytes, 0x00020000);
+                const int nb_wg = side == 0 ? L - 1 : L + 1;
+                const v4i v = __builtin_amdgcn_raw_buffer_load_b128(rxc, (unsigned)(((nb_wg * 2 + (int)(seq & 1u)) * 2 + (1 - side)) * ROWB + idx * 16), 0, 17);
+                const int col = idx / CPE, c16 = idx % CPE;
+                *(v4i*)(patch + ((side == 0 ? 0 : rows + 1) * PW + col + 1) * CS + c16 * 16) = v;
+            }
+            __syncthreads();
+        }
+    };
+
+    // ---- one 3x3: acc[j] (started at the bias) += W . patch taps; the halo rows of `patch` are fetched in front of the first tap that reads one
+    auto conv3x3 = [&](char* patch, const int8_t* w, const int* bias, v16i (&acc)[NPW]) {
+        F8_BLANES;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const v4i bv = *(const v4i*)(bias + ct * 32 + 8 * g + 4 * lh);
+#pragma unroll
+            for (int j = 0; j < NPW; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j][4 * g + e] = bv[e];
+        }
+        unsigned bpb[NPW];
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) {
+            const int oc = bpix[j] < npx ? bpix[j] : npx - 1;                    // padding lanes read a valid pixel, result unused
+            const int orow = oc / W, ocol = oc - orow * W;
+            bpb[j] = (unsigned)((orow * PW + ocol) * CS + lh * 16);
+        }
+        auto rd = [&](v4i (&xf)[NPW], auto gc) {
+            constexpr int G = decltype(gc)::value, TAP = tap_at(G / CT), CI = G % CT;
+#pragma unroll
+            for (int j = 0; j < NPW; ++j) xf[j] = *(const v4i*)(patch + bpb[j] + ((TAP / 3) * PW + TAP % 3) * CS + CI * 32);
+        };
+        const unsigned wl = (unsigned)(lane * 16);
+        constexpr int GH = T > 1 ? 3 * CT : NK + 1;                              // first step of a tap that reads a halo row
+        v4i xfa[NPW], xfb[NPW];
+        rd(xfa, std::integral_constant<int, 0>{});
+        static_for<NK>([&](auto gc) {
+            constexpr int G = decltype(gc)::value, Bi = G / NB, S = G % NB;
+            if constexpr (S == 0 && Bi + NBUF - 1 < NBAT) w_load(w, wbuf[(Bi + NBUF - 1) % NBUF], Bi + NBUF - 1, wl);
+            v4i (&cur)[NPW] = (G & 1) ? xfb : xfa;
+            v4i (&nxt)[NPW] = (G & 1) ? xfa : xfb;
+            if constexpr (G == GH) { consume(patch); rd(cur, gc); }
+            if constexpr (G + 1 < NK && G + 1 != GH) rd(nxt, std::integral_constant<int, G + 1>{});
+#pragma unroll
+            for (int j = 0; j < NPW; ++j) asm volatile("" : "+v"(cur[j]));
+#pragma unroll
+            for (int j = 0; j < NPW; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Bi % NBUF][S], cur[j], acc[j], 0, 0, 0);
+        });
+    };
+
+    for (int n = grp; n < a.N; n += a.NG) {
+        const int m_tile = (n * H + p0) * W;
+        const BChainBlk& B0 = a.blk[0];
+        {   // ---- stage input -> registers; its int8 copy -> patchX interior; both patches' borders <- biased zero
+            F8_BLANES;
+            const v4i zx = {(int)B0.xorq, (int)B0.xorq, (int)B0.xorq, (int)B0.xorq};
+            for (int o = tid * 16; o < Cfg::PATCH_BYTES; o += 512 * 16) *(v4i*)(patchX + o) = zx;
+            const __amdgpu_buffer_rsrc_t rxr = __builtin_amdgcn_make_buffer_rsrc((void*)a.xr, 0, (unsigned)(((a.N * H * W + 31) & ~31) * C * 4), 0x00020000);
+#pragma unroll
+            for (int j = 0; j < NPW; ++j) {
+                const int mc = m_tile + (bpix[j] < npx ? bpix[j] : 0);
+                const unsigned vo = (unsigned)((mc >> 5) * (C * 128) + lh * 512 + (mc & 31) * 16);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const v4i v = __builtin_amdgcn_raw_buffer_load_b128(rxr, vo + g * 1024, ct * 4096, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) res[j][4 * g + e] = v[e];
+                }
+            }
+            w_prime(B0.wa, (unsigned)(lane * 16));
+            __syncthreads();                                    // the zero fill is complete
+#pragma unroll
+            for (int j = 0; j < NPW; ++j) {
+                const int pix = bpix[j], pr = pix / W, pc = pix - pr * W;
+                const v4i o = bquant_tile16<FAST>(res[j], B0.nq, FAST ? 0 : B0.loq, FAST ? 255 : B0.hiq, FAST ? 0x80808080u : B0.xorq);
+                if (pix < npx) *(v4i*)(patchX + ((pr + 1) * PW + pc + 1) * CS + ct * 32 + lh * 16) = o;
+            }
+        }
+        __syncthreads();
+        publish(patchX);
+        F8_BT(0);
+
+        for (int b = 0; b < a.nblk; ++b) {
+            const BChainBlk& B = a.blk[b];
+            const bool last = b + 1 == a.nblk;
+            const BChainBlk& BN = a.blk[last ? b : b + 1];
+            const int n1 = B.n1, acc_shl = B.acc_shl, res_shl = B.res_shl;
+            const int lo1 = FAST ? 0 : B.lo1, hi1 = FAST ? 255 : B.hi1;
+            const unsigned xor1 = FAST ? 0x80808080u : B.xor1;
+            const int relu_a = FAST ? 1 : B.relu_a, relu1 = FAST ? 1 : B.relu1;
+            const int nq = last ? a.q[0].n : BN.nq;
+            const int loq = FAST ? 0 : (last ? a.q[0].lo : BN.loq), hiq = FAST ? 255 : (last ? a.q[0].hi : BN.hiq);
+            const unsigned xorq = FAST ? 0x80808080u : (last ? a.q[0].bias_xor : BN.xorq);
+            const int* const bl = bias_lds + b * 2 * C;
+
+            {   // ============ first conv: mid = requant(relu(conv3x3(x8) + ba)) -> patchM interior
+                {   // patchM <- biased zero (border, halo rows outside the image); nobody reads it before the barriers of this conv
+                    const v4i zm = {(int)xor1, (int)xor1, (int)xor1, (int)xor1};
+                    for (int o = tid * 16; o < Cfg::PATCH_BYTES; o += 512 * 16) *(v4i*)(patchM + o) = zm;
+                }
+                v16i acc[NPW];
+                conv3x3(patchX, B.wa, bl, acc);
+                { F8_BLANES; w_prime(B.wb, (unsigned)(lane * 16));
+                __syncthreads();                                // the zero fill is complete (T == 1: there was no hand-over barrier)
+                const int floor0 = relu_a ? 0 : INT32_MIN;
+#pragma unroll
+                for (int j = 0; j < NPW; ++j) {
+                    const int pix = bpix[j], pr = pix / W, pc = pix - pr * W;
+                    if constexpr (!FAST) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[j][r] = max(acc[j][r], floor0);
+                    }
+                    const v4i o = bquant_tile16<FAST>(acc[j], n1, lo1, hi1, xor1);
+                    if (pix < npx) *(v4i*)(patchM + ((pr + 1) * PW + pc + 1) * CS + ct * 32 + lh * 16) = o;
+                } }
+            }
+            __syncthreads();
+            publish(patchM);
+            F8_BT(1);
+
+            {   // ============ second conv + join: stream' = clamp((conv3x3(mid) + bb) << sa + (stream << sr)) [ReLU]; x8' = requant(stream') -> patchX
+                v16i acc[NPW];
+                conv3x3(patchM, B.wb, bl + C, acc);
+                F8_BLANES;
+                if (!last) w_prime(BN.wa, (unsigned)(lane * 16));
+                const int floor1 = relu1 ? 0 : -2147483647;
+#pragma unroll
+                for (int j = 0; j < NPW; ++j) {
+                    const int pix = bpix[j], pr = pix / W, pc = pix - pr * W;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if constexpr (FAST) res[j][r] = max((int)(((unsigned)acc[j][r] << acc_shl) + (unsigned)res[j][r]), 0);
+                        else res[j][r] = max((int)(((unsigned)acc[j][r] << acc_shl) + ((unsigned)res[j][r] << res_shl)), floor1);
+                    }
+                    if (!last || a.q[0].ptr) {
+                        const v4i o = bquant_tile16<FAST>(res[j], nq, loq, hiq, xorq);
+                        if (pix < npx) *(v4i*)(patchX + ((pr + 1) * PW + pc + 1) * CS + ct * 32 + lh * 16) = o;
+                    }
+                    if (last && pix < npx) {
+                        const int m = bopaque(m_tile) + pix;
+                        const unsigned tot = (unsigned)(((a.N * H * W + 31) & ~31) * C);
+                        if (a.out32) {
+                            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)a.out32, 0, tot * 4u, 0x00020000);
+                            const unsigned vo = (unsigned)((m >> 5) * (C * 128) + lh * 512 + (m & 31) * 16);
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const v4i o = {res[j][4 * g], res[j][4 * g + 1], res[j][4 * g + 2], res[j][4 * g + 3]};
+                                __builtin_amdgcn_raw_buffer_store_b128(o, ro, vo + g * 1024, ct * 4096, 0);
+                            }
+                        }
+                        if (a.q[1].ptr) {
+                            const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)a.q[1].ptr, 0, tot, 0x00020000);
+                            __builtin_amdgcn_raw_buffer_store_b128(bquant_tile16<false>(res[j], a.q[1].n, a.q[1].lo, a.q[1].hi, a.q[1].bias_xor), rq,
+                                                                   (unsigned)(m * C + 16 * lh), ct * 32, 0);
+                        }
+                    }
+                }
+            }
+            __syncthreads();                                    // patchX interior is complete; patchM may be zeroed again
+            if (failed) return;                                 // a neighbour never arrived (uniform: misc[1] is shared)
+            if (!last) publish(patchX);
+            F8_BT(2);
+        }
+
+        // ---- the first int8 form of the stage output: patchX interior -> whole NHWC rows in HBM
+        if (a.q[0].ptr) {
+            constexpr int CH = C / 16;
+            for (int idx = tid; idx < npx * CH; idx += 512) {
+                const int px = idx / CH, c16 = idx % CH;
+                const int pr = px / W, pc = px - pr * W;
+                const v4i v = *(const v4i*)(patchX + ((pr + 1) * PW + pc + 1) * CS + c16 * 16);
+                *(v4i*)(a.q[0].ptr + (size_t)(m_tile + px) * C + c16 * 16) = v;
+            }
+        }
+        __syncthreads();
+        F8_BT(3);
+    }
+#ifdef F8_TRACE
+    if (a.trace && tid == 0) {
+        unsigned long long* tp = (unsigned long long*)a.trace + (size_t)blockIdx.x * 8;
+        for (int i = 0; i < 4; ++i) tp[i] = tt[i];
+    }
+#endif
+}
+
+// instances: ResNet-18 / 34 stages 0-2 (the 7x7 stage streams 4.7 MB of weights per block and image: no instance)
+static int bchain_rows(int C, int H, int W) {
+    if (C == 64 && H == 56 && W == 56) return 8;
+    if (C == 128 && H == 28 && W == 28) return 7;
+    if (C == 256 && H == 14 && W == 14) return 7;
+    return 0;
+}
+bool bchain_supported(int C, int H, int W) { return bchain_rows(C, H, W) > 0; }
+int bchain_tiles_per_img(int C, int H, int W) { const int r = bchain_rows(C, H, W); return r ? (H + r - 1) / r : 0; }
+
+bool bchain_fast(const BChainArgs& a) {
+    for (int k = 0; k < a.nblk; ++k) {
+        const BChainBlk& B = a.blk[k];
+        if (!(B.relu_a && B.relu1 && B.n1 > 0 && B.nq > 0 && B.lo1 == 0 && B.loq == 0 && B.res_shl == 0)) return false;
+    }
+    if (a.q[0].ptr && !(a.q[0].n > 0 && a.q[0].lo == 0)) return false;
+    return true;
+}
+
+template <int C, int W, int H, int R, int NB, int NBUF, bool FAST>
+static hipError_t launch_bchain_t(const BChainArgs& a, hipStream_t s) {
+    using Cfg = BChainCfg<C, W, H, R>;
+    static unsigned long long attr_done = 0; int attr_dev = -1;
+    if (!dyn_lds_opted_in(&attr_done, &attr_dev)) {
+        hipError_t e = hipFuncSetAttribute((const void*)bchain_kernel<C, W, H, R, NB, NBUF, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        if (attr_dev >= 0) attr_done |= 1ull << attr_dev;
+    }
+    const int grid = a.NG * Cfg::T;
+    if (grid < 1 || grid > 256) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(a.sync, 0, (size_t)kChainSyncWords * 4, s);
+    if (e != hipSuccess) return e;
+#ifdef F8_TRACE
+    static unsigned long long* tbuf = nullptr; static int count = 0;
+    static const int want = [] { const char* e = getenv("F8_TRACE_BCHAIN"); return e ? atoi(e) : -1; }();
+    BChainArgs b = a;
+    const bool tracing = (count++ == want);
+    if (tracing) { if (!tbuf) (void)hipMalloc((void**)&tbuf, (size_t)1 << 16); (void)hipMemsetAsync(tbuf, 0, (size_t)grid * 64, s); b.trace = tbuf; }
+    hipLaunchKernelGGL((bchain_kernel<C, W, H, R, NB, NBUF, FAST>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, b);
+    if (tracing) {
+        (void)hipStreamSynchronize(s);
+        static unsigned long long hb[256 * 8];
+        (void)hipMemcpy(hb, tbuf, (size_t)grid * 64, hipMemcpyDeviceToHost);
+        double ph[4] = {}; for (int i = 0; i < grid; ++i) for (int k = 0; k < 4; ++k) ph[k] += (double)hb[(size_t)i * 8 + k];
+        fprintf(stderr, "[trace bchain<%d,%d>] grid %d, %d blocks, N %d: avg cycles per WG (whole launch): load %.0f | conv A %.0f | conv B + join %.0f | out %.0f\n", C, W, grid,
+                a.nblk, a.N, ph[0] / grid, ph[1] / grid, ph[2] / grid, ph[3] / grid);
+    }
+    return hipGetLastError();
+#else
+    hipLaunchKernelGGL((bchain_kernel<C, W, H, R, NB, NBUF, FAST>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, a);
+    return hipGetLastError();
+#endif
+}
+
+hipError_t launch_bchain(const BChainArgs& a, int C, int H, int W, hipStream_t s) {
+    if (a.nblk < 1 || a.nblk > kBChainMaxBlocks) return hipErrorInvalidValue;
+    const bool fast = bchain_fast(a);
+#define F8_BCH(...) (fast ? launch_bchain_t<__VA_ARGS__, true>(a, s) : launch_bchain_t<__VA_ARGS__, false>(a, s))
+    if (C == 64 && H == 56 && W == 56) return F8_BCH(64, 56, 56, 8, 2, 3);
+    if (C == 128 && H == 28 && W == 28) return F8_BCH(128, 28, 28, 7, 2, 3);
+    if (C == 256 && H == 14 && W == 14) return F8_BCH(256, 14, 14, 7, 2, 3);
+#undef F8_BCH
+    return hipErrorInvalidValue;
+}
+
+}  // namespace f8

@@ -24,6 +24,7 @@ struct Options {
     int wstat_fast = 1;          // 0: always the general epilogue (requant in either direction, explicit ReLU floor)
     int s2wreg = 1;              // stride-2 3x3 convs of the stage-2 / stage-3 openers on conv3x3s2_wreg_kernel (f8_s2conv.hip)
     int wreg = 1;                // late 1x1 convs on conv1x1_wreg_kernel (weights straight to registers, f8_wreg.hip)
+    int fuse_bchain = 1;         // consecutive BasicBlock identity blocks of a stage in ONE launch (f8_bchain.hip)
     int fuse_chain = 1;          // all consecutive bottleneck blocks of a stage in ONE launch, int32 residual stream in registers (f8_chain.hip)
     int chain_timeout_ms = 2000; // bound of its halo-exchange spins
     int fuse_p12 = 1;            // 7x7 identity blocks: body.0 + body.2 in one launch, split over a workgroup pair per image (f8_p12.hip)
@@ -191,6 +192,25 @@ struct ChainArgs {
 constexpr int kChainSyncWords = 16 + 256;
 constexpr size_t kChainXchgBytes = (size_t)256 * 2 * 2 * 3584;
 
+// One launch for consecutive BasicBlock identity blocks of a ResNet-18 / 34 stage (f8_bchain.hip); weights in fragment order.
+struct BChainBlk {
+    const int8_t* wa; const int8_t* wb;    // first / second 3x3
+    const int32_t* ba; const int32_t* bb;  // offset-corrected, single class (the LDS patches carry a biased-zero border)
+    int32_t nq, loq, hiq; uint32_t xorq;   // requant block input (int32 stream) -> the first conv's input format
+    int32_t n1, lo1, hi1; uint32_t xor1;   // requant first conv output -> second conv's input format
+    int32_t relu_a, relu1;                 // ReLU after the first conv / after the join
+    int32_t acc_shl, res_shl;              // join: (conv << acc_shl) + (stream << res_shl)
+};
+constexpr int kBChainMaxBlocks = 6;
+struct BChainArgs {
+    BChainBlk blk[kBChainMaxBlocks]; int32_t nblk;
+    const int32_t* xr;                     // the stage's int32 stream (I32T)
+    int32_t N, NG;
+    int32_t* out32; QuantOut q[2];
+    uint32_t* sync; uint32_t* err; int8_t* xchg; uint32_t timeout_ticks;   // as ChainArgs
+    void* trace;
+};
+
 // One launch for a MobileNet-V2 inverted-residual block: 1x1 expand -> depthwise 3x3 -> 1x1 project [+ int32 residual] (f8_ir.hip).
 struct IRArgs {
     const int8_t* x8;                      // block input, int8 NHWC [N*H*W][CIN_S] in the expand conv's input format
@@ -257,6 +277,10 @@ hipError_t launch_fused_opener(const FusedArgs& a, hipStream_t s);
 bool chain_supported(int C, int MID, int H, int W, int cin0);
 int chain_tiles_per_img(int H, int W);
 hipError_t launch_chain(const ChainArgs& a, int C, int MID, int H, int W, int cin0, hipStream_t s);
+// consecutive BasicBlock identity blocks of a stage in one launch (f8_bchain.hip)
+bool bchain_supported(int C, int H, int W);
+int bchain_tiles_per_img(int C, int H, int W);
+hipError_t launch_bchain(const BChainArgs& a, int C, int H, int W, hipStream_t s);
 // 1x1 -> 3x3 of a 7x7 bottleneck block in one launch (f8_p12.hip); FusedArgs: x8, w0 / b0, w2 / b2, requant 1, q[] = the int8 outputs
 bool fused_p12_supported(int C, int MID, int H, int W);
 hipError_t launch_fused_p12(const FusedArgs& a, hipStream_t s);

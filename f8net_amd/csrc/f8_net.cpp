@@ -85,6 +85,9 @@ struct Node {
     bool wstat = false;                  // 1x1 conv / dual GEMM / residual join on conv1x1_wstat_kernel (f8_wstat.hip)
     int chain_into = -1;                 // host conv of a bottleneck block that runs inside a stage-chain launch: the host of the chain's LAST block
     std::vector<int> chain;              // host of the last block of a chain: the hosts of all its blocks, in order (f8_chain.hip)
+    int bb_a = -1;                       // second 3x3 of a BasicBlock identity block that runs in a bchain launch: its first 3x3
+    int bchain_into = -1;                // ... the host (second conv) of the chain's LAST block
+    std::vector<int> bchain;             // host of the last block of a BasicBlock chain: the hosts of all its blocks (f8_bchain.hip)
     int p12_a = -1;                      // 3x3 conv hosting "1x1 -> 3x3 in one launch" (f8_p12.hip): its 1x1 producer
     int ir_a = -1, ir_b = -1, ir_R = 0, ir_G = 0;   // project conv of a fused inverted-residual block: its expand / depthwise convs, tile
     int dual = -1;                     // 1x1 conv hosting a join whose other operand is ANOTHER 1x1 conv (node id): one dual-GEMM launch
@@ -96,7 +99,7 @@ struct Node {
     size_t rc_off = 0, cc_off = 0; int ncc = 0;      // border-class tables (0 = single class)
     ConvTile tile{};
 };
-enum StepKind { S_INPUT, S_CONV, S_DW, S_ADD, S_MAXPOOL, S_AVGPOOL, S_REQUANT, S_OUTPUT, S_FUSED, S_STEMPOOL, S_IR, S_P12, S_CHAIN };
+enum StepKind { S_INPUT, S_CONV, S_DW, S_ADD, S_MAXPOOL, S_AVGPOOL, S_REQUANT, S_OUTPUT, S_FUSED, S_STEMPOOL, S_IR, S_P12, S_CHAIN, S_BCHAIN };
 struct OutSel { int t = -1; int f32 = -1; int f8[2] = {-1, -1}; };
 struct Step {
     int kind; int node;
@@ -219,6 +222,7 @@ static const OptKey kOptKeys[] = {
     {"fuse_ir", "F8_FUSE_IR", &Options::fuse_ir, 0, 2, true},
     {"fuse_p12", "F8_FUSE_P12", &Options::fuse_p12, 0, 1, true},
     {"fuse_chain", "F8_FUSE_CHAIN", &Options::fuse_chain, 0, 1, true},
+    {"fuse_bchain", "F8_FUSE_BCHAIN", &Options::fuse_bchain, 0, 1, true},
     {"chain_timeout_ms", "F8_CHAIN_TIMEOUT_MS", &Options::chain_timeout_ms, 1, 1 << 20, false},
     {"wreg", "F8_WREG", &Options::wreg, 0, 1, true},
     {"s2wreg", "F8_S2WREG", &Options::s2wreg, 0, 1, true},
@@ -891,6 +895,64 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         return -1;
     };
 
+    // ---- 1g. BasicBlock identity blocks (3x3 ReLU -> 3x3 + residual with the block input, all stride 1) -> f8_bchain.hip: ONE launch for
+    //          the consecutive ones of a stage, the int32 stream in registers (a single block is a chain of one: both convs in one
+    //          launch, `mid` only in LDS)
+    if (opt.fuse_bchain && fuse_blocks) {
+        auto bblock = [&](int i, int* in_t, int* out_t, int* C) -> bool {
+            const Node& c2 = ND[i];
+            if (c2.kind != N_CONV || c2.fused_add < 0 || c2.bchain_into >= 0 || c2.fb_a >= 0 || c2.fbd_a >= 0 || c2.dual >= 0 || c2.dual_host >= 0 ||
+                c2.absorbed_by >= 0 || c2.cd.groups != 1 || c2.cd.kernel != 3 || c2.cd.stride != 1 || c2.cd.pad != 1 || c2.cd.relu || !c2.cd.quant_input) return false;
+            const Tensor& tb = T[c2.a];
+            if (tb.consumers.size() != 1 || c2.a == net->out_t) return false;
+            const Node& c1 = ND[tb.prod];
+            if (c1.kind != N_CONV || c1.fused_add >= 0 || c1.absorbed_by >= 0 || c1.cd.groups != 1 || c1.cd.kernel != 3 || c1.cd.stride != 1 ||
+                c1.cd.pad != 1 || !c1.cd.quant_input || c1.dual >= 0 || c1.dual_host >= 0) return false;
+            const Node& ad = ND[c2.fused_add];
+            const int other = (ad.a == c2.out) ? ad.b : ad.a;
+            if (other != c1.a) return false;
+            const int cc = c1.cd.cin;
+            if (c1.cd.cout != cc || c2.cd.cin != cc || c2.cd.cout != cc || cc % 32) return false;
+            if (ND[T[c1.a].prod].kind == N_INPUT) return false;
+            if (!bchain_supported(cc, T[c1.a].H, T[c1.a].W)) return false;
+            *in_t = c1.a; *out_t = ad.out; *C = cc;
+            return true;
+        };
+        for (int i = 0; i < nn; ++i) {
+            int in_t, out_t, C;
+            if (!bblock(i, &in_t, &out_t, &C)) continue;
+            std::vector<int> hosts{i};
+            const bool sgn0 = ND[T[ND[i].a].prod].cd.input_signed;
+            int cur_out = out_t;
+            while ((int)hosts.size() < kBChainMaxBlocks && cur_out != net->out_t) {
+                const Tensor& y = T[cur_out];
+                if (y.consumers.size() != 2) break;
+                int next = -1, nin = -1, nout = -1, nC = 0;
+                for (int j = hosts.back() + 1; j < nn && next < 0; ++j)
+                    if (bblock(j, &nin, &nout, &nC) && nin == cur_out) next = j;
+                if (next < 0 || nC != C) break;
+                const int c1n = T[ND[next].a].prod;
+                if (ND[c1n].cd.input_signed != sgn0) break;              // one border pattern for the int8 copy of the stream
+                const int k0 = y.consumers[0], k1 = y.consumers[1], w0 = c1n, w1 = ND[next].fused_add;
+                if (!((k0 == w0 && k1 == w1) || (k0 == w1 && k1 == w0))) break;
+                hosts.push_back(next); cur_out = nout;
+            }
+            const int lastn = hosts.back();
+            for (int h : hosts) {
+                Node& c2 = ND[h]; Node& c1 = ND[T[c2.a].prod];
+                c2.bchain_into = lastn; c2.bb_a = T[c2.a].prod;
+                c1.absorbed_by = h; c1.no_classes = true; c2.no_classes = true;
+            }
+            ND[lastn].bchain = hosts;
+        }
+    }
+    auto bchain_pos = [&](int host) -> int {
+        if (host < 0 || ND[host].bchain_into < 0) return -1;
+        const std::vector<int>& ch = ND[ND[host].bchain_into].bchain;
+        for (size_t k = 0; k < ch.size(); ++k) if (ch[k] == host) return (int)k;
+        return -1;
+    };
+
     // ---- 1e. MobileNet-V2 inverted residual: 1x1 expand (ReLU) -> depthwise 3x3 (ReLU) -> 1x1 project [+ residual with the
     //          block input], intermediates read by nobody else  ->  one launch (f8_ir.hip), the expanded tensors stay in LDS
     for (int i = 0; opt.fuse_ir && i < nn; ++i) {
@@ -951,6 +1013,14 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 nd.depthwise = nd.cd.groups != 1;
                 if ((nd.absorbed_by >= 0 && ND[nd.absorbed_by].fbd_b == i) || (nd.dual_host >= 0 && ND[nd.dual_host].fbd_a >= 0)) break;   // DS: in LDS
                 if (nd.p12_a >= 0) break;                    // the 1x1's output lives in LDS inside the launch
+                if (nd.bb_a >= 0) {                          // second conv of a chained BasicBlock: its source (`mid`) lives in LDS
+                    if (bchain_pos(i) == 0) {
+                        const Node& ad = ND[nd.fused_add];
+                        add_form(T[(ad.a == nd.out) ? ad.b : ad.a], FORM_I32, 0, 0);      // the stage's int32 stream: the chain's only input form
+                    }
+                    break;
+                }
+                if (nd.absorbed_by >= 0 && ND[nd.absorbed_by].bb_a == i) break;            // first conv of a chained BasicBlock: its int8 input is made in the launch
                 {   // stage chain (f8_chain.hip): the tensors between its blocks exist in no form at all; an identity first block
                     // reads only the int32 form of the stage input (its int8 copy is made in the launch)
                     const int host = nd.absorbed_by >= 0 && ND[nd.absorbed_by].fb_a == i ? nd.absorbed_by : -1;   // nd = body.0 of an identity block
@@ -1042,6 +1112,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         if (nd.kind == N_ADD && nd.fused_into >= 0) continue;
         if (nd.kind == N_CONV && (nd.absorbed_by >= 0 || nd.dual_host >= 0)) continue;
         if (nd.kind == N_CONV && nd.chain_into >= 0 && nd.chain_into != i) continue;      // runs inside the chain launch of a later block
+        if (nd.kind == N_CONV && nd.bchain_into >= 0 && nd.bchain_into != i) continue;
         if (nd.kind == N_MAXPOOL && nd.sp_conv >= 0) continue;
         Step st; st.node = i;
         std::vector<int> extra;
@@ -1081,6 +1152,37 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     st.bytes_const = (double)nd.coutP * (nd.ktot + 4);
                     st.name = "stem7x7s2+maxpool3x3s2:" + tname(net, nd.out) + "+" + tname(net, pl.out);
                     st.kernel = "f8::stem_pool_kernel";
+                    break;
+                }
+                if (nd.bchain_into == i) {
+                    // ---- BasicBlock chain: nd is the second conv of its LAST block
+                    const std::vector<int> ch = nd.bchain;
+                    Node& f2 = ND[ch[0]]; Node& f1 = ND[f2.bb_a];
+                    Tensor& x = T[f1.a];
+                    st.kind = S_BCHAIN;
+                    st.src_t = f1.a; st.src_f = find_form(x, FORM_I32, 0, 0);
+                    double ops = 0, wbytes = 0;
+                    for (int hi : ch) {
+                        Node* cv[2] = {&ND[ND[hi].bb_a], &ND[hi]};
+                        for (Node* c : cv) {
+                            pack_conv_weights(net, *c, T[c->a], T[c->out]);
+                            pack_frag_weights(net, *c);
+                            ops += 2.0 * T[c->out].H * T[c->out].W * 9.0 * c->cd.cin * c->cd.cout;
+                            wbytes += (double)c->coutP * (c->ktot + 4);
+                        }
+                    }
+                    out_t = ND[nd.fused_add].out;
+                    select_outputs(net, out_t, &st.out, &extra);
+                    Tensor& o = T[out_t];
+                    const double px = (double)x.H * x.W;
+                    double b = px * x.Cs * 4;
+                    if (st.out.f32 >= 0) b += px * o.Cs * 4;
+                    for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += px * o.Cs;
+                    st.ops_per_img = ops; st.bytes_per_img = b; st.bytes_const = wbytes;
+                    st.name = "basic_chain_x" + std::to_string(ch.size()) + ":" + tname(net, f1.out) + ".." + tname(net, nd.out);
+                    char kb[160];
+                    snprintf(kb, sizeof kb, "f8::bchain_kernel<%d, %d, %d, %d, 2, 3, true>", x.C, x.W, x.H, x.C == 64 ? 8 : 7);   // keep in sync with launch_bchain
+                    st.kernel = kb;
                     break;
                 }
                 if (nd.chain_into == i) {
@@ -1611,7 +1713,7 @@ int f8_net_upload(f8_net* net) {
     if ((e = hipMalloc((void**)&net->d_err, 256)) != hipSuccess) return hip_fail(e, "hipMalloc(error words)");
     if ((e = hipMemset(net->d_err, 0, 256)) != hipSuccess) return hip_fail(e, "hipMemset(error words)");
     for (const Step& st : net->steps)
-        if (st.kind == S_CHAIN && !net->d_chain) {
+        if ((st.kind == S_CHAIN || st.kind == S_BCHAIN) && !net->d_chain) {
             net->chain_stride = round_up_z(4096 + kChainXchgBytes, 4096);
             if ((e = hipMalloc((void**)&net->d_chain, net->chain_stride * parts_cap)) != hipSuccess) return hip_fail(e, "hipMalloc(chain scratch)");
             if ((e = hipMemset(net->d_chain, 0, net->chain_stride * parts_cap)) != hipSuccess) return hip_fail(e, "hipMemset(chain scratch)");
@@ -1827,6 +1929,40 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             a.xchg = (int8_t*)(net->d_chain + (size_t)part * net->chain_stride + 4096);
             a.timeout_ticks = (uint32_t)std::min<long long>((long long)net->opt.chain_timeout_ms * 100000ll, 0x7fffffffll);
             e = launch_chain(a, C, MID, x.H, x.W, a0.cd.cin, s);
+            break;
+        }
+        case S_BCHAIN: {
+            const std::vector<int>& ch = nd.bchain;
+            BChainArgs a{};
+            a.nblk = (int)ch.size();
+            auto fmt = [&](const Node& cons, const Tensor& src, int32_t* n, int32_t* lo, int32_t* hi, uint32_t* x_or) {
+                int nn = 0; consumer_format(src, cons.cd, &nn, "run");
+                *n = nn; *lo = cons.cd.input_signed ? -127 : 0; *hi = cons.cd.input_signed ? 127 : 255;
+                *x_or = cons.cd.input_signed ? 0u : 0x80808080u;
+            };
+            for (int k = 0; k < a.nblk; ++k) {
+                const Node& c2 = net->nodes[ch[k]]; const Node& c1 = net->nodes[c2.bb_a];
+                BChainBlk& B = a.blk[k];
+                B.wa = (const int8_t*)(net->d_w + c1.wf_off); B.wb = (const int8_t*)(net->d_w + c2.wf_off);
+                B.ba = (const int32_t*)(net->d_w + c1.b_off); B.bb = (const int32_t*)(net->d_w + c2.b_off);
+                const Tensor& xin = T[c1.a];
+                fmt(c1, xin, &B.nq, &B.loq, &B.hiq, &B.xorq);
+                fmt(c2, T[c2.a], &B.n1, &B.lo1, &B.hi1, &B.xor1);
+                B.relu_a = c1.cd.relu; B.relu1 = net->nodes[c2.fused_add].relu;
+                const int dfl = T[c2.out].fl - xin.fl;
+                B.acc_shl = dfl < 0 ? -dfl : 0; B.res_shl = dfl > 0 ? dfl : 0;
+            }
+            const Tensor& x = T[st.src_t];
+            a.xr = (const int32_t*)fp(x.forms[st.src_f]);
+            const int tiles = bchain_tiles_per_img(x.C, x.H, x.W);
+            a.N = N; a.NG = std::max(1, std::min(N, (net->num_cu > 0 ? std::min(net->num_cu, 256) : 256) / tiles));
+            fill_out(&a.out32, a.q);
+            if (!net->d_chain) return fail(F8_ERR_STATE, "f8_net_run: chain scratch missing");
+            a.sync = (uint32_t*)(net->d_chain + (size_t)part * net->chain_stride);
+            a.err = a.sync + 512;
+            a.xchg = (int8_t*)(net->d_chain + (size_t)part * net->chain_stride + 4096);
+            a.timeout_ticks = (uint32_t)std::min<long long>((long long)net->opt.chain_timeout_ms * 100000ll, 0x7fffffffll);
+            e = launch_bchain(a, x.C, x.H, x.W, s);
             break;
         }
         case S_P12: {

@@ -133,3 +133,82 @@ def test_stage_chain_matches_oracle(dev, cfg, variant, tail):
         got2 = net.run(_t(x[:N - 1], dev)).cpu().numpy().reshape((N - 1,) + w.shape[1:])
         net.check()
         np.testing.assert_array_equal(got2, w[:N - 1])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# BasicBlock chains (f8_bchain.hip): ResNet-18 / 34 identity blocks of one stage in one launch
+def _basic_stage(C, nblk, variant):
+    blocks, fls = [], {}
+    for k in range(nblk):
+        name = f'b.{k}'
+        body = [topology.ConvSpec(name + '.body.0', C, C, 3, 1, 1, relu=True), topology.ConvSpec(name + '.body.2', C, C, 3, 1, 1)]
+        blocks.append(topology.BlockSpec(name, body, None, residual=True, post_relu=True))
+        if variant == 'acc_shifts_left':
+            fls[name + '.body.0'], fls[name + '.body.2'] = (4, 7), (3, 5 + (k % 2))
+        else:
+            fls[name + '.body.0'], fls[name + '.body.2'] = (4, 7), (min(5 + k, 7), 7)
+    return blocks, fls
+
+
+BCHAINS = [(64, 56, 2, 3), (64, 56, 3, 40), (128, 28, 1, 5), (128, 28, 2, 70), (256, 14, 1, 4), (256, 14, 3, 131)]   # C, H = W, blocks, N
+
+
+@pytest.mark.parametrize('cfg', BCHAINS, ids=lambda g: 'x'.join(map(str, g)))
+@pytest.mark.parametrize('variant', ['acc_shifts_left', 'res_shifts_left'])
+@pytest.mark.parametrize('tail', ['int32_out', 'int8_out'])
+def test_basic_block_chain_matches_oracle(dev, cfg, variant, tail):
+    C, HW, nblk, N = cfg
+    if tail == 'int8_out' and N > 8:
+        pytest.skip('the int8 tails are covered at the small batch')
+    blocks, fls = _basic_stage(C, nblk, variant)
+    convs = [c for b in blocks for c in b.body]
+    t0 = topology.ConvSpec('tail.0', C, 64, 1, 1, 0)
+    t1 = topology.ConvSpec('tail.1', C, 32, 1, 1, 0)
+    fls['tail.0'], fls['tail.1'] = (3, 6), (5, 7)
+    params = _params(convs + [t0, t1], fls, 31, variant)
+    x_fl = 9
+    x = synth.rand_normal_int(17, 'bchainx' + variant, (N, C, HW, HW), 3.0e3).astype(np.int32)
+    x.reshape(-1)[:3] = [2**31 - 1, -2**31, 2**30]
+    pre = topology.ConvSpec('pre.0', C, C, 1, 1, 0)              # a conv in front: the chain's input is not the network input
+    fls['pre.0'] = (4, 7)
+    params.update(_params([pre], fls, 33, variant))
+
+    net = F8Net()
+    t = net.input(C, HW, HW, x_fl)
+    r = net.conv(t, params['pre.0.weight'], params['pre.0.bias'], stride=1, pad=0, groups=1, weight_fl=7, input_fl=4, input_signed=False,
+                 quant_input=True, relu=True)
+    for b in blocks:
+        xin = r
+        for c in b.body:
+            r = net.conv(r, params[c.key + '.weight'], params[c.key + '.bias'], stride=1, pad=c.pad, groups=1,
+                         weight_fl=fls[c.key][1], input_fl=fls[c.key][0], input_signed=False, quant_input=True, relu=c.relu)
+        r = net.add(r, xin, relu=True)
+    if tail == 'int8_out':
+        # the stage output is only read as int8 (the second format of a downsample block's body.0 / shortcut.0 pair is covered by the
+        # whole-net ResNet-18 goldens: its stage-1 / stage-2 chains write two int8 forms)
+        y0 = net.conv(r, params['tail.0.weight'], params['tail.0.bias'], stride=1, pad=0, groups=1, weight_fl=6, input_fl=3,
+                      input_signed=False, quant_input=True, relu=False)
+        net.output(y0, as_float=False)
+    else:
+        net.output(r, as_float=False)
+    net.finalize(N)
+    plan = net.describe()
+    assert f'basic_chain_x{nblk}' in plan, plan
+    got = net.run(_t(x, dev)).cpu().numpy()
+    net.check()
+
+    w, fl = oracle._conv_layer(pre, params, x, x_fl)
+    w = np.maximum(w, 0)
+    for b in blocks:
+        w, fl = oracle.block_forward(b, params, w, fl)
+    if tail == 'int8_out':
+        w, fl = oracle._conv_layer(t0, params, w, fl)
+        got = got.reshape(N, 64, HW, HW)
+    else:
+        got = got.reshape(N, C, HW, HW)
+    assert net.output_fraclen == fl
+    np.testing.assert_array_equal(got, w)
+    if N > 2:
+        got2 = net.run(_t(x[:N - 1], dev)).cpu().numpy().reshape((N - 1,) + w.shape[1:])
+        net.check()
+        np.testing.assert_array_equal(got2, w[:N - 1])
