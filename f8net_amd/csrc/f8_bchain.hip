@@ -399,13 +399,23 @@ static hipError_t launch_bchain_t(const BChainArgs& a, hipStream_t s) {
 #endif
 }
 
+// K steps per register batch, batches in rotation (NB, NBUF) per instance (tuning builds override)
+#ifndef F8_BCH_S0
+#define F8_BCH_S0 2, 3
+#endif
+#ifndef F8_BCH_S1
+#define F8_BCH_S1 2, 3
+#endif
+#ifndef F8_BCH_S2
+#define F8_BCH_S2 2, 3
+#endif
 hipError_t launch_bchain(const BChainArgs& a, int C, int H, int W, hipStream_t s) {
     if (a.nblk < 1 || a.nblk > kBChainMaxBlocks) return hipErrorInvalidValue;
     const bool fast = bchain_fast(a);
 #define F8_BCH(...) (fast ? launch_bchain_t<__VA_ARGS__, true>(a, s) : launch_bchain_t<__VA_ARGS__, false>(a, s))
-    if (C == 64 && H == 56 && W == 56) return F8_BCH(64, 56, 56, 8, 2, 3);
-    if (C == 128 && H == 28 && W == 28) return F8_BCH(128, 28, 28, 7, 2, 3);
-    if (C == 256 && H == 14 && W == 14) return F8_BCH(256, 14, 14, 7, 2, 3);
+    if (C == 64 && H == 56 && W == 56) return F8_BCH(64, 56, 56, 8, F8_BCH_S0);
+    if (C == 128 && H == 28 && W == 28) return F8_BCH(128, 28, 28, 7, F8_BCH_S1);
+    if (C == 256 && H == 14 && W == 14) return F8_BCH(256, 14, 14, 7, F8_BCH_S2);
 #undef F8_BCH
     return hipErrorInvalidValue;
 }

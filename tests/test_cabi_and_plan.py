@@ -83,8 +83,8 @@ def test_run_without_gpu_fails_loudly():
                                                        ('mobilenet_v2', 39, 0, 0)])
 def test_plan_fuses_requant_relu_residual(arch, launches, fused, dual):
     spec = topology.get(arch)
-    # one launch per block (the stage-chain launches of f8_chain.hip have their own plan test below)
-    net = build_net(spec, synth.make_params(spec, 1), max_batch=8, hw=224, options={'fuse_chain': 0})
+    # one launch per block (the stage-chain launches of f8_chain.hip / f8_bchain.hip have their own plan tests below)
+    net = build_net(spec, synth.make_params(spec, 1), max_batch=8, hw=224, options={'fuse_chain': 0, 'fuse_bchain': 0})
     plan = net.describe()
     assert net.num_launches == launches, plan
     # ResNets: the head (stem conv + max-pool) is one launch, whatever forms (int32 / int8) the pool output needs
@@ -133,6 +133,30 @@ def test_plan_runs_each_stage_as_one_chain_launch():
     for arch in ('resnet18', 'mobilenet_v2'):
         sp = topology.get(arch)
         assert 'stage_chain' not in build_net(sp, synth.make_params(sp, 1), max_batch=8, hw=224).describe()
+
+
+def test_plan_runs_basic_block_stages_as_chain_launches():
+    """Default ResNet-18 plan: the identity BasicBlocks of stages 0-2 (56x56 x 64, 28x28 x 128, 14x14 x 256) that follow one another
+    are ONE launch per stage (f8_bchain.hip: both 3x3 convs of every block, the int32 stream in registers); the downsample blocks
+    and the 7x7 stage keep their per-conv launches.  fuse_bchain = 0 gives the per-conv plan back."""
+    spec = topology.get('resnet18')
+    params = synth.make_params(spec, 1)
+    net = build_net(spec, params, max_batch=8, hw=224)
+    lines = net.describe().splitlines()
+    chains = [l.split()[1] for l in lines if 'basic_chain_x' in l]
+    assert chains == ['basic_chain_x2:stage_0_layer_0.body.0..stage_0_layer_1.body.2',
+                      'basic_chain_x1:stage_1_layer_1.body.0..stage_1_layer_1.body.2',
+                      'basic_chain_x1:stage_2_layer_1.body.0..stage_2_layer_1.body.2'], net.describe()
+    assert net.num_launches == 18
+    # the stem hands the first chain the int32 stream only: the chain makes its own int8 copy
+    stem = [l for l in lines if 'stem7x7s2+maxpool3x3s2' in l]
+    assert len(stem) == 1 and 'i32=1 i8=0' in stem[0]
+    # 7x7 identity block: not chained (49 pixels per image do not fill a tile)
+    assert any('stage_3_layer_1.body.2' in l and '_res:' in l for l in lines)
+    off = build_net(spec, params, max_batch=8, hw=224, options={'fuse_bchain': 0})
+    assert 'basic_chain' not in off.describe() and off.num_launches == 23
+    # a resolution the kernel has no instance for: per-conv plan
+    assert 'basic_chain' not in build_net(spec, params, max_batch=8, hw=96).describe()
 
 
 def test_plan_keeps_int32_only_where_semantics_need_it():
