@@ -23,16 +23,20 @@
 
 namespace f8 {
 
-template <int C, int W, int H, int R>
+template <int C, int W, int H, int R, bool DS = false>
 struct BChainCfg {
     static constexpr int T = (H + R - 1) / R;
     static constexpr int PX = R * W, NPT = (PX + 31) / 32;
     static constexpr int PW = W + 2, PR = R + 2, CS = C + 16;          // patch entry stride: padded, see f8_chain.hip
     static constexpr int PATCH_BYTES = (PR * PW * CS + 255) / 256 * 256;
-    static constexpr int BIAS_BYTES = kBChainMaxBlocks * 2 * C * 4;
-    static constexpr int LDS_BYTES = 2 * PATCH_BYTES + BIAS_BYTES + 256;
+    // stage-opening block (DS): its int8 input at twice the resolution, half the channels: rows 2 p0 - 1 .. 2 (p0 + R) - 1, columns -1 .. 2 W - 1
+    static constexpr int CIN = C / 2, PWI = 2 * W + 1, PRI = 2 * R + 1, IS = CIN + 16;
+    static constexpr int PATCHI_BYTES = DS ? (PRI * PWI * IS + 255) / 256 * 256 : 0;
+    static constexpr int BIAS_BYTES = (kBChainMaxBlocks * 2 + 1) * C * 4;      // per block ba | bb, then the opening block's shortcut bias
+    static constexpr int LDS_BYTES = 2 * PATCH_BYTES + PATCHI_BYTES + BIAS_BYTES + 256;
     static constexpr int ROWB = W * C;
     static_assert(LDS_BYTES <= 160 * 1024 && PATCH_BYTES < 65536, "LDS / immediate offsets");
+    static_assert(!DS || PX * IS <= PATCH_BYTES, "the shortcut's operand borrows patchX");
     static_assert(ROWB / 16 <= 256 && (size_t)256 * 4 * ROWB <= kChainXchgBytes, "one 16-byte piece of a halo row per thread of a half workgroup");
 };
 
@@ -55,21 +59,25 @@ __device__ __forceinline__ v4i bquant_tile16(const Y& y, int n, int lo, int hi, 
 __device__ __forceinline__ int bopaque(int v) { asm volatile("" : "+s"(v)); return v; }
 
 // FAST: ReLU after the first conv and after the join, every int8 format of the chain unsigned with a right shift, the stream never shifted
-template <int C, int W, int H, int R, int NB, int NBUF, bool FAST>
+// DS: the chain starts with the stage-opening block (3x3 / 2 -> 3x3, 1x1 / 2 shortcut; C / 2 input channels at twice the resolution)
+template <int C, int W, int H, int R, int NB, int NBUF, bool FAST, bool DS>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 bchain_kernel(const BChainArgs a) {
-    using Cfg = BChainCfg<C, W, H, R>;
+    using Cfg = BChainCfg<C, W, H, R, DS>;
     constexpr int T = Cfg::T, NPT = Cfg::NPT, PW = Cfg::PW, CS = Cfg::CS, ROWB = Cfg::ROWB;
     constexpr int CT = C / 32, PG = 8 / CT, NPW = (NPT + PG - 1) / PG;
-    constexpr int NK = 9 * CT, NBAT = NK / NB, BPTAP = CT / NB;
+    constexpr int CTI = Cfg::CIN / 32, PWI = Cfg::PWI, IS = Cfg::IS;
     static_assert(CT == 2 || CT == 4 || CT == 8, "8 waves = CT channel tiles x PG pixel-tile groups");
-    static_assert(NB <= CT && CT % NB == 0, "a batch of K steps stays inside one tap");
+    static_assert(NB <= CT && CT % NB == 0 && (!DS || (NB <= CTI && CTI % NB == 0)), "a batch of K steps stays inside one tap");
     static_assert(NPW <= 4, "stream + accumulators in registers");
+    using ic_ct = std::integral_constant<int, CT>;
+    using ic_cti = std::integral_constant<int, CTI>;
 
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const patchX = lds;                                   // [(R+2)][(W+2)][CS]: int8 copy of the stream in the first conv's input format, with halo
     char* const patchM = lds + Cfg::PATCH_BYTES;                // the same for `mid`
-    int* const bias_lds = (int*)(lds + 2 * Cfg::PATCH_BYTES);   // per block: ba | bb
+    char* const patchI = lds + 2 * Cfg::PATCH_BYTES;            // DS: [(2R+1)][(2W+1)][IS]: the opening block's int8 input
+    int* const bias_lds = (int*)(lds + 2 * Cfg::PATCH_BYTES + Cfg::PATCHI_BYTES);   // per block: ba | bb; then bsc
     int* const misc = bias_lds + Cfg::BIAS_BYTES / 4;
 
     const int tid = threadIdx.x;
@@ -81,6 +89,7 @@ bchain_kernel(const BChainArgs a) {
         const BChainBlk& B = a.blk[b];
         for (int i = tid; i < 2 * C; i += 512) bias_lds[b * 2 * C + i] = i < C ? B.ba[i] : B.bb[i - C];
     }
+    if constexpr (DS) for (int i = tid; i < C; i += 512) bias_lds[kBChainMaxBlocks * 2 * C + i] = a.bsc[i];
     __syncthreads();
     const int L = __builtin_amdgcn_readfirstlane(misc[0]);
     const int grp = L / T, ti = L - grp * T;
@@ -105,25 +114,34 @@ bchain_kernel(const BChainArgs a) {
     _Pragma("unroll") for (int j = 0; j < NPW; ++j) { const int pt = (pg + PG * j) < NPT ? (pg + PG * j) : NPT - 1; bpix[j] = pt * 32 + l31; } \
     (void)lane; (void)lh; (void)bpix
 
-    int res[NPW][16];                                           // the stream: this wave's channel tile x its pixel tiles (a missing tile repeats the last one)
+    v16i res[NPW];                                              // the stream: this wave's channel tile x its pixel tiles (a missing tile repeats the last one)
     v4i wbuf[NBUF][NB];
     unsigned seq = 0;
     bool failed = false;
 
+#ifndef F8_BCH_ABL_NOW
     auto ldw = [](const int8_t* base, int soff, unsigned voff) { return *(const v4i*)(base + bopaque(soff) + voff); };
+#else
+    auto ldw = [](const int8_t* base, int soff, unsigned voff) { const int q = (int)(size_t)base + soff + (int)voff; const v4i r = {q, q, q, q}; return r; };
+#endif
     auto tap_at = [](int t) constexpr { return t < 3 ? t + 3 : (t < 6 ? t - 3 : t); };       // centre row first: it reads no halo row
-    auto w_load = [&](const int8_t* w, v4i (&dst)[NB], int bi, unsigned wl) {
-        const int k0 = tap_at(bi / BPTAP) * CT + (bi % BPTAP) * NB;
+    // ctk: K steps per tap (input channels / 32) of the conv the weights belong to
+    auto w_load = [&](auto ctk, const int8_t* w, v4i (&dst)[NB], int bi, unsigned wl) {
+        constexpr int CTK = decltype(ctk)::value, BPTAP = CTK / NB;
+        const int k0 = tap_at(bi / BPTAP) * CTK + (bi % BPTAP) * NB;
 #pragma unroll
-        for (int s = 0; s < NB; ++s) dst[s] = ldw(w, (k0 + s) * 1024, (unsigned)(ct * NK * 1024) + wl);
+        for (int s = 0; s < NB; ++s) dst[s] = ldw(w, (k0 + s) * 1024, (unsigned)(ct * 9 * CTK * 1024) + wl);
     };
-    auto w_prime = [&](const int8_t* w, unsigned wl) {
-        static_for<NBUF - 1>([&](auto bc) { constexpr int Bi = decltype(bc)::value; w_load(w, wbuf[Bi], Bi, wl); });
+    auto w_prime = [&](auto ctk, const int8_t* w, unsigned wl) {
+        static_for<NBUF - 1>([&](auto bc) { constexpr int Bi = decltype(bc)::value; w_load(ctk, w, wbuf[Bi], Bi, wl); });
     };
 
     // ---- halo rows of `patch`: publish this tile's first / last row
     auto publish = [&](char* patch) {
         if constexpr (T > 1) {
+#ifdef F8_TRACE
+            const unsigned long long tp0 = __builtin_readcyclecounter();
+#endif
             ++seq;
             constexpr int RCH = ROWB / 16, CPE = C / 16;
             const __amdgpu_buffer_rsrc_t rxc = __builtin_amdgcn_make_buffer_rsrc((void*)a.xchg, 0, (unsigned)kChainXchgBytes, 0x00020000);
@@ -138,11 +156,17 @@ bchain_kernel(const BChainArgs a) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) __hip_atomic_store(flags + L, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef F8_TRACE
+            tt[4] += __builtin_readcyclecounter() - tp0;
+#endif
         }
     };
     // ... and fetch the neighbours' rows into the patch's halo rows (called inside the K loop, after the centre-row taps)
     auto consume = [&](char* patch) {
         if constexpr (T > 1) {
+#ifdef F8_TRACE
+            const unsigned long long tc0 = __builtin_readcyclecounter();
+#endif
             constexpr int RCH = ROWB / 16, CPE = C / 16;
             int t2 = tid; asm volatile("" : "+v"(t2));
             if ((t2 == 0 && has_up) || (t2 == 256 && has_dn)) {
@@ -165,12 +189,22 @@ bchain_kernel(const BChainArgs a) {
                 const int col = idx / CPE, c16 = idx % CPE;
                 *(v4i*)(patch + ((side == 0 ? 0 : rows + 1) * PW + col + 1) * CS + c16 * 16) = v;
             }
+#ifdef F8_TRACE
+            tt[6] += __builtin_readcyclecounter() - tc0;
+#endif
             __syncthreads();
+#ifdef F8_TRACE
+            tt[5] += __builtin_readcyclecounter() - tc0;
+#endif
         }
     };
 
     // ---- one 3x3: acc[j] (started at the bias) += W . patch taps; the halo rows of `patch` are fetched in front of the first tap that reads one
-    auto conv3x3 = [&](char* patch, const int8_t* w, const int* bias, v16i (&acc)[NPW]) {
+    //      (opening block's first conv: stride 2 over patchI, no halo rows: the tile read all its input rows itself)
+    auto conv3x3 = [&](auto ctk, auto first_ds, char* patch, const int8_t* w, const int* bias, v16i (&acc)[NPW]) {
+        constexpr int CTK = decltype(ctk)::value, NK = 9 * CTK, NBAT = NK / NB;
+        constexpr bool S2 = decltype(first_ds)::value;
+        constexpr int PWp = S2 ? PWI : PW, CSp = S2 ? IS : CS, STR = S2 ? 2 : 1;
         F8_BLANES;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -185,38 +219,52 @@ bchain_kernel(const BChainArgs a) {
         for (int j = 0; j < NPW; ++j) {
             const int oc = bpix[j] < npx ? bpix[j] : npx - 1;                    // padding lanes read a valid pixel, result unused
             const int orow = oc / W, ocol = oc - orow * W;
-            bpb[j] = (unsigned)((orow * PW + ocol) * CS + lh * 16);
+            bpb[j] = (unsigned)((orow * STR * PWp + ocol * STR) * CSp + lh * 16);
         }
         auto rd = [&](v4i (&xf)[NPW], auto gc) {
-            constexpr int G = decltype(gc)::value, TAP = tap_at(G / CT), CI = G % CT;
+            constexpr int G = decltype(gc)::value, TAP = tap_at(G / CTK), CI = G % CTK;
 #pragma unroll
-            for (int j = 0; j < NPW; ++j) xf[j] = *(const v4i*)(patch + bpb[j] + ((TAP / 3) * PW + TAP % 3) * CS + CI * 32);
+            for (int j = 0; j < NPW; ++j) xf[j] = *(const v4i*)(patch + bpb[j] + ((TAP / 3) * PWp + TAP % 3) * CSp + CI * 32);
         };
         const unsigned wl = (unsigned)(lane * 16);
-        constexpr int GH = T > 1 ? 3 * CT : NK + 1;                              // first step of a tap that reads a halo row
+        constexpr int GH = (T > 1 && !S2) ? 3 * CTK : NK + 1;                    // first step of a tap that reads a halo row
         v4i xfa[NPW], xfb[NPW];
         rd(xfa, std::integral_constant<int, 0>{});
         static_for<NK>([&](auto gc) {
             constexpr int G = decltype(gc)::value, Bi = G / NB, S = G % NB;
-            if constexpr (S == 0 && Bi + NBUF - 1 < NBAT) w_load(w, wbuf[(Bi + NBUF - 1) % NBUF], Bi + NBUF - 1, wl);
+            if constexpr (S == 0 && Bi + NBUF - 1 < NBAT) w_load(ctk, w, wbuf[(Bi + NBUF - 1) % NBUF], Bi + NBUF - 1, wl);
             v4i (&cur)[NPW] = (G & 1) ? xfb : xfa;
             v4i (&nxt)[NPW] = (G & 1) ? xfa : xfb;
+#ifndef F8_BCH_ABL_NOB
             if constexpr (G == GH) { consume(patch); rd(cur, gc); }
             if constexpr (G + 1 < NK && G + 1 != GH) rd(nxt, std::integral_constant<int, G + 1>{});
+#else
+            if constexpr (G == GH) { consume(patch); }
+#endif
 #pragma unroll
             for (int j = 0; j < NPW; ++j) asm volatile("" : "+v"(cur[j]));
 #pragma unroll
-            for (int j = 0; j < NPW; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Bi % NBUF][S], cur[j], acc[j], 0, 0, 0);
+            for (int j = 0; j < NPW; ++j) {
+#ifndef F8_BCH_ABL_NOMMA
+                acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Bi % NBUF][S], cur[j], acc[j], 0, 0, 0);
+#else
+                asm volatile("" :: "v"(wbuf[Bi % NBUF][S]), "v"(cur[j]));
+#endif
+            }
         });
     };
 
     for (int n = grp; n < a.N; n += a.NG) {
         const int m_tile = (n * H + p0) * W;
         const BChainBlk& B0 = a.blk[0];
-        {   // ---- stage input -> registers; its int8 copy -> patchX interior; both patches' borders <- biased zero
-            F8_BLANES;
-            const v4i zx = {(int)B0.xorq, (int)B0.xorq, (int)B0.xorq, (int)B0.xorq};
+        auto fill_patchX = [&] {   // patchX <- biased zero (border; the interior is written before it is read)
+            const unsigned zq = FAST ? 0x80808080u : a.blk[DS && a.nblk > 1 ? 1 : 0].xorq;
+            const v4i zx = {(int)zq, (int)zq, (int)zq, (int)zq};
             for (int o = tid * 16; o < Cfg::PATCH_BYTES; o += 512 * 16) *(v4i*)(patchX + o) = zx;
+        };
+        if constexpr (!DS) fill_patchX();
+        if constexpr (!DS) {   // ---- stage input (int32 stream) -> registers; its int8 copy -> patchX interior
+            F8_BLANES;
             const __amdgpu_buffer_rsrc_t rxr = __builtin_amdgcn_make_buffer_rsrc((void*)a.xr, 0, (unsigned)(((a.N * H * W + 31) & ~31) * C * 4), 0x00020000);
 #pragma unroll
             for (int j = 0; j < NPW; ++j) {
@@ -229,7 +277,7 @@ bchain_kernel(const BChainArgs a) {
                     for (int e = 0; e < 4; ++e) res[j][4 * g + e] = v[e];
                 }
             }
-            w_prime(B0.wa, (unsigned)(lane * 16));
+            w_prime(ic_ct{}, B0.wa, (unsigned)(lane * 16));
             __syncthreads();                                    // the zero fill is complete
 #pragma unroll
             for (int j = 0; j < NPW; ++j) {
@@ -237,9 +285,37 @@ bchain_kernel(const BChainArgs a) {
                 const v4i o = bquant_tile16<FAST>(res[j], B0.nq, FAST ? 0 : B0.loq, FAST ? 255 : B0.hiq, FAST ? 0x80808080u : B0.xorq);
                 if (pix < npx) *(v4i*)(patchX + ((pr + 1) * PW + pc + 1) * CS + ct * 32 + lh * 16) = o;
             }
+            __syncthreads();
+            publish(patchX);
+        } else {               // ---- opening block: its int8 input rows (NHWC, twice the resolution) -> patchI; left column / rows outside the image <- biased zero
+            constexpr int CPI = Cfg::CIN / 16, RCHI = 2 * W * CPI, NPC = Cfg::PRI * RCHI, PER = (NPC + 511) / 512;
+            const int8_t* const xin = a.x8in + (size_t)n * (2 * H) * (2 * W) * Cfg::CIN;
+            const int r0 = 2 * p0 - 1, nr = 2 * rows + 1;
+            const v4i zi = {(int)B0.xorq, (int)B0.xorq, (int)B0.xorq, (int)B0.xorq};
+            int t3 = tid; asm volatile("" : "+v"(t3));
+            v4i v[PER];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int idx = t3 + k * 512, pr = idx / RCHI, pc = idx - pr * RCHI;
+                const int ir = r0 + pr;
+                v[k] = zi;
+                if (idx < NPC && pr < nr && ir >= 0 && ir < 2 * H) v[k] = *(const v4i*)(xin + (size_t)ir * (2 * W * Cfg::CIN) + pc * 16);
+            }
+            w_prime(ic_cti{}, B0.wa, (unsigned)((t3 & 63) * 16));
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int idx = t3 + k * 512, pr = idx / RCHI, pc = idx - pr * RCHI;
+                if (idx < NPC) *(v4i*)(patchI + (pr * PWI + pc / CPI + 1) * IS + (pc % CPI) * 16) = v[k];
+            }
+            for (int idx = t3; idx < Cfg::PRI * CPI; idx += 512) *(v4i*)(patchI + ((idx / CPI) * PWI) * IS + (idx % CPI) * 16) = zi;
+            // the shortcut's operand: the pixels (2r, 2c) of the block input in the SHORTCUT's int8 format -> [R][W][IS] where patchX will be
+            const int8_t* const xsc = a.x8sc + (size_t)n * (2 * H) * (2 * W) * Cfg::CIN;
+            for (int idx = t3; idx < npx * CPI; idx += 512) {
+                const int px = idx / CPI, c16 = idx - px * CPI, pr = px / W, pc = px - pr * W;
+                *(v4i*)(patchX + px * IS + c16 * 16) = *(const v4i*)(xsc + ((size_t)(2 * (p0 + pr)) * (2 * W) + 2 * pc) * Cfg::CIN + c16 * 16);
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        publish(patchX);
         F8_BT(0);
 
         for (int b = 0; b < a.nblk; ++b) {
@@ -261,9 +337,44 @@ bchain_kernel(const BChainArgs a) {
                     for (int o = tid * 16; o < Cfg::PATCH_BYTES; o += 512 * 16) *(v4i*)(patchM + o) = zm;
                 }
                 v16i acc[NPW];
-                conv3x3(patchX, B.wa, bl, acc);
-                { F8_BLANES; w_prime(B.wb, (unsigned)(lane * 16));
+                bool opened = false;
+                if constexpr (DS) {
+                    if (b == 0) {
+                        // the opening block: 3x3 / 2 over patchI, then the 1x1 / 2 shortcut INTO THE STREAM
+                        opened = true;
+                        v4i wsc[CTI];
+                        { F8_BLANES;
+#pragma unroll
+                          for (int k = 0; k < CTI; ++k) wsc[k] = ldw(a.wsc, k * 1024, (unsigned)(ct * CTI * 1024) + (unsigned)(lane * 16)); }
+                        conv3x3(ic_cti{}, std::true_type{}, patchI, B.wa, bl, acc);
+                        F8_BLANES;
+                        w_prime(ic_ct{}, B.wb, (unsigned)(lane * 16));
+                        const int* const bsc = bias_lds + kBChainMaxBlocks * 2 * C;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const v4i bv = *(const v4i*)(bsc + ct * 32 + 8 * g + 4 * lh);
+#pragma unroll
+                            for (int j = 0; j < NPW; ++j)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) res[j][4 * g + e] = bv[e];
+                        }
+#pragma unroll
+                        for (int k = 0; k < CTI; ++k)
+#pragma unroll
+                            for (int j = 0; j < NPW; ++j) {
+                                const int oc = bpix[j] < npx ? bpix[j] : npx - 1;
+                                const v4i xf = *(const v4i*)(patchX + oc * IS + lh * 16 + k * 32);
+                                res[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wsc[k], xf, res[j], 0, 0, 0);
+                            }
+                    }
+                }
+                if (!opened) {
+                    conv3x3(ic_ct{}, std::false_type{}, patchX, B.wa, bl, acc);
+                    F8_BLANES; w_prime(ic_ct{}, B.wb, (unsigned)(lane * 16));
+                }
+                { F8_BLANES;
                 __syncthreads();                                // the zero fill is complete (T == 1: there was no hand-over barrier)
+                if constexpr (DS) { if (b == 0) fill_patchX(); } // the shortcut's operand has been read by every wave; the barrier in front of publish() follows
                 const int floor0 = relu_a ? 0 : INT32_MIN;
 #pragma unroll
                 for (int j = 0; j < NPW; ++j) {
@@ -282,17 +393,17 @@ bchain_kernel(const BChainArgs a) {
 
             {   // ============ second conv + join: stream' = clamp((conv3x3(mid) + bb) << sa + (stream << sr)) [ReLU]; x8' = requant(stream') -> patchX
                 v16i acc[NPW];
-                conv3x3(patchM, B.wb, bl + C, acc);
+                conv3x3(ic_ct{}, std::false_type{}, patchM, B.wb, bl + C, acc);
                 F8_BLANES;
-                if (!last) w_prime(BN.wa, (unsigned)(lane * 16));
+                if (!last) w_prime(ic_ct{}, BN.wa, (unsigned)(lane * 16));
                 const int floor1 = relu1 ? 0 : -2147483647;
 #pragma unroll
                 for (int j = 0; j < NPW; ++j) {
                     const int pix = bpix[j], pr = pix / W, pc = pix - pr * W;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        if constexpr (FAST) res[j][r] = max((int)(((unsigned)acc[j][r] << acc_shl) + (unsigned)res[j][r]), 0);
-                        else res[j][r] = max((int)(((unsigned)acc[j][r] << acc_shl) + ((unsigned)res[j][r] << res_shl)), floor1);
+                        if constexpr (FAST && !DS) res[j][r] = max((int)(((unsigned)acc[j][r] << acc_shl) + (unsigned)res[j][r]), 0);
+                        else res[j][r] = max((int)(((unsigned)acc[j][r] << acc_shl) + ((unsigned)res[j][r] << res_shl)), FAST ? 0 : floor1);
                     }
                     if (!last || a.q[0].ptr) {
                         const v4i o = bquant_tile16<FAST>(res[j], nq, loq, hiq, xorq);
@@ -340,7 +451,7 @@ bchain_kernel(const BChainArgs a) {
 #ifdef F8_TRACE
     if (a.trace && tid == 0) {
         unsigned long long* tp = (unsigned long long*)a.trace + (size_t)blockIdx.x * 8;
-        for (int i = 0; i < 4; ++i) tp[i] = tt[i];
+        for (int i = 0; i < 8; ++i) tp[i] = tt[i];
     }
 #endif
 }
@@ -353,23 +464,27 @@ static int bchain_rows(int C, int H, int W) {
     return 0;
 }
 bool bchain_supported(int C, int H, int W) { return bchain_rows(C, H, W) > 0; }
+// ... starting with the stage-opening block (input 2H x 2W x C/2): the 28x28 and 14x14 stages
+bool bchain_ds_supported(int C, int H, int W) { return bchain_rows(C, H, W) > 0 && C >= 128; }
 int bchain_tiles_per_img(int C, int H, int W) { const int r = bchain_rows(C, H, W); return r ? (H + r - 1) / r : 0; }
 
 bool bchain_fast(const BChainArgs& a) {
     for (int k = 0; k < a.nblk; ++k) {
         const BChainBlk& B = a.blk[k];
-        if (!(B.relu_a && B.relu1 && B.n1 > 0 && B.nq > 0 && B.lo1 == 0 && B.loq == 0 && B.res_shl == 0)) return false;
+        if (!(B.relu_a && B.relu1 && B.n1 > 0 && B.lo1 == 0)) return false;
+        if (k == 0 && a.x8in) continue;                      // opening block: its input arrives as int8, its join shifts either operand
+        if (!(B.nq > 0 && B.loq == 0 && B.res_shl == 0)) return false;
     }
     if (a.q[0].ptr && !(a.q[0].n > 0 && a.q[0].lo == 0)) return false;
     return true;
 }
 
-template <int C, int W, int H, int R, int NB, int NBUF, bool FAST>
+template <int C, int W, int H, int R, int NB, int NBUF, bool FAST, bool DS>
 static hipError_t launch_bchain_t(const BChainArgs& a, hipStream_t s) {
-    using Cfg = BChainCfg<C, W, H, R>;
+    using Cfg = BChainCfg<C, W, H, R, DS>;
     static unsigned long long attr_done = 0; int attr_dev = -1;
     if (!dyn_lds_opted_in(&attr_done, &attr_dev)) {
-        hipError_t e = hipFuncSetAttribute((const void*)bchain_kernel<C, W, H, R, NB, NBUF, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)bchain_kernel<C, W, H, R, NB, NBUF, FAST, DS>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
         if (attr_dev >= 0) attr_done |= 1ull << attr_dev;
     }
@@ -383,18 +498,18 @@ static hipError_t launch_bchain_t(const BChainArgs& a, hipStream_t s) {
     BChainArgs b = a;
     const bool tracing = (count++ == want);
     if (tracing) { if (!tbuf) (void)hipMalloc((void**)&tbuf, (size_t)1 << 16); (void)hipMemsetAsync(tbuf, 0, (size_t)grid * 64, s); b.trace = tbuf; }
-    hipLaunchKernelGGL((bchain_kernel<C, W, H, R, NB, NBUF, FAST>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, b);
+    hipLaunchKernelGGL((bchain_kernel<C, W, H, R, NB, NBUF, FAST, DS>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, b);
     if (tracing) {
         (void)hipStreamSynchronize(s);
         static unsigned long long hb[256 * 8];
         (void)hipMemcpy(hb, tbuf, (size_t)grid * 64, hipMemcpyDeviceToHost);
-        double ph[4] = {}; for (int i = 0; i < grid; ++i) for (int k = 0; k < 4; ++k) ph[k] += (double)hb[(size_t)i * 8 + k];
-        fprintf(stderr, "[trace bchain<%d,%d>] grid %d, %d blocks, N %d: avg cycles per WG (whole launch): load %.0f | conv A %.0f | conv B + join %.0f | out %.0f\n", C, W, grid,
-                a.nblk, a.N, ph[0] / grid, ph[1] / grid, ph[2] / grid, ph[3] / grid);
+        double ph[8] = {}; for (int i = 0; i < grid; ++i) for (int k = 0; k < 8; ++k) ph[k] += (double)hb[(size_t)i * 8 + k];
+        fprintf(stderr, "[trace bchain<%d,%d>] grid %d, %d blocks, N %d: avg cycles per WG (whole launch): load %.0f | conv A %.0f | conv B + join %.0f | out %.0f || inside: publish %.0f, consume %.0f (of which to the data in LDS %.0f)\n", C, W, grid,
+                a.nblk, a.N, ph[0] / grid, ph[1] / grid, ph[2] / grid, ph[3] / grid, ph[4] / grid, ph[5] / grid, ph[6] / grid);
     }
     return hipGetLastError();
 #else
-    hipLaunchKernelGGL((bchain_kernel<C, W, H, R, NB, NBUF, FAST>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((bchain_kernel<C, W, H, R, NB, NBUF, FAST, DS>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, a);
     return hipGetLastError();
 #endif
 }
@@ -412,11 +527,15 @@ static hipError_t launch_bchain_t(const BChainArgs& a, hipStream_t s) {
 hipError_t launch_bchain(const BChainArgs& a, int C, int H, int W, hipStream_t s) {
     if (a.nblk < 1 || a.nblk > kBChainMaxBlocks) return hipErrorInvalidValue;
     const bool fast = bchain_fast(a);
-#define F8_BCH(...) (fast ? launch_bchain_t<__VA_ARGS__, true>(a, s) : launch_bchain_t<__VA_ARGS__, false>(a, s))
+    const bool ds = a.x8in != nullptr;
+    if (ds ? !(a.x8sc && a.wsc && a.bsc && bchain_ds_supported(C, H, W)) : !a.xr) return hipErrorInvalidValue;
+#define F8_BCH(...) (fast ? launch_bchain_t<__VA_ARGS__, true, false>(a, s) : launch_bchain_t<__VA_ARGS__, false, false>(a, s))
+#define F8_BCHD(...) (fast ? launch_bchain_t<__VA_ARGS__, true, true>(a, s) : launch_bchain_t<__VA_ARGS__, false, true>(a, s))
     if (C == 64 && H == 56 && W == 56) return F8_BCH(64, 56, 56, 8, F8_BCH_S0);
-    if (C == 128 && H == 28 && W == 28) return F8_BCH(128, 28, 28, 7, F8_BCH_S1);
-    if (C == 256 && H == 14 && W == 14) return F8_BCH(256, 14, 14, 7, F8_BCH_S2);
+    if (C == 128 && H == 28 && W == 28) return ds ? F8_BCHD(128, 28, 28, 7, F8_BCH_S1) : F8_BCH(128, 28, 28, 7, F8_BCH_S1);
+    if (C == 256 && H == 14 && W == 14) return ds ? F8_BCHD(256, 14, 14, 7, F8_BCH_S2) : F8_BCH(256, 14, 14, 7, F8_BCH_S2);
 #undef F8_BCH
+#undef F8_BCHD
     return hipErrorInvalidValue;
 }
 

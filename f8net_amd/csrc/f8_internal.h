@@ -24,7 +24,7 @@ struct Options {
     int wstat_fast = 1;          // 0: always the general epilogue (requant in either direction, explicit ReLU floor)
     int s2wreg = 1;              // stride-2 3x3 convs of the stage-2 / stage-3 openers on conv3x3s2_wreg_kernel (f8_s2conv.hip)
     int wreg = 1;                // late 1x1 convs on conv1x1_wreg_kernel (weights straight to registers, f8_wreg.hip)
-    int fuse_bchain = 1;         // consecutive BasicBlock identity blocks of a stage in ONE launch (f8_bchain.hip)
+    int fuse_bchain = 2;         // consecutive BasicBlock identity blocks of a stage in ONE launch (f8_bchain.hip); 2: with the stage-opening block in front of them
     int fuse_chain = 1;          // all consecutive bottleneck blocks of a stage in ONE launch, int32 residual stream in registers (f8_chain.hip)
     int chain_timeout_ms = 2000; // bound of its halo-exchange spins
     int fuse_p12 = 1;            // 7x7 identity blocks: body.0 + body.2 in one launch, split over a workgroup pair per image (f8_p12.hip)
@@ -204,7 +204,11 @@ struct BChainBlk {
 constexpr int kBChainMaxBlocks = 6;
 struct BChainArgs {
     BChainBlk blk[kBChainMaxBlocks]; int32_t nblk;
-    const int32_t* xr;                     // the stage's int32 stream (I32T)
+    const int32_t* xr;                     // the stage's int32 stream (I32T): chains of identity blocks
+    // chains that start with the stage-opening block (blk[0]: wa = 3x3 / 2 over C/2 channels, wb = 3x3, the stream = its 1x1 / 2 shortcut):
+    const int8_t* x8in;                    // int8 NHWC input [N][2H][2W][C/2] in the format blk[0].wa reads
+    const int8_t* x8sc;                    // ... in the format the shortcut reads (may be the same buffer)
+    const int8_t* wsc; const int32_t* bsc; // shortcut conv, fragment order / offset-corrected bias
     int32_t N, NG;
     int32_t* out32; QuantOut q[2];
     uint32_t* sync; uint32_t* err; int8_t* xchg; uint32_t timeout_ticks;   // as ChainArgs
@@ -279,6 +283,7 @@ int chain_tiles_per_img(int H, int W);
 hipError_t launch_chain(const ChainArgs& a, int C, int MID, int H, int W, int cin0, hipStream_t s);
 // consecutive BasicBlock identity blocks of a stage in one launch (f8_bchain.hip)
 bool bchain_supported(int C, int H, int W);
+bool bchain_ds_supported(int C, int H, int W);
 int bchain_tiles_per_img(int C, int H, int W);
 hipError_t launch_bchain(const BChainArgs& a, int C, int H, int W, hipStream_t s);
 // 1x1 -> 3x3 of a 7x7 bottleneck block in one launch (f8_p12.hip); FusedArgs: x8, w0 / b0, w2 / b2, requant 1, q[] = the int8 outputs

@@ -86,6 +86,7 @@ struct Node {
     int chain_into = -1;                 // host conv of a bottleneck block that runs inside a stage-chain launch: the host of the chain's LAST block
     std::vector<int> chain;              // host of the last block of a chain: the hosts of all its blocks, in order (f8_chain.hip)
     int bb_a = -1;                       // second 3x3 of a BasicBlock identity block that runs in a bchain launch: its first 3x3
+    int bds_a = -1, bds_b = -1;          // 1x1 / 2 shortcut conv of a stage-opening BasicBlock that opens a bchain launch: its 3x3 / 2 and its second 3x3
     int bchain_into = -1;                // ... the host (second conv) of the chain's LAST block
     std::vector<int> bchain;             // host of the last block of a BasicBlock chain: the hosts of all its blocks (f8_bchain.hip)
     int p12_a = -1;                      // 3x3 conv hosting "1x1 -> 3x3 in one launch" (f8_p12.hip): its 1x1 producer
@@ -222,7 +223,7 @@ static const OptKey kOptKeys[] = {
     {"fuse_ir", "F8_FUSE_IR", &Options::fuse_ir, 0, 2, true},
     {"fuse_p12", "F8_FUSE_P12", &Options::fuse_p12, 0, 1, true},
     {"fuse_chain", "F8_FUSE_CHAIN", &Options::fuse_chain, 0, 1, true},
-    {"fuse_bchain", "F8_FUSE_BCHAIN", &Options::fuse_bchain, 0, 1, true},
+    {"fuse_bchain", "F8_FUSE_BCHAIN", &Options::fuse_bchain, 0, 2, true},
     {"chain_timeout_ms", "F8_CHAIN_TIMEOUT_MS", &Options::chain_timeout_ms, 1, 1 << 20, false},
     {"wreg", "F8_WREG", &Options::wreg, 0, 1, true},
     {"s2wreg", "F8_S2WREG", &Options::s2wreg, 0, 1, true},
@@ -943,6 +944,40 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 c2.bchain_into = lastn; c2.bb_a = T[c2.a].prod;
                 c1.absorbed_by = h; c1.no_classes = true; c2.no_classes = true;
             }
+            // the stage-opening block in front of them (3x3 / 2 ReLU -> 3x3, 1x1 / 2 shortcut, join) joins the launch when the chain is
+            // the only reader of its output (its two convs over the block input may read different int8 forms of it)
+            [&] {
+                if (opt.fuse_bchain < 2 || (int)hosts.size() >= kBChainMaxBlocks || in_t == net->out_t) return;
+                const Tensor& y = T[in_t];
+                const int c1f = T[ND[i].a].prod, adf = ND[i].fused_add;
+                if (y.consumers.size() != 2 || !((y.consumers[0] == c1f && y.consumers[1] == adf) || (y.consumers[0] == adf && y.consumers[1] == c1f))) return;
+                if (y.prod < 0 || ND[y.prod].kind != N_ADD || ND[y.prod].fused_into < 0) return;
+                const Node& ad = ND[y.prod];
+                const int hi = ad.fused_into;
+                Node& h = ND[hi];
+                if (h.kind != N_CONV || h.fused_add != y.prod || h.bchain_into >= 0 || h.fb_a >= 0 || h.fbd_a >= 0 || h.dual >= 0 || h.dual_host >= 0 ||
+                    h.absorbed_by >= 0 || h.cd.groups != 1 || h.cd.kernel != 1 || h.cd.stride != 2 || h.cd.pad != 0 || h.cd.relu || !h.cd.quant_input) return;
+                const int other = (ad.a == h.out) ? ad.b : ad.a;
+                if (T[other].consumers.size() != 1 || other == net->out_t) return;
+                const int gi = T[other].prod;
+                Node& g = ND[gi];
+                if (g.kind != N_CONV || g.fused_add >= 0 || g.absorbed_by >= 0 || g.dual >= 0 || g.dual_host >= 0 || g.cd.groups != 1 || g.cd.kernel != 3 ||
+                    g.cd.stride != 1 || g.cd.pad != 1 || g.cd.relu || !g.cd.quant_input) return;
+                if (T[g.a].consumers.size() != 1 || g.a == net->out_t) return;
+                const int bi = T[g.a].prod;
+                Node& b0 = ND[bi];
+                if (b0.kind != N_CONV || b0.fused_add >= 0 || b0.absorbed_by >= 0 || b0.dual >= 0 || b0.dual_host >= 0 || b0.cd.groups != 1 || b0.cd.kernel != 3 ||
+                    b0.cd.stride != 2 || b0.cd.pad != 1 || !b0.cd.quant_input || b0.a != h.a) return;
+                const Tensor& x = T[h.a];
+                if (ND[x.prod].kind == N_INPUT || x.H != 2 * y.H || x.W != 2 * y.W) return;
+                if (b0.cd.cin * 2 != C || h.cd.cin * 2 != C || b0.cd.cout != C || g.cd.cin != C || g.cd.cout != C || h.cd.cout != C) return;
+                int na = 0, nh = 0;
+                if (consumer_format(x, b0.cd, &na, "finalize") || consumer_format(x, h.cd, &nh, "finalize")) return;
+                if (!bchain_ds_supported(C, y.H, y.W)) return;
+                h.bds_a = bi; h.bds_b = gi; h.bchain_into = lastn;
+                b0.absorbed_by = hi; g.absorbed_by = hi; b0.no_classes = true; g.no_classes = true;
+                hosts.insert(hosts.begin(), hi);
+            }();
             ND[lastn].bchain = hosts;
         }
     }
@@ -1013,6 +1048,8 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 nd.depthwise = nd.cd.groups != 1;
                 if ((nd.absorbed_by >= 0 && ND[nd.absorbed_by].fbd_b == i) || (nd.dual_host >= 0 && ND[nd.dual_host].fbd_a >= 0)) break;   // DS: in LDS
                 if (nd.p12_a >= 0) break;                    // the 1x1's output lives in LDS inside the launch
+                if (nd.absorbed_by >= 0 && ND[nd.absorbed_by].bds_b == i) break;   // second 3x3 of the opening block of a bchain launch: `mid` lives in LDS
+                                                                 // (its 3x3 / 2 and its shortcut conv each ask for their int8 form of the block input below)
                 if (nd.bb_a >= 0) {                          // second conv of a chained BasicBlock: its source (`mid`) lives in LDS
                     if (bchain_pos(i) == 0) {
                         const Node& ad = ND[nd.fused_add];
@@ -1053,7 +1090,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 } else {
                     add_form(s, FORM_I8, n, nd.cd.input_signed ? 1 : 0);
                 }
-                if (nd.fused_add >= 0 && nd.dual < 0) {
+                if (nd.fused_add >= 0 && nd.dual < 0 && nd.bds_a < 0) {
                     const Node& ad = ND[nd.fused_add];
                     const int other = (ad.a == nd.out) ? ad.b : ad.a;
                     add_form(T[other], FORM_I32, 0, 0);
@@ -1157,31 +1194,39 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 if (nd.bchain_into == i) {
                     // ---- BasicBlock chain: nd is the second conv of its LAST block
                     const std::vector<int> ch = nd.bchain;
-                    Node& f2 = ND[ch[0]]; Node& f1 = ND[f2.bb_a];
+                    Node& f2 = ND[ch[0]];
+                    const bool ds = f2.bds_a >= 0;               // the chain starts with the stage-opening block: f2 is its shortcut conv
+                    Node& f1 = ND[ds ? f2.bds_a : f2.bb_a];
                     Tensor& x = T[f1.a];
                     st.kind = S_BCHAIN;
-                    st.src_t = f1.a; st.src_f = find_form(x, FORM_I32, 0, 0);
+                    st.src_t = f1.a;
+                    if (ds) {
+                        int n0 = 0; consumer_format(x, f1.cd, &n0, "finalize"); st.src_f = find_form(x, FORM_I8, n0, f1.cd.input_signed ? 1 : 0);
+                        int n1 = 0; consumer_format(x, f2.cd, &n1, "finalize"); st.res_t = f1.a; st.res_f = find_form(x, FORM_I8, n1, f2.cd.input_signed ? 1 : 0);
+                    } else st.src_f = find_form(x, FORM_I32, 0, 0);
                     double ops = 0, wbytes = 0;
                     for (int hi : ch) {
-                        Node* cv[2] = {&ND[ND[hi].bb_a], &ND[hi]};
+                        const bool hds = ND[hi].bds_a >= 0;
+                        Node* cv[3] = {&ND[hds ? ND[hi].bds_a : ND[hi].bb_a], hds ? &ND[ND[hi].bds_b] : &ND[hi], hds ? &ND[hi] : nullptr};
                         for (Node* c : cv) {
+                            if (!c) continue;
                             pack_conv_weights(net, *c, T[c->a], T[c->out]);
                             pack_frag_weights(net, *c);
-                            ops += 2.0 * T[c->out].H * T[c->out].W * 9.0 * c->cd.cin * c->cd.cout;
+                            ops += 2.0 * T[c->out].H * T[c->out].W * (double)c->cd.kernel * c->cd.kernel * c->cd.cin * c->cd.cout;
                             wbytes += (double)c->coutP * (c->ktot + 4);
                         }
                     }
                     out_t = ND[nd.fused_add].out;
                     select_outputs(net, out_t, &st.out, &extra);
                     Tensor& o = T[out_t];
-                    const double px = (double)x.H * x.W;
-                    double b = px * x.Cs * 4;
+                    const double px = (double)o.H * o.W;
+                    double b = ds ? (double)x.H * x.W * x.Cs + (st.res_f != st.src_f ? px * x.Cs : 0) : px * x.Cs * 4;
                     if (st.out.f32 >= 0) b += px * o.Cs * 4;
                     for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += px * o.Cs;
                     st.ops_per_img = ops; st.bytes_per_img = b; st.bytes_const = wbytes;
-                    st.name = "basic_chain_x" + std::to_string(ch.size()) + ":" + tname(net, f1.out) + ".." + tname(net, nd.out);
+                    st.name = "basic_chain_x" + std::to_string(ch.size()) + (ds ? "_ds:" : ":") + tname(net, f1.out) + ".." + tname(net, nd.out);
                     char kb[160];
-                    snprintf(kb, sizeof kb, "f8::bchain_kernel<%d, %d, %d, %d, 2, 3, true>", x.C, x.W, x.H, x.C == 64 ? 8 : 7);   // keep in sync with launch_bchain
+                    snprintf(kb, sizeof kb, "f8::bchain_kernel<%d, %d, %d, %d, 2, 3, true, %s>", o.C, o.W, o.H, o.C == 64 ? 8 : 7, ds ? "true" : "false");   // keep in sync with launch_bchain
                     st.kernel = kb;
                     break;
                 }
@@ -1940,20 +1985,27 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
                 *n = nn; *lo = cons.cd.input_signed ? -127 : 0; *hi = cons.cd.input_signed ? 127 : 255;
                 *x_or = cons.cd.input_signed ? 0u : 0x80808080u;
             };
+            const bool ds = net->nodes[ch[0]].bds_a >= 0;
             for (int k = 0; k < a.nblk; ++k) {
-                const Node& c2 = net->nodes[ch[k]]; const Node& c1 = net->nodes[c2.bb_a];
+                const Node& hk = net->nodes[ch[k]];
+                const bool hds = hk.bds_a >= 0;                 // opening block: hk = its shortcut conv
+                const Node& c2 = hds ? net->nodes[hk.bds_b] : hk; const Node& c1 = net->nodes[hds ? hk.bds_a : hk.bb_a];
                 BChainBlk& B = a.blk[k];
                 B.wa = (const int8_t*)(net->d_w + c1.wf_off); B.wb = (const int8_t*)(net->d_w + c2.wf_off);
                 B.ba = (const int32_t*)(net->d_w + c1.b_off); B.bb = (const int32_t*)(net->d_w + c2.b_off);
                 const Tensor& xin = T[c1.a];
                 fmt(c1, xin, &B.nq, &B.loq, &B.hiq, &B.xorq);
                 fmt(c2, T[c2.a], &B.n1, &B.lo1, &B.hi1, &B.xor1);
-                B.relu_a = c1.cd.relu; B.relu1 = net->nodes[c2.fused_add].relu;
-                const int dfl = T[c2.out].fl - xin.fl;
+                B.relu_a = c1.cd.relu; B.relu1 = net->nodes[hk.fused_add].relu;
+                // identity: (second conv << acc_shl) + (block input << res_shl); opening block: (second conv << acc_shl) + (shortcut << res_shl)
+                const int dfl = T[c2.out].fl - (hds ? T[hk.out].fl : xin.fl);
                 B.acc_shl = dfl < 0 ? -dfl : 0; B.res_shl = dfl > 0 ? dfl : 0;
+                if (hds) { a.wsc = (const int8_t*)(net->d_w + hk.wf_off); a.bsc = (const int32_t*)(net->d_w + hk.b_off); }
             }
-            const Tensor& x = T[st.src_t];
-            a.xr = (const int32_t*)fp(x.forms[st.src_f]);
+            const Tensor& xs = T[st.src_t];
+            if (ds) { a.x8in = (const int8_t*)fp(xs.forms[st.src_f]); a.x8sc = (const int8_t*)fp(xs.forms[st.res_f]); }
+            else a.xr = (const int32_t*)fp(xs.forms[st.src_f]);
+            const Tensor& x = T[st.out.t];
             const int tiles = bchain_tiles_per_img(x.C, x.H, x.W);
             a.N = N; a.NG = std::max(1, std::min(N, (net->num_cu > 0 ? std::min(net->num_cu, 256) : 256) / tiles));
             fill_out(&a.out32, a.q);

@@ -136,23 +136,30 @@ def test_plan_runs_each_stage_as_one_chain_launch():
 
 
 def test_plan_runs_basic_block_stages_as_chain_launches():
-    """Default ResNet-18 plan: the identity BasicBlocks of stages 0-2 (56x56 x 64, 28x28 x 128, 14x14 x 256) that follow one another
-    are ONE launch per stage (f8_bchain.hip: both 3x3 convs of every block, the int32 stream in registers); the downsample blocks
-    and the 7x7 stage keep their per-conv launches.  fuse_bchain = 0 gives the per-conv plan back."""
+    """Default ResNet-18 plan: the BasicBlocks of a stage are ONE launch (f8_bchain.hip: every 3x3 of every block, the int32 stream in
+    registers): stage 0 (56x56 x 64) its two identity blocks, stages 1-2 (28x28 x 128, 14x14 x 256) the stage-opening block (3x3 / 2,
+    3x3, 1x1 / 2 shortcut) and the identity block behind it; the 7x7 stage keeps its per-conv launches.  fuse_bchain = 1 leaves the
+    opening blocks out, fuse_bchain = 0 gives the per-conv plan back."""
     spec = topology.get('resnet18')
     params = synth.make_params(spec, 1)
     net = build_net(spec, params, max_batch=8, hw=224)
     lines = net.describe().splitlines()
     chains = [l.split()[1] for l in lines if 'basic_chain_x' in l]
     assert chains == ['basic_chain_x2:stage_0_layer_0.body.0..stage_0_layer_1.body.2',
-                      'basic_chain_x1:stage_1_layer_1.body.0..stage_1_layer_1.body.2',
-                      'basic_chain_x1:stage_2_layer_1.body.0..stage_2_layer_1.body.2'], net.describe()
-    assert net.num_launches == 18
+                      'basic_chain_x2_ds:stage_1_layer_0.body.0..stage_1_layer_1.body.2',
+                      'basic_chain_x2_ds:stage_2_layer_0.body.0..stage_2_layer_1.body.2'], net.describe()
+    assert net.num_launches == 12
     # the stem hands the first chain the int32 stream only: the chain makes its own int8 copy
     stem = [l for l in lines if 'stem7x7s2+maxpool3x3s2' in l]
     assert len(stem) == 1 and 'i32=1 i8=0' in stem[0]
-    # 7x7 identity block: not chained (49 pixels per image do not fill a tile)
+    # a chain hands the next stage's opening block int8 forms only (its 3x3 / 2 and its shortcut may ask for different formats)
+    assert all('i32=0' in l for l in lines if 'basic_chain_x2:' in l or 'stage_1_layer_0' in l)
+    # 7x7 stage: not chained (49 pixels per image do not fill a tile)
     assert any('stage_3_layer_1.body.2' in l and '_res:' in l for l in lines)
+    assert any('stage_3_layer_0.shortcut.0' in l and '_res:' in l for l in lines)
+    mid = build_net(spec, params, max_batch=8, hw=224, options={'fuse_bchain': 1})
+    assert [l.split()[1].split(':')[0] for l in mid.describe().splitlines() if 'basic_chain_x' in l] == ['basic_chain_x2', 'basic_chain_x1', 'basic_chain_x1']
+    assert mid.num_launches == 18
     off = build_net(spec, params, max_batch=8, hw=224, options={'fuse_bchain': 0})
     assert 'basic_chain' not in off.describe() and off.num_launches == 23
     # a resolution the kernel has no instance for: per-conv plan

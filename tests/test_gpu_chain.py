@@ -212,3 +212,66 @@ def test_basic_block_chain_matches_oracle(dev, cfg, variant, tail):
         got2 = net.run(_t(x[:N - 1], dev)).cpu().numpy().reshape((N - 1,) + w.shape[1:])
         net.check()
         np.testing.assert_array_equal(got2, w[:N - 1])
+
+
+# ... starting with the stage-opening block: 3x3 / 2 (ReLU) -> 3x3, 1x1 / 2 shortcut, join (fix_resnet.py:55-77), then identity blocks
+BCHAINS_DS = [(128, 28, 1, 3), (128, 28, 2, 70), (256, 14, 1, 5), (256, 14, 3, 131)]   # C, H = W of the stage, identity blocks, N
+
+
+@pytest.mark.parametrize('cfg', BCHAINS_DS, ids=lambda g: 'x'.join(map(str, g)))
+@pytest.mark.parametrize('variant', ['one_input_form', 'two_input_forms', 'signed_mid'])
+def test_basic_block_chain_with_opening_block_matches_oracle(dev, cfg, variant):
+    """The opening block reads the previous stage's output at twice the resolution: its 3x3 / 2 and its shortcut each in their own
+    int8 format (`two_input_forms`: different fraclens, the shortcut's shifted left in the join; `one_input_form`: the same buffer,
+    the second conv's result shifted left); `signed_mid`: a symmetric (signed) input of the second conv — the kernel's general path."""
+    C, HW, nid, N = cfg
+    CIN, HWI = C // 2, 2 * HW
+    name = 'd.0'
+    body = [topology.ConvSpec(name + '.body.0', CIN, C, 3, 2, 1, relu=True),
+            topology.ConvSpec(name + '.body.2', C, C, 3, 1, 1, signed_in=(variant == 'signed_mid'))]
+    sc = topology.ConvSpec(name + '.shortcut.0', CIN, C, 1, 2, 0)
+    opener = topology.BlockSpec(name, body, sc, residual=True, post_relu=True)
+    idb, fls = _basic_stage(C, nid, 'acc_shifts_left' if variant != 'two_input_forms' else 'res_shifts_left')
+    if variant == 'two_input_forms':
+        fls[name + '.body.0'], fls[name + '.body.2'], fls[name + '.shortcut.0'] = (4, 7), (4, 7), (3, 6)     # shortcut 9 < body 11
+    else:
+        fls[name + '.body.0'], fls[name + '.body.2'], fls[name + '.shortcut.0'] = (4, 7), (3, 6), (4, 7)     # body 9 < shortcut 11
+    blocks = [opener] + idb
+    convs = [c for b in blocks for c in b.body] + [sc]
+    pre = topology.ConvSpec('pre.0', CIN, CIN, 1, 1, 0)
+    fls['pre.0'] = (4, 7)
+    params = _params(convs + [pre], fls, 41, variant)
+    x_fl = 9
+    x = synth.rand_normal_int(19, 'bchainds' + variant, (N, CIN, HWI, HWI), 3.0e3).astype(np.int32)
+
+    net = F8Net()
+    t = net.input(CIN, HWI, HWI, x_fl)
+    r = net.conv(t, params['pre.0.weight'], params['pre.0.bias'], stride=1, pad=0, groups=1, weight_fl=7, input_fl=4, input_signed=False,
+                 quant_input=True, relu=True)
+    for b in blocks:
+        xin = r
+        for c in b.body:
+            r = net.conv(r, params[c.key + '.weight'], params[c.key + '.bias'], stride=c.stride, pad=c.pad, groups=1,
+                         weight_fl=fls[c.key][1], input_fl=fls[c.key][0], input_signed=c.signed_in, quant_input=True, relu=c.relu)
+        if b.shortcut is not None:
+            c = b.shortcut
+            xin = net.conv(xin, params[c.key + '.weight'], params[c.key + '.bias'], stride=2, pad=0, groups=1,
+                           weight_fl=fls[c.key][1], input_fl=fls[c.key][0], input_signed=False, quant_input=True, relu=False)
+        r = net.add(r, xin, relu=True)
+    net.output(r, as_float=False)
+    net.finalize(N)
+    plan = net.describe()
+    assert f'basic_chain_x{nid + 1}_ds' in plan, plan
+    assert sum(k in plan for k in ('conv3x3', 'conv1x1s2', '_res:')) == 0, plan     # every conv of the stage runs inside the chain launch
+    got = net.run(_t(x, dev)).cpu().numpy().reshape(N, C, HW, HW)
+    net.check()
+
+    w, fl = oracle._conv_layer(pre, params, x, x_fl)
+    w = np.maximum(w, 0)
+    for b in blocks:
+        w, fl = oracle.block_forward(b, params, w, fl)
+    assert net.output_fraclen == fl
+    np.testing.assert_array_equal(got, w)
+    got2 = net.run(_t(x[:N - 1], dev)).cpu().numpy().reshape((N - 1,) + w.shape[1:])
+    net.check()
+    np.testing.assert_array_equal(got2, w[:N - 1])
