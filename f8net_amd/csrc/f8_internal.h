@@ -34,6 +34,7 @@ struct Options {
     int deep_nk = 7;             // K loops of at least this many steps use the deepest DMA ring
     int bk128 = 0;               // 128-byte K steps in conv_igemm_kernel
     int dw_dot4 = 1;             // v_dot4 depthwise kernel
+    int stem_rows = 1;           // ResNet head: the row-walking kernel (pool in registers) where it has an instance, else the tile kernel
     int stem_wpc = 3;            // resident stem workgroups per CU (2 / 3 / 4: 84.0 / 84.5 / 84.7 k img/s, same box)
     int opener_stg = 1;          // stride-2 opener: int8 output staged through LDS into 128-byte lines
     int chunk56 = -1, chunk28 = -1, chunk14 = -1;   // images per chunk of the fused blocks (-1: derived from chunk_budget_mb, 0: whole batch)
@@ -244,6 +245,7 @@ struct StemPoolArgs {
     int32_t* out32;                        // pooled int32 (I32T, 64 channels) or nullptr
     QuantOut q[2];                         // pooled int8 NHWC (64 channels) in up to two formats
     int32_t wpc;                           // Options::stem_wpc
+    int32_t rows;                          // Options::stem_rows: the row-walking kernel where it has an instance
     // raw network input read by the stem launch itself (no input launch, no haloed NHWC4 copy): NCHW planes, raw_kind 0 = int32 (xi),
     // 1 = fp32 quantised on the fly (xf, scale, qlo, qhi), 2 = uint8 through `lut`; raw_kind < 0: the haloed form `x`
     int32_t raw_kind, rC, rH, rW;
@@ -309,7 +311,7 @@ hipError_t launch_fused_ir(const IRArgs& a, int cinS, int coutS, hipStream_t s);
 // 3x3 / stride 1 / pad 1 with the input patch resident in LDS (f8_conv3x3.hip); config = false: no instance
 bool conv3x3_patch_config(int cin, int H, int W, int coutP, int* R, int* IMGS, int* BN);
 hipError_t launch_conv3x3_patch(const ConvArgs& a, int cin, hipStream_t s);
-bool stem_pool_supported(int cin, int cout, int k, int stride, int pad, int pool_k, int pool_s, int pool_p, int P, int Q);
+bool stem_pool_supported(int cin, int cout, int k, int stride, int pad, int pool_k, int pool_s, int pool_p, int P, int Q, int rows);
 hipError_t launch_stem_pool(const StemPoolArgs& a, hipStream_t s);
 hipError_t launch_dwconv(const DwArgs& a, hipStream_t s);
 hipError_t launch_maxpool(const PoolArgs& a, hipStream_t s);

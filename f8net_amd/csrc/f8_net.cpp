@@ -236,6 +236,7 @@ static const OptKey kOptKeys[] = {
     {"bk128", "F8_BK128", &Options::bk128, 0, 1, true},
     {"dw_dot4", "F8_DW_DOT4", &Options::dw_dot4, 0, 1, true},
     {"stem_wpc", "F8_STEM_WPC", &Options::stem_wpc, 1, 8, false},
+    {"stem_rows", "F8_STEM_ROWS", &Options::stem_rows, 0, 1, true},
     {"opener_stg", "F8_OPENER_STG", &Options::opener_stg, 0, 1, true},
     {"chunk56", "F8_CHUNK", &Options::chunk56, -1, 1 << 20, false},
     {"chunk28", "F8_CHUNK28", &Options::chunk28, -1, 1 << 20, false},
@@ -1107,7 +1108,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     Node& c = ND[T[nd.a].prod];
                     if (c.kind == N_CONV && c.cd.groups == 1 && c.fused_add < 0 && ND[T[c.a].prod].kind == N_INPUT && T[c.a].consumers.size() == 1 &&
                         c.a != net->out_t && (!c.cd.quant_input || T[c.a].fl == c.cd.input_fl) && opt.fuse_stem &&
-                        stem_pool_supported(c.cd.cin, c.cd.cout, c.cd.kernel, c.cd.stride, c.cd.pad, nd.pk, nd.pstride, nd.ppad, o.H, o.W)) {
+                        stem_pool_supported(c.cd.cin, c.cd.cout, c.cd.kernel, c.cd.stride, c.cd.pad, nd.pk, nd.pstride, nd.ppad, o.H, o.W, opt.stem_rows)) {
                         c.sp_pool = i; nd.sp_conv = T[nd.a].prod;
                         break;                                   // no HBM form of the conv output
                     }
@@ -1188,7 +1189,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     st.bytes_per_img = (double)s.H * s.W * 4 + (double)o.H * o.W * o.Cs * ((st.out.f32 >= 0 ? 4 : 0) + (st.out.f8[0] >= 0) + (st.out.f8[1] >= 0));
                     st.bytes_const = (double)nd.coutP * (nd.ktot + 4);
                     st.name = "stem7x7s2+maxpool3x3s2:" + tname(net, nd.out) + "+" + tname(net, pl.out);
-                    st.kernel = "f8::stem_pool_kernel";
+                    st.kernel = (opt.stem_rows && T[pl.out].W >= 2 && T[pl.out].W <= 56) ? "f8::stem_rows_kernel" : "f8::stem_pool_kernel";    // keep in sync with launch_stem_pool
                     break;
                 }
                 if (nd.bchain_into == i) {
@@ -1864,7 +1865,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             a.bias = (const int32_t*)(net->d_w + nd.b_off);
             a.N = N; a.Hp = sF.Hp; a.Wp = sF.Wp; a.org = sF.pad - nd.cd.pad;
             a.Pc = cT.H; a.Qc = cT.W; a.P = oT.H; a.Q = oT.W;
-            a.relu0 = st.relu0; a.wpc = net->opt.stem_wpc;
+            a.relu0 = st.relu0; a.wpc = net->opt.stem_wpc; a.rows = net->opt.stem_rows;
             a.raw_kind = -1;
             if (st.raw_input && !(net->in_u8 && net->in_u8_nhwc)) {
                 const size_t img = (size_t)sT.C * sT.H * sT.W;

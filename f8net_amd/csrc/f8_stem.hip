@@ -242,12 +242,300 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemPoolArgs a) {
     }
 }
 
-bool stem_pool_supported(int cin, int cout, int k, int stride, int pad, int pool_k, int pool_s, int pool_p, int P, int Q) {
-    return cin <= 4 && cout == 64 && k == 7 && stride == 2 && pad == 3 && pool_k == 3 && pool_s == 2 && pool_p == 1 && P > 0 && Q > 0 &&
-           P % TP == 0 && Q % TQ == 0;
+// ---------------------------------------------------------------------------------------------------------------------------------
+// stem_rows_kernel — the same head, organised so that the pool never goes through LDS and the input is always in flight.
+//
+// stem_pool_kernel above parks every conv tile in LDS as int32 (73 KB written, 129 KB read per 56 pooled pixels) behind four
+// barriers per tile, and keeps three 16-byte loads per thread in flight: 80 us for 103 - 180 MB.  Here
+//   * a COMPUTE wave owns a strip of 28 pooled columns and walks down its rows: per conv row it multiplies two 32-pixel MFMA
+//     tiles — E: the even conv columns 2c, O: the odd ones 2c - 1 (c = the lane's pooled column) — so the pool's horizontal window
+//     {2c-1, 2c, 2c+1} is max(O[lane], E[lane], O[lane+1]): one DPP lane shift, no memory; the vertical window is a running max
+//     over three consecutive conv rows in registers (the last one is carried into the next pooled row).  Bias rides in the
+//     accumulators' start value, ReLU and the requantisations run on the POOLED values (monotone: they commute with max).
+//     Conv pixels outside the image (column -1, row -1: the pool's padding) are replaced by a pixel of the same window that lies
+//     inside (column 1 / row 1) — max over a window with a duplicate is the max over the window: no masks.  The wave's 7 weight
+//     fragments (32 couts x 7 kernel rows x 32 B) live in registers for its whole life; the only LDS traffic is the B
+//     operand: one 16-byte read (O) / two 8-byte reads (E) per lane and kernel row from the band's input patch (NHWC4 bytes);
+//   * LOADER waves bring in the NEXT band's input rows meanwhile — every load of a band in flight at once (24 x 16 B per thread,
+//     ~100 KB per CU: what the HBM latency asks for; registers the compute waves could not spare) — converted from the raw network
+//     input (int32 / fp32 / uint8 NCHW planes, as stem_pool_kernel's KIND) or copied from the haloed NHWC4 form into the other
+//     patch buffer.  One barrier per band.
+// Workgroup = 768 threads = 8 compute waves (32-cout half x 2 strips x 2 half-bands; pooled width <= 28: 1 strip x 4 quarter-bands:
+// two per SIMD, 28 weight registers each, so one wave's maxima and stores run under the other's multiplies; the two halves of a
+// strip read the same B fragments — LDS has the room) + 4 loader waves, persistent, one per CU; band = 7 pooled rows x the full width of one image (35 input rows, 32 KB per patch buffer); 7 of a
+// band's 35 rows are shared with the band above (L2: the bands of one image run on one XCD).
+#ifndef F8_STEM_DB
+#define F8_STEM_DB 3                                  // B fragments in flight per compute wave (tuning builds override)
+#endif
+namespace {
+constexpr int RB = 7;                               // pooled rows per band
+constexpr int SW = 28;                              // pooled columns per strip (lane 28 of a strip only provides O for lane 27)
+constexpr int RB_ROWS = 4 * RB + 7;                 // input rows of a band
+
+__device__ __forceinline__ int dpp_next_lane(int v) {   // lane i <- lane i + 1 (across the 16-lane DPP rows; lane 63 keeps its value)
+    return __builtin_amdgcn_update_dpp(v, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+template <class Y>
+__device__ __forceinline__ v4i stem_quant16(const Y& y, int n, int lo, int hi, unsigned x_or) {
+    unsigned d[4];
+    if (n > 0) {                                     // the usual case, a right shift: four VALU operations per value (wave-uniform branch)
+        const unsigned hf = 1u << (n - 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) d[g] = pack4(requant_shr(y[4 * g], n, hf, 0u, lo, hi), requant_shr(y[4 * g + 1], n, hf, 0u, lo, hi),
+                                                 requant_shr(y[4 * g + 2], n, hf, 0u, lo, hi), requant_shr(y[4 * g + 3], n, hf, 0u, lo, hi)) ^ x_or;
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) d[g] = pack4(requant1(y[4 * g], n, lo, hi), requant1(y[4 * g + 1], n, lo, hi), requant1(y[4 * g + 2], n, lo, hi),
+                                                 requant1(y[4 * g + 3], n, lo, hi)) ^ x_or;
+    }
+    auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+    auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+    const v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
+    return o;                                        // lane (pixel, half): channels 16 half .. 16 half + 15 of the 32-channel tile
+}
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) stem_rows_kernel(const StemPoolArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];      // 2 x [RB_ROWS][PWB pixels][4 B] (patch column pc = input column pc - 5) | 64 biases
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0 .. 7 compute, 8 .. 11 loaders
+    const int PWB = 4 * a.Q + 8, ROWB = PWB * 4, SPR = PWB / 4;     // patch row: pixels, bytes, 16-byte slots
+    const int PBUF = RB_ROWS * ROWB;
+    const int bands = (a.P + RB - 1) / RB, ntiles = a.N * bands;
+    // XCD-aware order: dispatch slot d (d % 8 = the XCD of a persistent workgroup's every slot) -> band tile; the bands of one image,
+    // which share input rows, run on one XCD
+    auto tile_of = [&](int d) {
+        const int xcd = d & 7, qq = ntiles >> 3, rr = ntiles & 7;
+        return (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (d >> 3);
+    };
+    // loaders' unit: one 16-byte SLOT = 4 pixels of one input row.  Raw planes: slots are image-aligned (columns 4j .. 4j + 3: whole
+    // inside the image, 16-byte aligned in memory, so every load is one unconditional b128 / b32 — no branch, hence no wait, between
+    // the loads of a band) and land 5 pixels to the right in the patch (four dword stores); the patch columns left and right of the
+    // image are written once, below.  Haloed form: slots are patch-aligned (a plain copy).
+    const int SPI = KIND < 0 ? SPR : a.Q;                           // slots per input row (raw: rW / 4 = Q)
+    struct Band { int n, p0, rp, r0, nslot; };
+    auto band_of = [&](int d) {
+        const int t = tile_of(d);
+        Band B;
+        B.n = t / bands; B.p0 = (t - B.n * bands) * RB;
+        B.rp = (a.P - B.p0) < RB ? (a.P - B.p0) : RB;               // pooled rows of this band
+        B.r0 = 4 * B.p0 - 5; B.nslot = (4 * B.rp + 7) * SPI;        // input rows r0 .. r0 + 4 rp + 6
+        return B;
+    };
+    constexpr int NR = KIND < 0 ? 4 : (KIND == 2 ? 3 : 12);
+    constexpr int LSLOTS = 8;                           // slots per loader thread and pass, all in flight (35 rows x 56 slots / 256 threads = 7.7)
+    const __amdgpu_buffer_rsrc_t rsrc = KIND < 0 ? __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc((void*)(KIND == 0 ? (const void*)a.xi : KIND == 1 ? (const void*)a.xf : (const void*)a.xu8), 0,
+                                            (unsigned)((size_t)a.N * a.rC * a.rH * a.rW * (KIND == 2 ? 1 : 4)), 0x00020000);
+    const unsigned plane = (unsigned)(a.rH * a.rW);
+    unsigned bad = 0;                                    // KIND 0: an int32 input value outside the head's 8-bit format was seen
+    auto slot_issue = [&](const Band& B, int sl, int (&raw)[NR], unsigned& ok) {
+        const int pr = sl / SPI, j = sl - pr * SPI;
+        if constexpr (KIND < 0) {
+            // haloed row / column = input row / column + 3 + org; org = 2 (stem_rows_ok): patch slot j = haloed pixels 4j .. 4j + 3
+            const int hr = B.r0 + pr + 5, wc = 4 * j;
+            ok = (sl < B.nslot && hr >= 0 && hr < a.Hp && wc + 4 <= a.Wp) ? 1u : 0u;
+            const v4i v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? (unsigned)((((size_t)B.n * a.Hp + hr) * a.Wp + wc) * 4) : kOOB, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) raw[q] = v[q];
+        } else {
+            const int row = B.r0 + pr;
+            ok = (sl < B.nslot && row >= 0 && row < a.rH) ? 1u : 0u;
+            const unsigned e0 = (unsigned)((B.n * a.rC * a.rH + row) * a.rW + 4 * j);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const unsigned e = (ok && c < a.rC) ? e0 + (unsigned)c * plane : kOOB;
+                if constexpr (KIND == 2) raw[c] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, e, 0, 0);
+                else {
+                    const v4i q4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, e == kOOB ? kOOB : e * 4u, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) raw[c * 4 + q] = q4[q];
+                }
+            }
+        }
+    };
+    auto slot_commit = [&](char* buf, const Band& B, int sl, const int (&raw)[NR], unsigned ok) {
+        const int pr = sl / SPI, j = sl - pr * SPI;
+        v4i o;
+        if constexpr (KIND < 0) {
+            const int z = (int)a.xor8;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = ok ? raw[q] : z;
+            if (sl < B.nslot) *(v4i*)(buf + sl * 16) = o;
+        } else {
+            int v[3][4];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int x;
+                    if constexpr (KIND == 0) { x = raw[c * 4 + q]; bad |= (ok && c < a.rC && (unsigned)(x - a.chk_lo) > (unsigned)(a.chk_hi - a.chk_lo)) ? 1u : 0u; }
+                    else if constexpr (KIND == 1) x = quant_in_stem(__builtin_bit_cast(float, raw[c * 4 + q]), a.scale, a.qlo, a.qhi);
+                    else x = (int)((const short*)(lds + 2 * PBUF + 256))[c * 256 + ((raw[c] >> (8 * q)) & 0xff)];
+                    v[c][q] = (ok && c < a.rC) ? x : 0;         // rows outside the image: (biased) zero
+                }
+            if (sl < B.nslot) {
+                int* const dst = (int*)(buf + pr * ROWB + (4 * j + 5) * 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[q] = (int)(pack4(v[0][q], v[1][q], v[2][q], 0) ^ a.xor8);
+            }
+        }
+    };
+    // a band's rows -> `buf`, by `nthr` threads (this one is number `t`): LSLOTS slots per thread in flight
+    auto load_band = [&](const Band& B, char* buf, int t, int nthr) {
+        for (int s0 = t; s0 < B.nslot; s0 += LSLOTS * nthr) {
+            int raw[LSLOTS][NR]; unsigned ok[LSLOTS];
+#pragma unroll
+            for (int u = 0; u < LSLOTS; ++u) slot_issue(B, s0 + u * nthr, raw[u], ok[u]);
+#pragma unroll
+            for (int u = 0; u < LSLOTS; ++u) slot_commit(buf, B, s0 + u * nthr, raw[u], ok[u]);
+        }
+    };
+    if constexpr (KIND == 2) {   // the u8 -> head-format table: LDS (a dynamically indexed kernel argument would live in scratch)
+        for (int i = tid; i < 3 * 256; i += 768) ((short*)(lds + 2 * PBUF + 256))[i] = a.lut[i];
+        __syncthreads();
+    }
+    if constexpr (KIND >= 0) {   // patch columns outside the image (5 on the left, 3 + padding on the right) of both buffers: biased zero, once
+        const int nside = PWB - 4 * a.Q;                            // 8
+        for (int i = tid; i < 2 * RB_ROWS * nside; i += 768) {
+            const int r = i / nside, c = i - r * nside;
+            *(unsigned*)(lds + r * ROWB + (c < 5 ? c : 4 * a.Q + c) * 4) = a.xor8;
+        }
+    }
+
+    const int G = gridDim.x;
+    int d = blockIdx.x;
+    if (d >= ntiles) return;
+    load_band(band_of(d), lds, tid, 768);                           // the first band: every wave loads
+    if (tid < 64) *(int*)(lds + 2 * PBUF + tid * 4) = a.bias[tid];
+    __syncthreads();
+
+    if (wave >= 8) {
+        // =================================================== loader waves: band it + 1 -> the other patch while band it is multiplied
+        for (int it = 0; d < ntiles; d += G, ++it) {
+            if (d + G < ntiles) load_band(band_of(d + G), lds + ((it & 1) ^ 1) * PBUF, tid - 512, 256);
+            __syncthreads();
+        }
+        if constexpr (KIND == 0) { if (a.err && bad) atomicOr(a.err, 1u); }
+        return;
+    }
+    if constexpr (KIND == 0) { if (a.err && bad) atomicOr(a.err, 1u); }   // (the first band's share of the check)
+
+    // ======================================================= compute waves: (cout half, strip, sub-band)
+    const int half = wave & 1;
+    // weights -> registers: A fragment (kernel row r): lane (cout of this wave's half, half of the row's 8 taps)
+    v4i wf[7];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) wf[r] = *(const v4i*)(a.w + (half * 32 + l31) * 224 + r * 32 + lh * 16);
+    const int nstrip = a.Q > SW ? 2 : 1, nsb = 4 / nstrip;
+    const int strip = nstrip == 2 ? ((wave >> 1) & 1) : 0, sb = nstrip == 2 ? (wave >> 2) : (wave >> 1);
+    const int col = strip * SW + l31;                               // pooled column of this lane
+    // E: conv column 2 col (lanes past the image repeat its last column: unused), O: conv column 2 col - 1 (column -1, the pool's
+    // padding, is replaced by column 1 of the same window)
+    const int colE = col < a.Q ? col : a.Q - 1, colO = col == 0 ? 1 : (col < a.Q ? col : a.Q);
+    const unsigned offO = (unsigned)(16 * colO + 16 * lh), offE = (unsigned)(16 * colE + 8 + 16 * lh);
+    const bool lane_out = l31 < SW && col < a.Q;
+    const int floor0 = a.relu0 ? 0 : INT32_MIN;
+    const char* const bias_l = lds + 2 * PBUF + half * 128 + 16 * lh;   // this half's 32 biases, behind the patches (kept out of the registers)
+
+    for (int it = 0; d < ntiles; d += G, ++it) {
+        const Band B = band_of(d);
+        const char* const patch = lds + (it & 1) * PBUF;
+        const int p0 = B.p0;
+
+        // one conv row -> its horizontal pool maxima, handed to `sink(register, value)` one by one
+        auto conv_row = [&](int cr, auto&& sink) {
+            cr = cr < 0 ? 1 : cr;                                   // the row above the image: a row of the same window instead
+            v16i e, o;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const v4i b = *(const v4i*)(bias_l + 8 * g * 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { e[4 * g + q] = b[q]; o[4 * g + q] = b[q]; }
+            }
+            const char* const base = patch + (2 * (cr - 2 * p0) + 2) * ROWB;
+            // B fragments DB - 1 kernel rows ahead of their multiplies, no further (registers)
+            constexpr int DB = F8_STEM_DB;
+            v4i xo[DB], xe[DB];
+            auto rd = [&](int r, v4i& o_, v4i& e_) {
+                o_ = *(const v4i*)(base + r * ROWB + offO);
+                const v2i x0 = *(const v2i*)(base + r * ROWB + offE), x1 = *(const v2i*)(base + r * ROWB + offE + 8);
+                e_ = v4i{x0.x, x0.y, x1.x, x1.y};
+            };
+#pragma unroll
+            for (int r = 0; r < DB - 1; ++r) rd(r, xo[r], xe[r]);
+#pragma unroll
+            for (int r = 0; r < 7; ++r) {
+                if (r + DB - 1 < 7) rd(r + DB - 1, xo[(r + DB - 1) % DB], xe[(r + DB - 1) % DB]);
+                asm volatile("" : "+v"(xo[r % DB]), "+v"(xe[r % DB]));
+                e = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[r], xe[r % DB], e, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[r], xo[r % DB], o, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sink(q, max(max(e[q], o[q]), dpp_next_lane(o[q])));
+        };
+
+        const int rps = (B.rp + nsb - 1) / nsb;
+        const int pb = sb * rps, pe = (pb + rps) < B.rp ? (pb + rps) : B.rp;
+        if (pb < pe) {
+            v16i carry;
+            conv_row(2 * (p0 + pb) - 1, [&](int q, int v) { carry[q] = v; });
+            for (int p = pb; p < pe; ++p) {
+                const int P = p0 + p;
+                v16i pm;
+                conv_row(2 * P, [&](int q, int v) { pm[q] = max(carry[q], v); });
+                conv_row(2 * P + 1, [&](int q, int v) { carry[q] = v; pm[q] = max(max(pm[q], v), floor0); });
+                // ---- pooled row P: outputs
+                const int m = (B.n * a.P + P) * a.Q + (lane_out ? col : 0);
+                if (lane_out && a.out32) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const v4i v = {pm[4 * g], pm[4 * g + 1], pm[4 * g + 2], pm[4 * g + 3]};
+                        *(v4i*)((char*)a.out32 + (size_t)(m >> 5) * (64 * 128) + half * 4096 + g * 1024 + lh * 512 + (m & 31) * 16) = v;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (a.q[k].ptr) {
+                        const v4i v = stem_quant16(pm, a.q[k].n, a.q[k].lo, a.q[k].hi, a.q[k].bias_xor);
+                        if (lane_out) *(v4i*)(a.q[k].ptr + (size_t)m * 64 + half * 32 + lh * 16) = v;
+                    }
+            }
+        }
+        __syncthreads();                                            // patch `it` is consumed, patch `it + 1` is complete
+    }
+}
+
+// instances of the row-walking kernel: pooled width <= 56 (two strips), any height; a haloed form must carry 5 halo pixels
+static bool stem_rows_ok(const StemPoolArgs& a) {
+    if (a.Q < 2 || a.Q > 2 * SW || a.P < 1 || a.Qc != 2 * a.Q || a.Pc != 2 * a.P) return false;
+    if (a.raw_kind < 0) return a.org == 2 && a.Wp % 4 == 0;
+    return a.rW == 2 * a.Qc && a.rH == 2 * a.Pc;
+}
+
+bool stem_pool_supported(int cin, int cout, int k, int stride, int pad, int pool_k, int pool_s, int pool_p, int P, int Q, int rows) {
+    if (!(cin <= 4 && cout == 64 && k == 7 && stride == 2 && pad == 3 && pool_k == 3 && pool_s == 2 && pool_p == 1 && P > 0 && Q > 0)) return false;
+    return (P % TP == 0 && Q % TQ == 0) || (rows && Q >= 2 && Q <= 2 * SW);     // tile kernel | row-walking kernel (launch_stem_pool picks)
 }
 
 hipError_t launch_stem_pool(const StemPoolArgs& a, hipStream_t s) {
+    if (a.rows && stem_rows_ok(a)) {
+        const int lds_bytes = 2 * RB_ROWS * (4 * a.Q + 8) * 4 + 256 + 1536;   // 67 KB at 224 x 224: patches, biases, the u8 table
+        static int ncu2 = 0;
+        if (!ncu2) { int dev = 0; hipDeviceProp_t p; ncu2 = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+        const int ntiles = a.N * ((a.P + RB - 1) / RB);
+        const int grid = ntiles < ncu2 ? ntiles : ncu2;                     // persistent, one per CU: a workgroup walks slots b, b + grid, ...
+        switch (a.raw_kind) {
+            case 0: hipLaunchKernelGGL(stem_rows_kernel<0>, dim3(grid), dim3(768), lds_bytes, s, a); break;
+            case 1: hipLaunchKernelGGL(stem_rows_kernel<1>, dim3(grid), dim3(768), lds_bytes, s, a); break;
+            case 2: hipLaunchKernelGGL(stem_rows_kernel<2>, dim3(grid), dim3(768), lds_bytes, s, a); break;
+            default: hipLaunchKernelGGL(stem_rows_kernel<-1>, dim3(grid), dim3(768), lds_bytes, s, a); break;
+        }
+        return hipGetLastError();
+    }
+    if (!(a.P % TP == 0 && a.Q % TQ == 0)) return hipErrorInvalidValue;
     const int ntiles = a.N * (a.P / TP) * (a.Q / TQ);
     const int wpc = a.wpc > 0 ? a.wpc : 2;               // resident workgroups per CU (63 KB LDS each), Options::stem_wpc
     static int ncu = 0;
