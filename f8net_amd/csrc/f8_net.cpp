@@ -237,6 +237,7 @@ static const OptKey kOptKeys[] = {
     {"dw_dot4", "F8_DW_DOT4", &Options::dw_dot4, 0, 1, true},
     {"stem_wpc", "F8_STEM_WPC", &Options::stem_wpc, 1, 8, false},
     {"stem_rows", "F8_STEM_ROWS", &Options::stem_rows, 0, 1, true},
+    {"stem_grid_div", "F8_STEM_GRID_DIV", &Options::stem_grid_div, 0, 32, false},
     {"opener_stg", "F8_OPENER_STG", &Options::opener_stg, 0, 1, true},
     {"chunk56", "F8_CHUNK", &Options::chunk56, -1, 1 << 20, false},
     {"chunk28", "F8_CHUNK28", &Options::chunk28, -1, 1 << 20, false},
@@ -1865,7 +1866,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             a.bias = (const int32_t*)(net->d_w + nd.b_off);
             a.N = N; a.Hp = sF.Hp; a.Wp = sF.Wp; a.org = sF.pad - nd.cd.pad;
             a.Pc = cT.H; a.Qc = cT.W; a.P = oT.H; a.Q = oT.W;
-            a.relu0 = st.relu0; a.wpc = net->opt.stem_wpc; a.rows = net->opt.stem_rows;
+            a.relu0 = st.relu0; a.wpc = net->opt.stem_wpc; a.rows = net->opt.stem_rows; a.grid_div = net->opt.stem_grid_div;
             a.raw_kind = -1;
             if (st.raw_input && !(net->in_u8 && net->in_u8_nhwc)) {
                 const size_t img = (size_t)sT.C * sT.H * sT.W;

@@ -228,7 +228,9 @@ int f8_net_check(f8_net* net);
  * chunk56) and otherwise the measured best; two handles in one process may differ.  Keys that decide the plan must be set
  * before f8_net_finalize (F8_ERR_STATE afterwards); scheduling keys may change between runs.
  *   planning  : split (1..4 concurrent sub-batches = arena copies), fuse_blocks, fuse_stages (bit mask, -1 = auto), fuse_dual,
- *               fuse_ds, fuse_opener, fuse_fc (the classifier writes the caller's logits buffer itself), fuse_stem, fuse_input (the fused stem launch reads the caller's NCHW buffer itself), fuse_ir (1 = where it wins, 2 = every block), fuse_chain (all consecutive bottleneck blocks of a stage in one launch, the int32 residual stream in registers), fuse_p12 (7x7 block: first two
+ *               fuse_ds, fuse_opener, fuse_fc (the classifier writes the caller's logits buffer itself), fuse_stem, fuse_input (the fused stem launch reads the caller's NCHW buffer itself), fuse_ir (1 = where it wins, 2 = every block), fuse_chain (all consecutive bottleneck blocks of a stage in one launch, the int32 residual stream in registers),
+ *               fuse_bchain (the same for BasicBlock stages: 1 = consecutive identity blocks, 2 = with the stage-opening block in front), stem_rows (ResNet head:
+ *               row-walking kernel, pool in registers), fuse_p12 (7x7 block: first two
  *               convs in one launch), wstat (weight-stationary 1x1 kernel: plain, dual-GEMM and residual-join instances) with
  *               wstat_min_tiles (pixel tiles per workgroup a launch must offer; 0 = always) and wstat_fast (0 = general epilogue), wreg (weights-streamed 1x1 kernel for the
  *               512 -> 256 / 1024 -> 512 reductions of smaller launches),
@@ -236,7 +238,7 @@ int f8_net_check(f8_net* net);
  *               f8_net_set_pipelined(2))
  *   scheduling: chunk56 / chunk28 / chunk14 (images per chunk of the fused blocks; -1 = derived from chunk_budget_mb, 0 = whole
  *               batch), chunk_budget_mb (memory-side cache a chunk's int32 stream may occupy), chunk_ds, chunk_opener,
- *               split_streams, graph, stagger, stagger_pipelined, stem_wpc, check_device, check_input_range, pipeline_depth (2..4 runs in flight),
+ *               split_streams, graph, stagger, stagger_pipelined, stem_wpc, stem_grid_div (row-walking head on 1 / n of the CUs; 0 = by output form), check_device, check_input_range, pipeline_depth (2..4 runs in flight),
  *               chain_timeout_ms (bound of a stage-chain launch's halo waits)
  * F8_ERR_INVALID for an unknown key or a value outside the key's range. */
 int f8_net_set_option(f8_net* net, const char* key, int value);
