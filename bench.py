@@ -18,7 +18,8 @@ Model-Zoo checkpoints are unreachable (no network).
 Other BASELINE.json configurations:  --arch resnet18 --bs 128 (C2), --arch mobilenet_v2 --bs 128 (C3),
 --arch resnet50 --bs 256 (C4), --gpus 8 --bs 256 (C5: 2048 images over 8 GPUs).
 
-value            : the timed region is EXACTLY --steps steps with two batches in flight (f8_net_set_pipelined(2)).
+value            : the timed region is EXACTLY --steps steps with F8_PIPELINE_DEPTH (default 3) batches in flight (f8_net_set_pipelined(2),
+                   options arena_copies = pipeline_depth = 3).
 value_unpipelined: the same steps, one batch in flight (runs back to back; each run = two concurrent sub-batches).
 roofline         : dominant kernel symbol by time; achieved = sum(algorithmic bytes of its launches) / sum(their
                    durations), durations from HIP events on the launch stream (f8_net_run_profiled).  `traffic` (HBM bytes per
@@ -145,7 +146,10 @@ def main():
     x_np, x_fl = synth.make_input(spec, params, BS, 224, seed=1 + rank)
     pipe_mode = int(os.environ.get('F8_BENCH_PIPELINED', '2'))
     # planning hint: under pipelining mode 2 every launch covers the whole batch (matters for the 14x14 fusion rule at bs 64..127)
-    net = build_net(spec, params, max_batch=BS, hw=224, options={'whole_batch_launches': 1} if pipe_mode == 2 else None)
+    # ... and `depth` whole batches are in flight, one arena copy each (a run with ONE batch in flight still cuts it `split` = 2 ways)
+    depth = max(2, min(4, int(os.environ.get('F8_PIPELINE_DEPTH', '3')))) if pipe_mode == 2 else 2
+    net = build_net(spec, params, max_batch=BS, hw=224,
+                    options={'whole_batch_launches': 1, 'arena_copies': depth, 'pipeline_depth': depth} if pipe_mode == 2 else None)
     net.upload()
     retiled = net.autotune(BS, dev) if args.autotune else 0      # one-time, outside the timed region
     x = torch.from_numpy(x_np).to(dev)
@@ -153,7 +157,6 @@ def main():
     # outstanding collective before the clock stops
     # consecutive steps overlap inside the library as well (f8_net_set_pipelined: static input, double-buffered outputs)
     # F8_BENCH_PIPELINED: 0 = runs back to back, 1 = lagged sub-batches, 2 = whole batches alternating between two streams
-    depth = int(os.environ.get('F8_PIPELINE_DEPTH', '2')) if pipe_mode == 2 else 2
 
     def timed(mode, steps, warmup):
         net.set_pipelined(mode)
@@ -223,23 +226,24 @@ def main():
     if world == 1 and not lean:
         from f8net_amd import int_model, stream_eval
         m = int_model.from_params(spec, params).to(dev)
-        m.set_pipelined(pipe_mode if pipe_mode else 0)
+        m.set_pipelined(pipe_mode if pipe_mode else 0, depth=depth)
         xi = x.clone(); setattr(xi, 'output_fraclen', x_fl)
-        outs = [torch.empty((BS, spec.num_classes), dtype=torch.float32, device=dev) for _ in range(3)]
+        NO = depth + 1
+        outs = [torch.empty((BS, spec.num_classes), dtype=torch.float32, device=dev) for _ in range(NO)]
         for i in range(min(args.warmup, 10) + 2):
-            m.forward(xi, out=outs[i % 3])
+            m.forward(xi, out=outs[i % NO])
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for i in range(args.steps):
-            m.forward(xi, out=outs[i % 3])
+            m.forward(xi, out=outs[i % NO])
         torch.cuda.synchronize(dev)
         dtm = time.perf_counter() - t0
         extra['value_intmodel'] = round(BS * args.steps / dtm, 1)
-        extra['intmodel_matches'] = bool(torch.equal(outs[(args.steps - 1) % 3], logits[:BS]))
+        extra['intmodel_matches'] = bool(torch.equal(outs[(args.steps - 1) % NO], logits[:BS]))
         del m
         if spec.head.cin == 3:
-            hnet = build_net(spec, params, max_batch=BS, hw=224, options={'whole_batch_launches': 1})
-            ev = stream_eval.StreamEvaluator(hnet, normalize=normalize, mean=stream_eval.IMAGENET_MEAN, std=stream_eval.IMAGENET_STD, device=dev)
+            hnet = build_net(spec, params, max_batch=BS, hw=224, options={'whole_batch_launches': 1, 'arena_copies': depth, 'pipeline_depth': depth})
+            ev = stream_eval.StreamEvaluator(hnet, normalize=normalize, mean=stream_eval.IMAGENET_MEAN, std=stream_eval.IMAGENET_STD, device=dev, depth=depth + 1)
             g = torch.Generator().manual_seed(11)
             pool = [torch.randint(0, 256, (BS, 224, 224, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(4)]
             labels = [torch.randint(0, spec.num_classes, (BS,), dtype=torch.int64, generator=g) for _ in range(4)]
@@ -247,7 +251,7 @@ def main():
             r = ev.run(((pool[i % 4], labels[i % 4]) for i in range(args.steps)))
             extra['value_host_fed'] = round(r['img_per_s'], 1)
             extra['host_fed'] = {'input': f'uint8 NHWC [{BS},224,224,3] per batch in page-locked host memory ({BS * 150528 / 1e6:.1f} MB), H2D on a copy stream, '
-                                          'f8_net_run_u8 + f8_topk_correct_f32, two batches in flight', 'top1_on_random_labels': r['top1']}
+                                          f'f8_net_run_u8 + f8_topk_correct_f32, {depth} batches in flight', 'top1_on_random_labels': r['top1']}
             del ev, hnet
 
     result = None
@@ -315,7 +319,7 @@ def main():
                        'launches_per_step': sum(net.step_launches(i, BS) for i in range(n_l)), 'sub_batches': parts, 'autotuned_launches': retiled,
                        'schedule': {0: 'runs back to back (two concurrent sub-batches per run)',
                                     1: 'pipelined: sub-batches of consecutive runs overlap (f8_net_set_pipelined(1))',
-                                    2: 'pipelined: two consecutive batches in flight, each launch covers a whole batch '
+                                    2: f'pipelined: {depth} consecutive batches in flight (one arena copy each), each launch covers a whole batch '
                                        '(f8_net_set_pipelined(2)); every timed step completes inside the timed region; '
                                        'value_unpipelined = the same steps with one batch in flight'}[pipe_mode]},
             # the roof that binds the dominant kernel = the one it is closer to: the stage-chain launches keep the int32 stream on the

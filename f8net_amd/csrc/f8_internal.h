@@ -44,6 +44,9 @@ struct Options {
                                                     // CU, 7 per image: measured 139 us in one 128-image launch, 161 us in 4 chunks)
     int whole_batch_launches = 0;   // planning hint: launches will cover the whole batch (f8_net_set_pipelined(2)), not max_batch / split images
     int pipeline_depth = 2;      // f8_net_set_pipelined(2): runs in flight (2..4, at most `split` arena copies)
+    int shared_streams = 1;      // the internal streams are one set per device, shared by all handles (0: four streams of its own per handle)
+    int arena_copies = 0;        // arena copies allocated at upload; 0 = `split`.  More than `split`: that many whole runs may be in flight
+                                 // under pipelining mode 2 (pipeline_depth) while a non-pipelined run still cuts the batch `split` ways
     int split_streams = 1;       // 0: same launches serialised on the caller's stream (profiling)
     int graph = 0;               // hipGraph capture / replay of a run
     int stagger = -1, stagger_pipelined = 2;

@@ -22,6 +22,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <mutex>
 #include <vector>
 
 using namespace f8;
@@ -138,6 +139,7 @@ struct f8_net {
     uint32_t* d_err = nullptr;         // sticky device error words: [0] an int32 input value outside the head's 8-bit format
     char* d_chain = nullptr; size_t chain_stride = 0;   // per arena copy: sync words + halo exchange rows of the stage-chain launches
     hipEvent_t* events = nullptr; int n_events = 0;
+    bool aux_shared = false;           // aux[] belong to the per-device pool (run_common), not to this handle
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t aux_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t lag_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     const float* in_f32 = nullptr; float in_scale = 0.f; int in_lo = 0, in_hi = 0;   // set by f8_net_run_f32 for the duration of the call
@@ -252,6 +254,8 @@ static const OptKey kOptKeys[] = {
     {"check_device", "F8_CHECK_DEVICE", &Options::check_device, 0, 1, false},
     {"check_input_range", "F8_CHECK_INPUT_RANGE", &Options::check_input_range, 0, 1, false},
     {"pipeline_depth", "F8_PIPELINE_DEPTH", &Options::pipeline_depth, 2, 4, false},
+    {"arena_copies", "F8_ARENA_COPIES", &Options::arena_copies, 0, 4, true},
+    {"shared_streams", "F8_SHARED_STREAMS", &Options::shared_streams, 0, 1, true},
     {"whole_batch_launches", "F8_WHOLE_BATCH_LAUNCHES", &Options::whole_batch_launches, 0, 1, true},
 };
 static const OptKey* find_opt(const char* key) {
@@ -398,7 +402,7 @@ void f8_net_destroy(f8_net* net) {
         for (int i = 0; i < net->n_events; ++i) (void)hipEventDestroy(net->events[i]);
         delete[] net->events;
     }
-    for (int k = 0; k < 4; ++k) if (net->aux[k]) (void)hipStreamDestroy(net->aux[k]);
+    for (int k = 0; k < 4; ++k) if (net->aux[k] && !net->aux_shared) (void)hipStreamDestroy(net->aux[k]);
     for (int k = 0; k < 5; ++k) if (net->aux_ev[k]) (void)hipEventDestroy(net->aux_ev[k]);
     for (int k = 0; k < 4; ++k) if (net->lag_ev[k]) (void)hipEventDestroy(net->lag_ev[k]);
     if (net->g_exec) (void)hipGraphExecDestroy(net->g_exec);
@@ -1748,7 +1752,7 @@ int f8_net_upload(f8_net* net) {
     if (!net || !net->finalized) return fail(F8_ERR_STATE, "f8_net_upload: not finalized");
     if (net->uploaded) return F8_OK;
     hipError_t e;
-    const int parts_cap = net->opt.split;
+    const int parts_cap = std::max(net->opt.split, net->opt.arena_copies);     // arena copies: sub-batches of one run, or whole runs in flight (pipelining mode 2)
     if ((e = hipGetDevice(&net->device)) != hipSuccess) return hip_fail(e, "hipGetDevice");
     net->n_copies = parts_cap;
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, net->device) == hipSuccess && pr.multiProcessorCount > 0) net->num_cu = pr.multiProcessorCount; }
@@ -2329,6 +2333,26 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
     }
     auto ensure_aux = [&]() -> int {
         if (net->aux[0]) return F8_OK;
+        // The internal streams are ONE set per device, shared by every handle of the process.  HIP maps streams onto a few hardware
+        // queues (GPU_MAX_HW_QUEUES, default 4) in creation order: the first handle's streams got a queue each, a later handle's
+        // shared queues with them and its concurrent sub-batches / batches in flight serialised — measured, ResNet-18 with three
+        // batches in flight: the handle created first 330 k img/s, every later one 308 k (all 332 k with GPU_MAX_HW_QUEUES=16;
+        // tools/prof_intmodel.py).  Work of two handles on one stream is ordered, which costs nothing they would not contend for anyway.
+        // (hipGraph capture needs streams of its own: a capture must not see another handle's launches.)
+        static std::mutex pool_mu;
+        static hipStream_t pool[64][4] = {};
+        const int dv = net->device;
+        if (net->opt.shared_streams && !net->opt.graph && dv >= 0 && dv < 64) {
+            std::lock_guard<std::mutex> lk(pool_mu);
+            for (int k = 0; k < 4; ++k) {
+                if (!pool[dv][k]) {
+                    hipError_t e = hipStreamCreateWithFlags(&pool[dv][k], hipStreamNonBlocking);
+                    if (e != hipSuccess) { pool[dv][k] = nullptr; return hip_fail(e, "hipStreamCreate"); }
+                }
+            }
+            for (int k = 0; k < 4; ++k) net->aux[k] = pool[dv][k];
+            net->aux_shared = true;
+        } else
         for (int k = 0; k < 4; ++k) {
             hipError_t e = hipStreamCreateWithFlags(&net->aux[k], hipStreamNonBlocking);
             if (e != hipSuccess) return hip_fail(e, "hipStreamCreate");

@@ -97,6 +97,7 @@ class IntModel(nn.Module):
         self._ptensors = None
         self._head_fl = None
         self._pipelined = 0
+        self._depth = 2
 
     # -- performance path ------------------------------------------------------------------
     def _param_version(self):
@@ -133,7 +134,8 @@ class IntModel(nn.Module):
         ver = self._param_version()
         ent = self._plans.get(key)
         if ent is None or ent[0] != ver or ent[1].max_batch < max_batch:
-            net = build_net(self.spec, self.state_dict(), max_batch, hw)
+            opts = {'whole_batch_launches': 1, 'arena_copies': self._depth, 'pipeline_depth': self._depth} if self._pipelined == 2 else None
+            net = build_net(self.spec, self.state_dict(), max_batch, hw, options=opts)
             if self._pipelined:
                 net.set_pipelined(self._pipelined)
             ent = (ver, net)
@@ -148,13 +150,18 @@ class IntModel(nn.Module):
         self._plans = {}
         self._ptensors = None
 
-    def set_pipelined(self, mode):
-        """Let consecutive forwards overlap inside the library (f8_net_set_pipelined; 2 = two whole batches in flight).
+    def set_pipelined(self, mode, depth=2):
+        """Let consecutive forwards overlap inside the library (f8_net_set_pipelined; 2 = `depth` whole batches in flight, 2..4:
+        one arena copy each).
         CONTRACT (include/f8net.h): a run then no longer waits for work queued on the stream after the PREVIOUS run's entry.
         `forward` / `forward_f32` therefore refuse to allocate in this mode: pass `out=` (buffers that rotate with at least the
         pipeline depth) and hand over inputs produced on another stream with `input_ready=` (an event recorded behind the
         producer); inputs produced on the current stream must have been complete one call earlier."""
-        self._pipelined = 2 if mode in (2, 'alternate') else int(bool(mode))
+        new = 2 if mode in (2, 'alternate') else int(bool(mode))
+        depth = max(2, min(4, int(depth)))
+        if (new == 2) != (self._pipelined == 2) or depth != self._depth:
+            self._plans = {}                                  # whole-batch planning hint / arena copies are decided when a plan is built
+        self._pipelined, self._depth = new, depth
         for _, net in self._plans.values():
             net.set_pipelined(self._pipelined)
 

@@ -227,7 +227,8 @@ int f8_net_check(f8_net* net);
 /* Per-handle tuning options.  A new handle takes its defaults from the environment (F8_<KEY IN CAPITALS>; F8_CHUNK for
  * chunk56) and otherwise the measured best; two handles in one process may differ.  Keys that decide the plan must be set
  * before f8_net_finalize (F8_ERR_STATE afterwards); scheduling keys may change between runs.
- *   planning  : split (1..4 concurrent sub-batches = arena copies), fuse_blocks, fuse_stages (bit mask, -1 = auto), fuse_dual,
+ *   planning  : split (1..4 concurrent sub-batches of a run), arena_copies (0 = split; more: that many whole runs in flight under
+ *               f8_net_set_pipelined(2) with pipeline_depth), fuse_blocks, fuse_stages (bit mask, -1 = auto), fuse_dual,
  *               fuse_ds, fuse_opener, fuse_fc (the classifier writes the caller's logits buffer itself), fuse_stem, fuse_input (the fused stem launch reads the caller's NCHW buffer itself), fuse_ir (1 = where it wins, 2 = every block), fuse_chain (all consecutive bottleneck blocks of a stage in one launch, the int32 residual stream in registers),
  *               fuse_bchain (the same for BasicBlock stages: 1 = consecutive identity blocks, 2 = with the stage-opening block in front), stem_rows (ResNet head:
  *               row-walking kernel, pool in registers), fuse_p12 (7x7 block: first two
