@@ -35,7 +35,7 @@ struct Options {
     int bk128 = 0;               // 128-byte K steps in conv_igemm_kernel
     int dw_dot4 = 1;             // v_dot4 depthwise kernel
     int stem_rows = 1;           // ResNet head: the row-walking kernel (pool in registers) where it has an instance, else the tile kernel
-    int stem_grid_div = 0;       // row-walking head on 1 / n of the CUs; 0 = all of them when it writes int32 (write-bound), a third otherwise
+    int stem_grid_div = 0;       // row-walking head on 1 / n of the CUs; 0 = all of them when it writes int32 (write-bound), half otherwise
     int stem_wpc = 3;            // resident stem workgroups per CU (2 / 3 / 4: 84.0 / 84.5 / 84.7 k img/s, same box)
     int opener_stg = 1;          // stride-2 opener: int8 output staged through LDS into 128-byte lines
     int chunk56 = -1, chunk28 = -1, chunk14 = -1;   // images per chunk of the fused blocks (-1: derived from chunk_budget_mb, 0: whole batch)

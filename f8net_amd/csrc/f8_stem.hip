@@ -526,11 +526,12 @@ hipError_t launch_stem_pool(const StemPoolArgs& a, hipStream_t s) {
         static int ncu2 = 0;
         if (!ncu2) { int dev = 0; hipDeviceProp_t p; ncu2 = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
         const int ntiles = a.N * ((a.P + RB - 1) / RB);
-        // Persistent, one workgroup per CU, on ALL CUs when the launch is write-bound (int32 pooled output: ResNet-18 / 34), on a THIRD of
-        // them otherwise (int8 output: compute-bound): measured, not assumed — with two batches in flight the other batch's launches run
-        // on the rest of the chip, and the sclk the firmware grants the launches AFTER a full-chip run of this kernel is 1.6 % lower
-        // (2345 vs 2383 MHz at LOWER package power, rocm-smi; tools/clk_probe.sh).  Options::stem_grid_div overrides.
-        const int gdiv = a.grid_div > 0 ? a.grid_div : (a.out32 ? 1 : 3);
+        // Persistent, one workgroup per CU, on ALL CUs when the launch is write-bound (int32 pooled output: ResNet-18 / 34), on HALF of
+        // them otherwise (int8 output: compute-bound): measured, not assumed — with several batches in flight the other batches' launches
+        // run on the rest of the chip, and on some boxes of the pool the sclk the firmware grants the launches AFTER a full-chip run of
+        // this kernel is 1.6 % lower (2345 vs 2383 MHz at LOWER package power, rocm-smi; tools/clk_probe.sh).  Options::stem_grid_div
+        // overrides (DESIGN.md §9 has the sweep).
+        const int gdiv = a.grid_div > 0 ? a.grid_div : (a.out32 ? 1 : 2);
         const int gmax = (ncu2 / gdiv + 7) / 8 * 8;                         // a multiple of 8: tile_of's XCD arithmetic
         const int grid = ntiles < gmax ? ntiles : gmax;                     // a workgroup walks slots b, b + grid, ...
         switch (a.raw_kind) {
