@@ -30,7 +30,7 @@ struct S2Cfg {
     static constexpr int NL = PATCH_BYTES / 16 / 512;               // DMA instructions per thread (whole 1 KB wave instructions)
     static constexpr int SPT = CIN / 32;                            // K32 steps per tap
     static constexpr int NB = 8, NBAT = 9 * SPT / NB;               // steps per weight batch, batches
-    static constexpr int NBUF = PT <= 2 ? 4 : 3;
+    static constexpr int NBUF = 3;                                  // (4 for the two-tile instances spills once the B fragments are read a step ahead)
     static_assert(RSPLIT * CSPLIT == 2 && HO % RO == 0 && SPT % NB == 0 && (SPT & (SPT - 1)) == 0 && CIN >= 256, "a workgroup pair per image");
     static_assert(PATCH_BYTES <= 160 * 1024, "LDS");
 };
@@ -105,25 +105,36 @@ __global__ void __launch_bounds__(512) conv3x3s2_wreg_kernel(const ConvArgs a, c
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    static_for<NBAT>([&](auto bc) {                      // static batch index: the tap is a constant
-        constexpr int B = decltype(bc)::value;
-        constexpr int T = (B * NB) / SPT, SB = (B * NB) % SPT;
-        if constexpr (B + NBUF - 1 < NBAT) load_batch(wbuf[(B + NBUF - 1) % NBUF], (B + NBUF - 1) * NB);
-        unsigned eoff[PT], esw[PT];
-#pragma unroll
-        for (int j = 0; j < PT; ++j) {
-            const int ent = ent0[j] + (T / 3) * PC + T % 3;
-            eoff[j] = (unsigned)(ent * CIN); esw[j] = (unsigned)(ent & 15);
-        }
-#pragma unroll
-        for (int s = 0; s < NB; ++s) {
-            const unsigned c2 = (unsigned)(((SB + s + rot) & (SPT - 1)) * 2 + lh);
+    // One flat, fully unrolled K loop (static step index: the tap and the batch are constants).  The B fragments of step G + 1 are read
+    // from the patch BEFORE the multiplies of step G (two register sets): the compiler left a `ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma`
+    // triple per multiply otherwise (found by scanning the ISA for it: 275 of this kernel's 288 multiplies waited for a read issued right
+    // in front of them; no other kernel of the library had the pattern).
+    unsigned eoff[PT], esw[PT];
+    auto rdx = [&](auto gc, v4i (&xf)[PT]) {
+        constexpr int G = decltype(gc)::value, T = G / SPT;
+        if constexpr (G % SPT == 0) {                    // a new tap: its patch entries (the fragments of the previous tap are in registers)
 #pragma unroll
             for (int j = 0; j < PT; ++j) {
-                const v4i xf = *(const v4i*)(patch + eoff[j] + ((c2 ^ esw[j]) << 4));
-                acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[B % NBUF][s], xf, acc[j], 0, 0, 0);
+                const int ent = ent0[j] + (T / 3) * PC + T % 3;
+                eoff[j] = (unsigned)(ent * CIN); esw[j] = (unsigned)(ent & 15);
             }
         }
+        const unsigned c2 = (unsigned)((((G % SPT) + rot) & (SPT - 1)) * 2 + lh);
+#pragma unroll
+        for (int j = 0; j < PT; ++j) xf[j] = *(const v4i*)(patch + eoff[j] + ((c2 ^ esw[j]) << 4));
+    };
+    v4i xa[PT], xb[PT];
+    rdx(std::integral_constant<int, 0>{}, xa);
+    static_for<NK>([&](auto gc) {
+        constexpr int G = decltype(gc)::value, B = G / NB, S = G % NB;
+        if constexpr (S == 0 && B + NBUF - 1 < NBAT) load_batch(wbuf[(B + NBUF - 1) % NBUF], (B + NBUF - 1) * NB);
+        v4i (&cur)[PT] = (G & 1) ? xb : xa;
+        v4i (&nxt)[PT] = (G & 1) ? xa : xb;
+        if constexpr (G + 1 < NK) rdx(std::integral_constant<int, G + 1>{}, nxt);
+#pragma unroll
+        for (int j = 0; j < PT; ++j) asm volatile("" : "+v"(cur[j]));
+#pragma unroll
+        for (int j = 0; j < PT; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[B % NBUF][S], cur[j], acc[j], 0, 0, 0);
     });
 
     const int floor0 = a.relu0 ? 0 : INT32_MIN;
