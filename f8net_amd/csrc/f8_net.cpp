@@ -1747,6 +1747,16 @@ int f8_net_launch_kernel(const f8_net* net, int i, char* buf, size_t cap) {
     return F8_OK;
 }
 
+// Image groups resident at once in a chain launch (grid = groups x tiles per image, one workgroup per CU): a group walks
+// ceil(N / groups) images, so of all group counts that need the same number of rounds the SMALLEST is taken — every group then
+// has the same number of images (128 images on 18 groups of 14 tiles is 8 rounds for 2 groups and 7 for 16; on 16 groups it is 8
+// for all, in the same time, on 224 CUs instead of 252) and the CUs left over run the other batches in flight.
+static int chain_groups(int N, int max_groups) {
+    const int g = std::max(1, std::min(N, max_groups));
+    const int rounds = (N + g - 1) / g;
+    return (N + rounds - 1) / rounds;
+}
+
 // ------------------------------------------------------------------------------ executor
 int f8_net_upload(f8_net* net) {
     if (!net || !net->finalized) return fail(F8_ERR_STATE, "f8_net_upload: not finalized");
@@ -1972,7 +1982,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             const Node& a0 = net->nodes[ds ? hf.fbd_a : hf.fb_a];
             const int C = T[st.out.t].C, MID = a0.cd.cout;
             const int tiles = chain_tiles_per_img(x.H, x.W);
-            a.N = N; a.NG = std::max(1, std::min(N, (net->num_cu > 0 ? std::min(net->num_cu, 256) : 256) / tiles));
+            a.N = N; a.NG = chain_groups(N, (net->num_cu > 0 ? std::min(net->num_cu, 256) : 256) / tiles);
             fill_out(&a.out32, a.q);
             if (!net->d_chain) return fail(F8_ERR_STATE, "f8_net_run: chain scratch missing");
             a.sync = (uint32_t*)(net->d_chain + (size_t)part * net->chain_stride);
@@ -2013,7 +2023,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             else a.xr = (const int32_t*)fp(xs.forms[st.src_f]);
             const Tensor& x = T[st.out.t];
             const int tiles = bchain_tiles_per_img(x.C, x.H, x.W);
-            a.N = N; a.NG = std::max(1, std::min(N, (net->num_cu > 0 ? std::min(net->num_cu, 256) : 256) / tiles));
+            a.N = N; a.NG = chain_groups(N, (net->num_cu > 0 ? std::min(net->num_cu, 256) : 256) / tiles);
             fill_out(&a.out32, a.q);
             if (!net->d_chain) return fail(F8_ERR_STATE, "f8_net_run: chain scratch missing");
             a.sync = (uint32_t*)(net->d_chain + (size_t)part * net->chain_stride);
