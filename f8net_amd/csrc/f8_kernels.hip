@@ -664,27 +664,35 @@ __global__ void __launch_bounds__(256) maxpool_i8x16_kernel(const PoolArgs a) {
 }
 
 // FXQAvgPool2d int branch: int64 sum over H*W, truncate to int32 (fix_quant_ops.py:130-133).
+// Eight lanes per (image, 4 channels): lane j sums the pixels j, j + 8, ... (consecutive lanes read consecutive 16-byte pieces of an
+// I32T tile), three xor-shuffles add the partial sums.  (One thread per (image, 4 channels) walking all 49 pixels was 64 workgroups
+// and a chain of dependent loads for ResNet-18's 12.8 MB: 14 us.)  int32 wrapping adds: what the reference's int64 sum becomes when
+// its result is narrowed (fix_quant_ops.py: FXQAvgPool2d).
 __global__ void __launch_bounds__(256) avgpool_kernel(const AvgArgs a) {
     const int cgs = a.Cs >> 2;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= a.N * cgs) return;
-    const int cg = idx % cgs, n = idx / cgs, c = cg << 2;
-    long long s[4] = {0, 0, 0, 0};
-    for (int i = 0; i < a.HW; ++i) {
+    const int j = idx & 7, item = idx >> 3;
+    const bool live = item < a.N * cgs;                  // (a whole group of 8 lanes is live or not: the shuffles below stay inside it)
+    const int it = live ? item : 0;
+    const int cg = it % cgs, n = it / cgs, c = cg << 2;
+    unsigned t[4] = {0u, 0u, 0u, 0u};
+    for (int i = j; i < a.HW; i += 8) {
         const v4i v = *(const v4i*)(a.x + i32t_index(n * a.HW + i, c, a.Cs));
-        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        t[0] += (unsigned)v.x; t[1] += (unsigned)v.y; t[2] += (unsigned)v.z; t[3] += (unsigned)v.w;
     }
-    int t[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) t[e] = (int)(unsigned)(unsigned long long)s[e];
+    for (int m = 1; m < 8; m <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] += (unsigned)__shfl_xor((int)t[e], m);
+    if (!live || j != 0) return;
     const size_t o = (size_t)n * a.Cs + c;
-    if (a.out32) { v4i v = {t[0], t[1], t[2], t[3]}; *(v4i*)(a.out32 + i32t_index(n, c, a.Cs)) = v; }
+    if (a.out32) { v4i v = {(int)t[0], (int)t[1], (int)t[2], (int)t[3]}; *(v4i*)(a.out32 + i32t_index(n, c, a.Cs)) = v; }
 #pragma unroll
     for (int k = 0; k < 2; ++k)
         if (a.q[k].ptr)
             *(unsigned*)(a.q[k].ptr + o) =
-                pack4(requant1(t[0], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(t[1], a.q[k].n, a.q[k].lo, a.q[k].hi),
-                      requant1(t[2], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1(t[3], a.q[k].n, a.q[k].lo, a.q[k].hi)) ^ a.q[k].bias_xor;
+                pack4(requant1((int)t[0], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1((int)t[1], a.q[k].n, a.q[k].lo, a.q[k].hi),
+                      requant1((int)t[2], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1((int)t[3], a.q[k].n, a.q[k].lo, a.q[k].hi)) ^ a.q[k].bias_xor;
 }
 
 // Stand-alone residual join (only when it cannot ride in a conv epilogue) and stand-alone requant
@@ -1031,7 +1039,7 @@ hipError_t launch_maxpool(const PoolArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_avgpool(const AvgArgs& a, hipStream_t s) {
-    const size_t work = (size_t)a.N * (a.Cs >> 2);
+    const size_t work = (size_t)a.N * (a.Cs >> 2) * 8;
     hipLaunchKernelGGL(avgpool_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
