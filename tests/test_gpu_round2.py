@@ -327,3 +327,28 @@ def test_out_of_format_int32_input_is_reported(dev):
         net.check()                                                   # the word is cleared by the report
         quiet = build_net(spec, params, max_batch=2, hw=hw, options={'check_input_range': 0})
         quiet.run(_t(bad, dev)); quiet.check()
+
+
+def test_handles_share_the_internal_streams_and_stay_independent(dev):
+    """The internal streams are one set per device for every handle of the process (a later handle's own streams shared hardware
+    queues with the first one's and its batches in flight serialised: DESIGN.md round-3 page).  Two nets, three batches in flight
+    each, their runs interleaved call by call on one caller stream: every output equals its oracle."""
+    from f8net_amd.net import build_net
+    cases = []
+    for arch, seed in (('resnet18', 3), ('mobilenet_v2', 4)):
+        spec = topology.get(arch, num_classes=24)
+        params = synth.make_params(spec, seed=seed)
+        x, x_fl = synth.make_input(spec, params, 4, 64, seed=seed + 10)
+        net = build_net(spec, params, max_batch=4, hw=64, options={'whole_batch_launches': 1, 'arena_copies': 3, 'pipeline_depth': 3})
+        net.upload(); net.set_pipelined(2)
+        want = oracle.net_forward(spec, params, x, x_fl)
+        outs = [torch.empty((4, 24), dtype=torch.float32, device=dev) for _ in range(4)]
+        cases.append((net, _t(x, dev), want, outs))
+    for rep in range(9):
+        for net, xd, want, outs in cases:
+            net.run(xd, out=outs[rep % 4])
+    torch.cuda.synchronize()
+    for net, xd, want, outs in cases:
+        net.check()
+        for o in outs:
+            assert np.array_equal(o.cpu().numpy(), want)

@@ -105,6 +105,8 @@ OPTION_SETS = [
     ({'wstat': 0}, None), ({'wstat_min_tiles': 0}, 'wstat'), ({'s2wreg': 0}, None), ({'wreg': 0}, None), ({'fuse_p12': 0}, None),
     ({'fuse_opener': 0}, None), ({'opener_stg': 0}, 'fused_opener_s2'), ({'fuse_fc': 0}, 'output'), ({'fuse_input': 0}, None),
     ({'wstat_fast': 0}, None), ({'split': 3, 'pipeline_depth': 3}, None),
+    ({'arena_copies': 3, 'pipeline_depth': 3}, None), ({'arena_copies': 4, 'pipeline_depth': 4}, None),      # bench.py's schedule: whole batches in flight, split stays 2
+    ({'shared_streams': 0}, None),
     ({'stem_rows': 0}, None), ({'stem_rows': 0, 'fuse_input': 0}, None),      # the tile kernel of the head (f8_stem.hip), raw input / haloed form
 ]
 
@@ -132,9 +134,10 @@ def test_options_keep_results_bit_exact_at_full_resolution():
         net.check()
         assert np.array_equal(got, want), opts
         net.set_pipelined(2)
-        outs = [torch.empty((8, 1000), dtype=torch.float32, device='cuda') for _ in range(3)]
-        for rep in range(5):
-            net.run(xd, out=outs[rep % 3])
+        nb = max(3, opts.get('pipeline_depth', 2) + 1)
+        outs = [torch.empty((8, 1000), dtype=torch.float32, device='cuda') for _ in range(nb)]
+        for rep in range(2 * nb + 1):
+            net.run(xd, out=outs[rep % nb])
         torch.cuda.synchronize()
         net.check()
         assert all(np.array_equal(o.cpu().numpy(), want) for o in outs), opts
