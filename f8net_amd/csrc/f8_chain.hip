@@ -650,7 +650,7 @@ static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t s) {
 // K steps per register batch, batches per stream (NB, NBUF) of the 56x56 / 28x28 / 14x14 instances (tuning builds override; measured:
 // deeper batches than these spill — a scratch reload in front of a K loop waits for every weight load in flight — and are slower)
 #ifndef F8_CH_S0
-#define F8_CH_S0 2, 3
+#define F8_CH_S0 2, 2
 #endif
 #ifndef F8_CH_S1
 #define F8_CH_S1 2, 3

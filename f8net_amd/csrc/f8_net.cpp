@@ -1272,7 +1272,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     st.name = "stage_chain_x" + std::to_string(ch.size()) + (ds ? "_ds:" : ":") + tname(net, a0.out) + ".." + tname(net, nd.out);
                     char kb[160];
                     const int C = o.C, MID = a0.cd.cout;
-                    snprintf(kb, sizeof kb, "f8::chain_kernel<%d, %d, %d, %d, 4, %d, %s>", C, MID, x.W, x.H, a0.cd.cin, MID == 256 ? "2, 4, true, false" : "2, 3, true, false");   // keep in sync with launch_chain (the FAST instance: real fraclen tables)
+                    snprintf(kb, sizeof kb, "f8::chain_kernel<%d, %d, %d, %d, 4, %d, %s>", C, MID, x.W, x.H, a0.cd.cin, MID == 256 ? "2, 4, true, false" : (MID == 64 ? "2, 2, true, false" : "2, 3, true, false"));   // keep in sync with launch_chain (the FAST instance: real fraclen tables)
                     st.kernel = kb;
                     break;
                 }
