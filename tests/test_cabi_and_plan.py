@@ -214,3 +214,14 @@ def test_two_consumer_formats_and_fallback():
     net.finalize(2)
     plan = net.describe()
     assert plan.count('requant:') == 1, plan
+
+
+def test_smoke_plans_hold_the_kernels_smoke_asserts():
+    """__graft_entry__.smoke() asserts that its small nets run the round's kernels; the same plans, checked without a GPU (a plan
+    change that silently drops one of them would otherwise only fail on the GPU box)."""
+    r50 = topology.get('resnet50', normalize=True)
+    plan = build_net(r50, synth.make_params(r50, seed=3, fraclens=topology.R50_NVIDIA_FRACLENS), max_batch=2, hw=224).describe()
+    assert all(k in plan for k in ('stem7x7s2+maxpool3x3s2', 'stage_chain_x5', '_dual', 'fused_p12')), plan
+    r18 = topology.get('resnet18')
+    plan = build_net(r18, synth.make_params(r18, seed=3), max_batch=2, hw=224).describe()
+    assert 'basic_chain_x2_ds' in plan and 'patch' in plan, plan
