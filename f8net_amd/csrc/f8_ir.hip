@@ -23,7 +23,11 @@
 
 namespace f8 {
 
-template <int CIN_S, int COUT_S>
+// P2MMA: the depthwise phase on the matrix cores (instances whose project accumulators leave 52 registers for it)
+// FQ: both inner requantisations are right shifts into UNSIGNED 8-bit behind a ReLU (every block of MobileNet-V2): the ReLU is the clamp's
+// lower bound (requant is monotone and maps 0 to 0), the bias rides in the accumulators' start value, the shift is requant_shr: 5 vector
+// operations per expanded value instead of 9 — and the expanded values are what this kernel is bound by (VALU, not memory)
+template <int CIN_S, int COUT_S, bool FQ, bool P2MMA = (COUT_S <= 96)>
 __global__ void __launch_bounds__(256) fused_ir_kernel(const IRArgs a) {
     constexpr int KK1 = CIN_S / 32, NCO = COUT_S / 32;
     constexpr int W0_BYTES = 64 * CIN_S, W4_BYTES = COUT_S * 64;
@@ -138,6 +142,8 @@ __global__ void __launch_bounds__(256) fused_ir_kernel(const IRArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc3[j][r] = 0;
     const int floor_a = a.relu_a ? 0 : INT32_MIN, floor_b = a.relu_b ? 0 : INT32_MIN;
+    const unsigned half1 = FQ ? 1u << (a.n1 - 1) : 0u, half2 = FQ ? 1u << (a.n2 - 1) : 0u;
+    (void)floor_a; (void)half1; (void)half2;
     const unsigned padv = a.xor1;
 
     for (int e = 0; e < nchunk; ++e) {
@@ -153,7 +159,12 @@ __global__ void __launch_bounds__(256) fused_ir_kernel(const IRArgs a) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] = 0;
+                for (int gq = 0; gq < 4; ++gq) {
+                    v4i bv = {0, 0, 0, 0};
+                    if constexpr (FQ) bv = *(const v4i*)(wb + OFF_B0 + (i * 32 + 8 * gq + 4 * lh) * 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[i][4 * gq + q] = bv[q];
+                }
 #pragma unroll
             for (int kk = 0; kk < KK1; ++kk) {
                 const v4i xf = *(const v4i*)(X + ((size_t)kk * a.xp + pt * 32 + l31) * 32 + lh * 16);
@@ -176,11 +187,17 @@ __global__ void __launch_bounds__(256) fused_ir_kernel(const IRArgs a) {
                 unsigned d[4];
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
-                    const v4i bv = *(const v4i*)(wb + OFF_B0 + (i * 32 + 8 * gq + 4 * lh) * 4);
                     int y[4];
+                    if constexpr (FQ) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) y[q] = requant1(max((int)((unsigned)acc[i][4 * gq + q] + (unsigned)bv[q]), floor_a), a.n1, a.lo1, a.hi1);
-                    d[gq] = pack4(y[0], y[1], y[2], y[3]) ^ a.xor1;
+                        for (int q = 0; q < 4; ++q) y[q] = requant_shr(acc[i][4 * gq + q], a.n1, half1, 0u, 0, 255);
+                        d[gq] = pack4(y[0], y[1], y[2], y[3]) ^ 0x80808080u;
+                    } else {
+                        const v4i bv = *(const v4i*)(wb + OFF_B0 + (i * 32 + 8 * gq + 4 * lh) * 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) y[q] = requant1(max((int)((unsigned)acc[i][4 * gq + q] + (unsigned)bv[q]), floor_a), a.n1, a.lo1, a.hi1);
+                        d[gq] = pack4(y[0], y[1], y[2], y[3]) ^ a.xor1;
+                    }
                 }
                 auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
                 auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
@@ -192,7 +209,68 @@ __global__ void __launch_bounds__(256) fused_ir_kernel(const IRArgs a) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                      // patch complete
-        // ================= P2: depthwise 3x3 on the patch -> mid2   (one item = one output pixel x 16 channels)
+        // ================= P2: depthwise 3x3 on the patch -> mid2
+        if constexpr (P2MMA) {
+            // ... ON THE MATRIX CORES: for a 32-channel tile the 3x3 depthwise conv is nine v_mfma_i32_32x32x32_i8 with a DIAGONAL
+            // weight fragment (A[c][k] = w[tap][c] for k == c, else 0) — the B operand is the patch pixel as it lies in LDS (16 channels
+            // per lane half), nothing is byte-transposed, the accumulators start at the bias and come out in the layout the epilogue of
+            // every conv in the library turns into a 16-byte row (permlane32 swap).  The VALU version below spends 8 v_perm_b32 + 4 v_dot4
+            // per quad and tap group on transposing 4 taps x 4 channels: ~9 vector operations per output against 9 MFMAs per 1024.
+            const int npo = (OUT_PX + 31) >> 5;
+            for (int ctd = 0; ctd < nct; ++ctd) {
+                if (wave >= npo) break;
+                v4i wa[9];                                       // the nine diagonal fragments of this 32-channel tile
+                {
+                    const int cch = ctd * 32 + l31;              // channel (of the chunk) this lane's A row belongs to
+                    const unsigned* wq = (const unsigned*)(wb + OFF_DW + (cch >> 2) * 36);      // [wA0..3, wB0..3, wC]: dot4 image
+                    const unsigned dA = wq[cch & 3], dB = wq[4 + (cch & 3)], dC = wq[8];
+                    const bool mine = (l31 >> 4) == lh;          // K index == row index: rows 0-15 live in K half 0, 16-31 in half 1
+                    const int dsel = (l31 & 15) >> 2, bsh = 8 * (l31 & 3);
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const unsigned wv = t < 4 ? (dA >> (8 * t)) & 0xffu : t < 8 ? (dB >> (8 * (t - 4))) & 0xffu : (dC >> (8 * (cch & 3))) & 0xffu;
+                        const int piece = mine ? (int)(wv << bsh) : 0;
+                        wa[t] = v4i{dsel == 0 ? piece : 0, dsel == 1 ? piece : 0, dsel == 2 ? piece : 0, dsel == 3 ? piece : 0};
+                    }
+                }
+                for (int pt = wave; pt < npo; pt += 4) {
+                    const int op = pt * 32 + l31;
+                    const bool ok2 = op < OUT_PX;
+                    int g, orow, ocol;
+                    split_out(ok2 ? op : 0, g, orow, ocol);
+                    const char* pp = patch + ((size_t)((g * PR + orow * s) * PW + ocol * s)) * 64 + ctd * 32 + lh * 16;
+                    v16i acc2;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const v4i bv = *(const v4i*)(wb + OFF_DWB + (ctd * 32 + 8 * gq + 4 * lh) * 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc2[4 * gq + q] = bv[q];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const v4i xf = *(const v4i*)(pp + ((t / 3) * PW + t % 3) * 64);
+                        acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wa[t], xf, acc2, 0, 0, 0);
+                    }
+                    unsigned d[4];
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        if constexpr (FQ)
+                            d[gq] = pack4(requant_shr(acc2[4 * gq], a.n2, half2, 0u, 0, 255), requant_shr(acc2[4 * gq + 1], a.n2, half2, 0u, 0, 255),
+                                          requant_shr(acc2[4 * gq + 2], a.n2, half2, 0u, 0, 255), requant_shr(acc2[4 * gq + 3], a.n2, half2, 0u, 0, 255)) ^ 0x80808080u;
+                        else
+                            d[gq] = pack4(requant1(max(acc2[4 * gq], floor_b), a.n2, a.lo2, a.hi2), requant1(max(acc2[4 * gq + 1], floor_b), a.n2, a.lo2, a.hi2),
+                                          requant1(max(acc2[4 * gq + 2], floor_b), a.n2, a.lo2, a.hi2), requant1(max(acc2[4 * gq + 3], floor_b), a.n2, a.lo2, a.hi2)) ^ a.xor2;
+                    }
+                    auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+                    auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+                    if (ok2) {
+                        const v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
+                        *(v4i*)(mid2 + ctd * 4096 + op * 32 + lh * 16) = o;
+                    }
+                }
+            }
+        } else {
+        //                  (VALU: one item = one output pixel x 16 channels)
         for (int it = tid; it < OUT_PX * 4; it += 256) {
             const int op = it >> 2, cg = it & 3;
             if (cg >= nct * 2) continue;
@@ -236,6 +314,7 @@ __global__ void __launch_bounds__(256) fused_ir_kernel(const IRArgs a) {
             }
             const v4i o = {(int)outw[0], (int)outw[1], (int)outw[2], (int)outw[3]};
             *(v4i*)(mid2 + (cg >> 1) * 4096 + op * 32 + (cg & 1) * 16) = o;
+        }
         }
         (void)padv;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -349,19 +428,19 @@ bool fused_ir_config(int cinS, int coutS, int H, int W, int stride, int* R, int*
     return true;
 }
 
-template <int CIN_S, int COUT_S>
+template <int CIN_S, int COUT_S, bool FQ>
 static hipError_t launch_ir_t(const IRArgs& a, int lds, hipStream_t s) {
     // dynamic LDS above 64 KB must be opted into per kernel AND per device (a process may drive several GPUs): keep the maximum per device
     static int attr_lds[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
     if (dev < 0 || lds > attr_lds[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)fused_ir_kernel<CIN_S, COUT_S>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)fused_ir_kernel<CIN_S, COUT_S, FQ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         if (dev >= 0) attr_lds[dev] = lds;
     }
     const int grid = a.G > 1 ? (a.N + a.G - 1) / a.G : a.N * a.tiles_per_img;
-    hipLaunchKernelGGL((fused_ir_kernel<CIN_S, COUT_S>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((fused_ir_kernel<CIN_S, COUT_S, FQ>), dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
@@ -369,7 +448,10 @@ hipError_t launch_fused_ir(const IRArgs& a0, int cinS, int coutS, hipStream_t s)
     IRArgs a = a0;
     int lds = 0;
     if (!ir_layout(cinS, coutS, a.H, a.W, a.stride, a.R, a.G, &a, &lds)) return hipErrorInvalidValue;
-#define F8_IR(C_, O_) if (cinS == C_ && coutS == O_) return launch_ir_t<C_, O_>(a, lds, s);
+    // FQ: ReLU + right shift into unsigned 8-bit after the expand AND the depthwise conv (the VALU depthwise path keeps its general epilogue)
+    const bool fq = a.relu_a && a.relu_b && a.n1 > 0 && a.n2 > 0 && a.lo1 == 0 && a.lo2 == 0 && a.hi1 == 255 && a.hi2 == 255 &&
+                    a.xor1 == 0x80808080u && a.xor2 == 0x80808080u && coutS <= 96;
+#define F8_IR(C_, O_) if (cinS == C_ && coutS == O_) return fq ? launch_ir_t<C_, O_, true>(a, lds, s) : launch_ir_t<C_, O_, false>(a, lds, s);
     F8_IR(32, 32) F8_IR(32, 64) F8_IR(64, 64) F8_IR(64, 96) F8_IR(96, 96) F8_IR(96, 160) F8_IR(160, 160) F8_IR(160, 320)
 #undef F8_IR
     return hipErrorInvalidValue;

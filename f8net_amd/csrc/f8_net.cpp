@@ -1374,7 +1374,12 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     char kb[200];
                     snprintf(kb, sizeof kb, "fused_ir_s%d_%s:", nb.cd.stride, nd.ir_G > 1 ? ("G" + std::to_string(nd.ir_G)).c_str() : ("R" + std::to_string(nd.ir_R)).c_str());
                     st.name = std::string(kb) + tname(net, na.out) + "+" + tname(net, nb.out) + "+" + tname(net, nd.out);
-                    snprintf(kb, sizeof kb, "f8::fused_ir_kernel<%d, %d>", x.Cs, nd.coutP);
+                    {   // keep in sync with launch_fused_ir (FQ) and f8_ir.hip (P2MMA)
+                        int n1 = 0, n2 = 0;
+                        consumer_format(T[nb.a], nb.cd, &n1, "finalize"); consumer_format(T[nd.a], nd.cd, &n2, "finalize");
+                        const bool fq = na.cd.relu && nb.cd.relu && !nb.cd.input_signed && !nd.cd.input_signed && n1 > 0 && n2 > 0 && nd.coutP <= 96;
+                        snprintf(kb, sizeof kb, "f8::fused_ir_kernel<%d, %d, %s, %s>", x.Cs, nd.coutP, fq ? "true" : "false", nd.coutP <= 96 ? "true" : "false");
+                    }
                     st.kernel = kb;
                     break;
                 }
