@@ -1021,13 +1021,13 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         int R = 0, G = 0;
         if (!fused_ir_config(x.Cs, round_up(c.cd.cout, 32), x.H, x.W, b.cd.stride, &R, &G)) continue;
         if (opt.fuse_ir == 1) {
-            // Where the fused launch wins (MobileNet-V2, 128 images, fused vs the three launches, us): 56x56 / 2: 64 vs 77; 28x28:
-            // 50 vs 53; 28x28 / 2: 33 vs 38; 14x14, E = 384: 33 vs 39.  It loses where one workgroup's chunk loop is the critical
-            // path — 7x7 maps (64 workgroups for 128 images: 85 vs 36) and E = 576 at 14x14 (51 vs 47) — and on the two largest
-            // maps, where a 2-row tile recomputes every expand row twice and the requantisation of the expanded tensor is VALU
-            // bound (112x112 / 2: 153 vs 139; 56x56: 141 vs 127).  fuse_ir = 2 fuses every block that has an instance.
-            const int opx = T[c.out].H * T[c.out].W;
-            if (opx < 196 || round_up(a0.cd.cout, 32) > 384 || x.W > 56 || (x.W >= 56 && b.cd.stride == 1)) continue;
+            // Where the fused launch wins (measured per block on MobileNet-V2 at 128 images, round 3 — after the depthwise phase moved to
+            // the matrix cores and the requantisations to five operations; three launches / fused, us): stage 1 (112x112 / 2 and 56x56
+            // maps: the 6x expanded tensor is 154 MB) 139.5 / 118.6 and 126.3 / 108.0; stage 2 (56x56 / 2, 28x28): 138 / 50.6, 69 / 40.4,
+            // 68 / 38.7; stages 3 - 4 (28x28 / 2, 14x14): 44 / 30.5, 48 / 34.4, 46 / 33.3, 45 / 30.5, 51 / 37.4 and, with 576 expanded
+            // channels, 49.1 / 46.3 and 46.1 / 43.3.  The 7x7 blocks (960 channels = 15 chunks over 49 pixels, 64 workgroups for 128
+            // images) stay three launches: 34 - 40 / 90 - 114.  fuse_ir = 2 fuses every block that has an instance.
+            if (T[c.out].H * T[c.out].W < 128) continue;
         }
         a0.absorbed_by = i; b.absorbed_by = i;
         c.ir_a = ta.prod; c.ir_b = tb.prod; c.ir_R = R; c.ir_G = G;

@@ -80,7 +80,7 @@ def test_run_without_gpu_fails_loudly():
 
 
 @pytest.mark.parametrize('arch,launches,fused,dual', [('resnet18', 23, 0, 0), ('resnet50', 38, 5, 3), ('mobilenet_v1', 30, 0, 0),
-                                                       ('mobilenet_v2', 39, 0, 0)])
+                                                       ('mobilenet_v2', 31, 0, 0)])
 def test_plan_fuses_requant_relu_residual(arch, launches, fused, dual):
     spec = topology.get(arch)
     # one launch per block (the stage-chain launches of f8_chain.hip / f8_bchain.hip have their own plan tests below)
@@ -103,7 +103,7 @@ def test_plan_fuses_requant_relu_residual(arch, launches, fused, dual):
     assert opener == (1 if arch == 'resnet50' else 0)
     # MobileNet-V2: every inverted-residual block (expand -> depthwise -> project [+ residual]) is ONE launch (f8_ir.hip)
     ir = [l for l in plan.splitlines() if 'fused_ir_' in l]
-    assert len(ir) == (8 if arch == 'mobilenet_v2' else 0)      # the blocks where the fused launch wins (option fuse_ir = 2: all 16)
+    assert len(ir) == (12 if arch == 'mobilenet_v2' else 0)     # the blocks where the fused launch wins: all but the 7x7 ones (option fuse_ir = 2: all 16)
     assert plan.count('_res:') + plan.count('_dual:') + fused + opener + sum('res=1' in l for l in ir) == n_res_blocks
     # the 7x7 identity blocks of ResNet-50: body.0 + body.2 are one launch (f8_p12.hip), the residual-carrying 1x1 stays
     assert plan.count('fused_p12:') == (2 if arch == 'resnet50' else 0)
