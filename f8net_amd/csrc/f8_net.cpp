@@ -1113,7 +1113,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     Node& c = ND[T[nd.a].prod];
                     if (c.kind == N_CONV && c.cd.groups == 1 && c.fused_add < 0 && ND[T[c.a].prod].kind == N_INPUT && T[c.a].consumers.size() == 1 &&
                         c.a != net->out_t && (!c.cd.quant_input || T[c.a].fl == c.cd.input_fl) && opt.fuse_stem &&
-                        stem_pool_supported(c.cd.cin, c.cd.cout, c.cd.kernel, c.cd.stride, c.cd.pad, nd.pk, nd.pstride, nd.ppad, o.H, o.W, opt.stem_rows)) {
+                        stem_pool_supported(c.cd.cin, c.cd.cout, c.cd.kernel, c.cd.stride, c.cd.pad, nd.pk, nd.pstride, nd.ppad, o.H, o.W, opt.stem_rows, T[c.a].H, T[c.a].W)) {
                         c.sp_pool = i; nd.sp_conv = T[nd.a].prod;
                         break;                                   // no HBM form of the conv output
                     }
@@ -1194,7 +1194,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     st.bytes_per_img = (double)s.H * s.W * 4 + (double)o.H * o.W * o.Cs * ((st.out.f32 >= 0 ? 4 : 0) + (st.out.f8[0] >= 0) + (st.out.f8[1] >= 0));
                     st.bytes_const = (double)nd.coutP * (nd.ktot + 4);
                     st.name = "stem7x7s2+maxpool3x3s2:" + tname(net, nd.out) + "+" + tname(net, pl.out);
-                    st.kernel = (opt.stem_rows && T[pl.out].W >= 2 && T[pl.out].W <= 56) ? "f8::stem_rows_kernel" : "f8::stem_pool_kernel";    // keep in sync with launch_stem_pool
+                    st.kernel = (opt.stem_rows && T[pl.out].W >= 2 && T[pl.out].W <= 56 && s.W == 4 * T[pl.out].W && s.H == 4 * T[pl.out].H) ? "f8::stem_rows_kernel" : "f8::stem_pool_kernel";    // keep in sync with launch_stem_pool
                     break;
                 }
                 if (nd.bchain_into == i) {

@@ -515,9 +515,10 @@ static bool stem_rows_ok(const StemPoolArgs& a) {
     return a.rW == 2 * a.Qc && a.rH == 2 * a.Pc;
 }
 
-bool stem_pool_supported(int cin, int cout, int k, int stride, int pad, int pool_k, int pool_s, int pool_p, int P, int Q, int rows) {
+bool stem_pool_supported(int cin, int cout, int k, int stride, int pad, int pool_k, int pool_s, int pool_p, int P, int Q, int rows, int H, int W) {
     if (!(cin <= 4 && cout == 64 && k == 7 && stride == 2 && pad == 3 && pool_k == 3 && pool_s == 2 && pool_p == 1 && P > 0 && Q > 0)) return false;
-    return (P % TP == 0 && Q % TQ == 0) || (rows && Q >= 2 && Q <= 2 * SW);     // tile kernel | row-walking kernel (launch_stem_pool picks)
+    // tile kernel | row-walking kernel (launch_stem_pool picks; the latter wants input sides that are multiples of 4: stem_rows_ok)
+    return (P % TP == 0 && Q % TQ == 0) || (rows && Q >= 2 && Q <= 2 * SW && H == 4 * P && W == 4 * Q);
 }
 
 hipError_t launch_stem_pool(const StemPoolArgs& a, hipStream_t s) {

@@ -352,3 +352,23 @@ def test_handles_share_the_internal_streams_and_stay_independent(dev):
         net.check()
         for o in outs:
             assert np.array_equal(o.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('hw', [56, 70, 100, 120])
+def test_resnet_head_at_odd_sizes(dev, hw):
+    """The row-walking head takes input sides that are multiples of 4 (ragged last band, one strip, lanes past the image); other sizes
+    keep the tile kernel or the unfused pair: 56 -> pooled 14x14 (two bands), 100 -> 25x25 (3 bands + 4 rows), 120 -> 30x30 (two strips,
+    the second 2 columns wide), 70 -> conv 35x35, pool 18x18 (no fused head).  ResNet-18, bs 3, against the oracle; uint8 entry too."""
+    from f8net_amd.net import build_net
+    spec = topology.get('resnet18', num_classes=16)
+    params = synth.make_params(spec, seed=21)
+    x, x_fl = synth.make_input(spec, params, 3, hw, seed=22)
+    net = build_net(spec, params, max_batch=3, hw=hw)
+    plan = net.describe()
+    assert ('stem7x7s2+maxpool3x3s2' in plan) == (hw % 4 == 0), plan
+    want = oracle.net_forward(spec, params, x, x_fl)
+    got = net.run(_t(x, dev)).cpu().numpy()
+    net.check()
+    assert np.array_equal(got, want)
+    got1 = net.run(_t(x[:1], dev)).cpu().numpy()
+    assert np.array_equal(got1, want[:1])
