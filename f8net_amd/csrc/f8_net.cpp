@@ -2347,7 +2347,11 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
         return F8_OK;
     }
     auto ensure_aux = [&]() -> int {
-        if (net->aux[0]) return F8_OK;
+        if (net->aux[0] && !(net->opt.graph && net->aux_shared)) return F8_OK;
+        if (net->aux[0]) {                               // `graph` was switched on after the pooled streams were taken: streams of its own
+            for (int k = 0; k < 4; ++k) { (void)hipStreamSynchronize(net->aux[k]); net->aux[k] = nullptr; }
+            net->aux_shared = false;
+        }
         // The internal streams are ONE set per device, shared by every handle of the process.  HIP maps streams onto a few hardware
         // queues (GPU_MAX_HW_QUEUES, default 4) in creation order: the first handle's streams got a queue each, a later handle's
         // shared queues with them and its concurrent sub-batches / batches in flight serialised — measured, ResNet-18 with three
@@ -2373,6 +2377,7 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
             if (e != hipSuccess) return hip_fail(e, "hipStreamCreate");
         }
         for (int k = 0; k < 5; ++k) {
+            if (net->aux_ev[k]) continue;
             hipError_t e = hipEventCreateWithFlags(&net->aux_ev[k], hipEventDisableTiming);
             if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
         }

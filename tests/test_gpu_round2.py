@@ -372,3 +372,24 @@ def test_resnet_head_at_odd_sizes(dev, hw):
     assert np.array_equal(got, want)
     got1 = net.run(_t(x[:1], dev)).cpu().numpy()
     assert np.array_equal(got1, want[:1])
+
+
+def test_graph_switched_on_after_the_first_runs(dev):
+    """`graph` is a scheduling key: switched on after a handle already took the device's shared internal streams, the handle moves to
+    streams of its own (a capture must not see another handle's launches) and keeps its results."""
+    from f8net_amd.net import build_net
+    spec = topology.get('resnet18', num_classes=16)
+    params = synth.make_params(spec, seed=31)
+    x, x_fl = synth.make_input(spec, params, 4, 64, seed=32)
+    want = oracle.net_forward(spec, params, x, x_fl)
+    net = build_net(spec, params, max_batch=4, hw=64)
+    other = build_net(spec, params, max_batch=4, hw=64)
+    xd = _t(x, dev)
+    assert np.array_equal(net.run(xd).cpu().numpy(), want)
+    assert np.array_equal(other.run(xd).cpu().numpy(), want)
+    net.set_option('graph', 1)
+    out = torch.empty((4, 16), dtype=torch.float32, device=dev)
+    for _ in range(4):                                   # eager, capture, replay, replay
+        net.run(xd, out=out)
+        assert np.array_equal(other.run(xd).cpu().numpy(), want)
+        assert np.array_equal(out.cpu().numpy(), want)
