@@ -34,6 +34,7 @@ struct Options {
     int deep_nk = 7;             // K loops of at least this many steps use the deepest DMA ring
     int bk128 = 0;               // 128-byte K steps in conv_igemm_kernel
     int dw_dot4 = 1;             // v_dot4 depthwise kernel
+    int dw_mma = 1;              // depthwise 3x3 on the matrix cores (f8_dwmma.hip) where it has an instance (output width >= 14, int8 outputs)
     int stem_rows = 1;           // ResNet head: the row-walking kernel (pool in registers) where it has an instance, else the tile kernel
     int stem_grid_div = 0;       // row-walking head on 1 / n of the CUs; 0 = all of them when it writes int32 (write-bound), half otherwise
     int stem_wpc = 3;            // resident stem workgroups per CU (2 / 3 / 4: 84.0 / 84.5 / 84.7 k img/s, same box)
@@ -112,6 +113,7 @@ struct DwArgs {
     int32_t* out32;
     QuantOut q[2];
     int32_t use_dot4;                      // Options::dw_dot4
+    int32_t use_mma;                       // Options::dw_mma
 };
 
 struct PoolArgs {                          // max-pool, NHWC
@@ -316,6 +318,8 @@ hipError_t launch_fused_ir(const IRArgs& a, int cinS, int coutS, hipStream_t s);
 // 3x3 / stride 1 / pad 1 with the input patch resident in LDS (f8_conv3x3.hip); config = false: no instance
 bool conv3x3_patch_config(int cin, int H, int W, int coutP, int* R, int* IMGS, int* BN);
 hipError_t launch_conv3x3_patch(const ConvArgs& a, int cin, hipStream_t s);
+bool dwconv_mma_supported(const DwArgs& a);
+hipError_t launch_dwconv_mma(const DwArgs& a, hipStream_t s);
 bool stem_pool_supported(int cin, int cout, int k, int stride, int pad, int pool_k, int pool_s, int pool_p, int P, int Q, int rows, int H, int W);
 hipError_t launch_stem_pool(const StemPoolArgs& a, hipStream_t s);
 hipError_t launch_dwconv(const DwArgs& a, hipStream_t s);

@@ -1016,6 +1016,7 @@ hipError_t launch_conv(const ConvArgs& a0, const ConvTile& t, hipStream_t s) {
 
 hipError_t launch_dwconv(const DwArgs& a, hipStream_t s) {
     // dot4 kernel: int8 outputs only, stride 1 / 2, pad 1, channel stride a multiple of 16 (always: Cs % 32 == 0)
+    if (a.use_mma && dwconv_mma_supported(a)) return launch_dwconv_mma(a, s);
     if (a.use_dot4 && !a.out32 && a.w4 && a.pad == 1 && (a.stride == 1 || a.stride == 2)) {
         const size_t work = (size_t)a.N * a.P * ((a.Q + 1) / 2) * (a.Cs >> 4);
         const unsigned grid = (unsigned)((work + 255) / 256);

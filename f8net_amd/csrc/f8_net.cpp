@@ -237,6 +237,7 @@ static const OptKey kOptKeys[] = {
     {"deep_nk", "F8_DEEP_NK", &Options::deep_nk, 1, 1 << 20, true},
     {"bk128", "F8_BK128", &Options::bk128, 0, 1, true},
     {"dw_dot4", "F8_DW_DOT4", &Options::dw_dot4, 0, 1, true},
+    {"dw_mma", "F8_DW_MMA", &Options::dw_mma, 0, 1, true},
     {"stem_wpc", "F8_STEM_WPC", &Options::stem_wpc, 1, 8, false},
     {"stem_rows", "F8_STEM_ROWS", &Options::stem_rows, 0, 1, true},
     {"stem_grid_div", "F8_STEM_GRID_DIV", &Options::stem_grid_div, 0, 32, false},
@@ -716,7 +717,16 @@ static void label_conv_step(f8_net* net, Step& st, const Node& nd) {
     if (nd.p3_R > 0) snprintf(buf, sizeof buf, "conv3x3s1_patch_R%dx%d_bn%d%s:%s", nd.p3_R, nd.p3_imgs, nd.p3_bn, st.res_t >= 0 ? "_res" : "",
                               tname(net, nd.out).c_str());
     st.name = buf;
-    if (nd.depthwise) snprintf(buf, sizeof buf, "f8::dwconv3x3_dot4_kernel<%d, 2>", d.stride);
+    if (nd.depthwise) {
+        const Tensor& od = net->tensors[nd.out];         // keep in sync with launch_dwconv / dwconv_mma_supported / launch_dwconv_mma (FQ)
+        bool fq = d.relu;
+        int n8 = 0;
+        for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) { const Form& F = od.forms[st.out.f8[k]]; ++n8; if (!(F.n > 0 && !F.sgn)) fq = false; }
+        const bool mma = net->opt.dw_mma && st.out.f32 < 0 && n8 > 0 && d.pad == 1 && (d.stride == 1 || d.stride == 2) && od.W >= 28 &&
+                         (d.stride == 1 ? (od.H == s.H && od.W == s.W) : (s.H == 2 * od.H && s.W == 2 * od.W));
+        if (mma) snprintf(buf, sizeof buf, "f8::dwconv3x3_mma_kernel<%d, %s>", d.stride, fq ? "true" : "false");
+        else snprintf(buf, sizeof buf, "f8::dwconv3x3_dot4_kernel<%d, 2>", d.stride);
+    }
     else if (nd.p3_R > 0) snprintf(buf, sizeof buf, "f8::conv3x3_patch_kernel<%d, %d, %d, %d, %d, %d, %s>", d.cin, s.W, nd.p3_R, nd.p3_imgs, nd.p3_bn,
                                    d.cin == 64 ? 64 : (nd.p3_bn == 128 ? 128 : 256), st.res_t >= 0 ? "true" : "false");   // keep in sync with launch_conv3x3_patch
     else {
@@ -2090,7 +2100,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             a.x = (const int8_t*)fp(sF); a.w = (const int8_t*)(net->d_w + nd.w_off); a.bias = (const int32_t*)(net->d_w + nd.b_off);
             a.w4 = (const int8_t*)(net->d_w + nd.rc_off); a.bias4 = (const int32_t*)(net->d_w + nd.cc_off);
             a.N = N; a.H = sT.H; a.W = sT.W; a.P = oT.H; a.Q = oT.W; a.Cs = sT.Cs; a.stride = nd.cd.stride; a.pad = nd.cd.pad;
-            a.in_signed = nd.cd.input_signed; a.relu0 = st.relu0; a.use_dot4 = net->opt.dw_dot4;
+            a.in_signed = nd.cd.input_signed; a.relu0 = st.relu0; a.use_dot4 = net->opt.dw_dot4; a.use_mma = net->opt.dw_mma;
             fill_out(&a.out32, a.q);
             e = launch_dwconv(a, s);
             break;
