@@ -18,7 +18,7 @@ namespace f8 {
 
 namespace {
 constexpr int DW_SW = 28;                           // output columns per strip (lanes 28 .. 31 only feed the shifts)
-constexpr int DW_BAND = 14;                         // output rows per wave
+constexpr int DW_BAND = 14;                         // output rows per wave (8 where that leaves the chip short of waves)
 
 __device__ __forceinline__ v4i dw_next_lane(const v4i& v) {   // lane i <- lane i + 1, each dword (= 4 channels of one pixel) on its own
     v4i r;
@@ -28,12 +28,15 @@ __device__ __forceinline__ v4i dw_next_lane(const v4i& v) {   // lane i <- lane 
 }
 }
 
-// S: stride.  FQ: every int8 output format is a right shift into unsigned 8-bit behind a ReLU (4-operation requantisation, ReLU = the clamp)
-template <int S, bool FQ>
+// S: stride.  FQ: every int8 output format is a right shift into unsigned 8-bit behind a ReLU (4-operation requantisation, ReLU = the clamp).
+// SUBS: output rows per MFMA pixel tile: 1 = 32 lanes along one row (28 outputs), 2 = two rows of 16 lanes (14 outputs each: 14-wide maps)
+template <int S, bool FQ, int SUBS>
 __global__ void __launch_bounds__(256) dwconv3x3_mma_kernel(const DwArgs a) {
+    constexpr int VW = SUBS == 2 ? 14 : DW_SW;                      // output columns per sub-row
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 3;
-    const int cts = a.Cs >> 5, strips = (a.Q + DW_SW - 1) / DW_SW, bands = (a.P + DW_BAND - 1) / DW_BAND;
+    const int cts = a.Cs >> 5, strips = (a.Q + VW - 1) / VW, bands = (a.P + a.band - 1) / a.band;
+    const int sub = SUBS == 2 ? l31 >> 4 : 0, u = SUBS == 2 ? l31 & 15 : l31;      // sub-row of the tile, lane inside it
     // item = (image, band, strip, channel tile), channel tile fastest: the waves of a workgroup read the same pixels' other channels
     const long long item = (long long)blockIdx.x * 4 + wave;
     if (item >= (long long)a.N * bands * strips * cts) return;
@@ -42,8 +45,8 @@ __global__ void __launch_bounds__(256) dwconv3x3_mma_kernel(const DwArgs a) {
     const int strip = (int)(t % strips); t /= strips;
     const int band = (int)(t % bands);
     const int n = (int)(t / bands);
-    const int q0 = strip * DW_SW, p0 = band * DW_BAND;
-    const int p1 = (p0 + DW_BAND) < a.P ? (p0 + DW_BAND) : a.P;
+    const int q0 = strip * VW, p0 = band * a.band;
+    const int p1 = (p0 + a.band) < a.P ? (p0 + a.band) : a.P;
     const int ch = ct * 32 + 16 * lh;                               // first of this lane's 16 channels (B operand / int8 output row)
 
     // ---- the nine diagonal weight fragments of this channel tile, the bias in accumulator order
@@ -66,8 +69,8 @@ __global__ void __launch_bounds__(256) dwconv3x3_mma_kernel(const DwArgs a) {
     const int padv = a.in_signed ? 0 : (int)0x80808080u;
     // input column of this lane: stride 1: q0 - 1 + l (taps kx = 0, 1, 2 are this fragment shifted by 0, 1, 2 lanes);
     // stride 2: O = 2 (q0 + l) - 1 (kx = 0; kx = 2 is O of the next lane), E = 2 (q0 + l) (kx = 1)
-    const int colA = S == 1 ? q0 - 1 + l31 : 2 * (q0 + l31) - 1;
-    const int colB = 2 * (q0 + l31);
+    const int colA = S == 1 ? q0 - 1 + u : 2 * (q0 + u) - 1;
+    const int colB = 2 * (q0 + u);
     const bool okA = colA >= 0 && colA < a.W, okB = colB < a.W;
     auto row_off = [&](int r, int col, bool ok) -> unsigned {
         return (ok && r >= 0 && r < a.H) ? (unsigned)((((size_t)n * a.H + r) * a.W + col) * a.Cs + ch) : kOOB;
@@ -87,11 +90,12 @@ __global__ void __launch_bounds__(256) dwconv3x3_mma_kernel(const DwArgs a) {
         va = __builtin_amdgcn_raw_buffer_load_b128(rx, oa, 0, 0);
         if constexpr (S == 2) { ob = row_off(r, colB, okB); vb = __builtin_amdgcn_raw_buffer_load_b128(rx, ob, 0, 0); }
     };
-    const int col_out = q0 + l31;
-    const bool lane_out = l31 < DW_SW && col_out < a.Q;
+    const int col_out = q0 + u;
+    const bool col_ok = u < VW && col_out < a.Q;
 
     auto emit = [&](const v16i& acc, int p) {
-        const size_t o = (((size_t)n * a.P + p) * a.Q + col_out) * a.Cs + ch;
+        const bool lane_out = col_ok && p < p1;
+        const size_t o = (((size_t)n * a.P + (p < p1 ? p : p0)) * a.Q + (col_ok ? col_out : 0)) * a.Cs + ch;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             if (!a.q[k].ptr) continue;                              // wave-uniform
@@ -132,37 +136,35 @@ __global__ void __launch_bounds__(256) dwconv3x3_mma_kernel(const DwArgs a) {
         return acc;
     };
 
-    if constexpr (S == 1) {
-        // rows p - 1, p, p + 1 -> output row p; the fragments slide: (R0, R1, R2) <- (R1, R2, new)
-        v4i va, vb, vn; unsigned oa = 0, ob = 0, on = 0;
-        load_row(p0 - 1, va, vb, oa, ob);
-        Row R0 = make_row(fix(va, oa), vb);
-        load_row(p0, va, vb, oa, ob);
-        Row R1 = make_row(fix(va, oa), vb);
-        load_row(p0 + 1, vn, vb, on, ob);
-        for (int p = p0; p < p1; ++p) {
-            const Row R2 = make_row(fix(vn, on), vb);
-            if (p + 1 < p1) load_row(p + 2, vn, vb, on, ob);        // in flight under this row's multiplies
-            v16i acc = acc0();
-            acc = mac3(acc, R0, 0); acc = mac3(acc, R1, 1); acc = mac3(acc, R2, 2);
-            emit(acc, p);
-            R0 = R1; R1 = R2;
+    // Output row p + sub reads input rows S (p + sub) - 1 + k, k = 0 .. 2 (fragment k).  A step advances SUBS output rows: fragment k of
+    // the next step is fragment k + NEW of this one where that exists (the rows slide in registers), NEW fragments are loaded — one
+    // step ahead, under this step's multiplies.
+    constexpr int NEW = S == 1 ? SUBS : (SUBS == 1 ? 2 : 3), KEEP = 3 - NEW;
+    auto in_row = [&](int p, int k) { return S * (p + sub) - 1 + k; };
+    Row R[3];
+    {
+        v4i va[3], vb[3]; unsigned oa[3], ob[3] = {0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) load_row(in_row(p0, k), va[k], vb[k], oa[k], ob[k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) R[k] = make_row(fix(va[k], oa[k]), S == 2 ? fix(vb[k], ob[k]) : vb[k]);
+    }
+    for (int p = p0; p < p1; p += SUBS) {
+        v4i na[NEW], nb[NEW]; unsigned noa[NEW], nob[NEW];
+        const bool more = p + SUBS < p1;
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < NEW; ++j) { nob[j] = 0; load_row(in_row(p + SUBS, KEEP + j), na[j], nb[j], noa[j], nob[j]); }
         }
-    } else {
-        // rows 2p - 1, 2p, 2p + 1 -> output row p; row 2p + 1 is row 2(p+1) - 1 of the next output row
-        v4i va, vb, ua, ub, wa2, wb2; unsigned oa = 0, ob = 0, pa = 0, pb = 0, qa = 0, qb = 0;
-        load_row(2 * p0 - 1, va, vb, oa, ob);
-        Row R0 = make_row(fix(va, oa), fix(vb, ob));
-        load_row(2 * p0, ua, ub, pa, pb);
-        load_row(2 * p0 + 1, wa2, wb2, qa, qb);
-        for (int p = p0; p < p1; ++p) {
-            const Row R1 = make_row(fix(ua, pa), fix(ub, pb));
-            const Row R2 = make_row(fix(wa2, qa), fix(wb2, qb));
-            if (p + 1 < p1) { load_row(2 * p + 2, ua, ub, pa, pb); load_row(2 * p + 3, wa2, wb2, qa, qb); }
-            v16i acc = acc0();
-            acc = mac3(acc, R0, 0); acc = mac3(acc, R1, 1); acc = mac3(acc, R2, 2);
-            emit(acc, p);
-            R0 = R2;
+        v16i acc = acc0();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc = mac3(acc, R[k], k);
+        emit(acc, p + sub);
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k) R[k] = R[k + NEW];
+#pragma unroll
+            for (int j = 0; j < NEW; ++j) R[KEEP + j] = make_row(fix(na[j], noa[j]), S == 2 ? fix(nb[j], nob[j]) : nb[j]);
         }
     }
 }
@@ -170,7 +172,7 @@ __global__ void __launch_bounds__(256) dwconv3x3_mma_kernel(const DwArgs a) {
 // int8 outputs only, pad 1, stride 1 / 2, whole 32-channel tiles, strips that fill their lanes: output width >= 28 (measured: 14-wide maps,
 // 14 of 32 lanes live, are 10 - 15 % SLOWER than the v_dot4 kernel: 17.7 -> 20.0 us; 112 / 56 / 28-wide ones 41 -> 26, 43 -> 27, 27 -> 19 us)
 bool dwconv_mma_supported(const DwArgs& a) {
-    return !a.out32 && a.w && a.bias4 && a.pad == 1 && (a.stride == 1 || a.stride == 2) && (a.Cs & 31) == 0 && a.Q >= DW_SW &&
+    return !a.out32 && a.w && a.bias4 && a.pad == 1 && (a.stride == 1 || a.stride == 2) && (a.Cs & 31) == 0 && (a.Q >= DW_SW || a.Q == 14) &&
            (a.stride == 1 ? (a.P == a.H && a.Q == a.W) : (a.H == 2 * a.P && a.W == 2 * a.Q)) &&
            (size_t)a.N * a.H * a.W * a.Cs < 0x7fffffffull;
 }
@@ -180,10 +182,15 @@ hipError_t launch_dwconv_mma(const DwArgs& a0, hipStream_t s) {
     bool fq = a.relu0 != 0;
     for (int k = 0; k < 2; ++k)
         if (a.q[k].ptr && !(a.q[k].n > 0 && a.q[k].lo == 0 && a.q[k].hi == 255 && a.q[k].bias_xor == 0x80808080u)) fq = false;
-    const long long items = (long long)a.N * ((a.P + DW_BAND - 1) / DW_BAND) * ((a.Q + DW_SW - 1) / DW_SW) * (a.Cs >> 5);
+    const int subs = a.Q >= DW_SW ? 1 : 2, vw = subs == 2 ? 14 : DW_SW;
+    a.band = DW_BAND;
+    long long items = (long long)a.N * ((a.P + a.band - 1) / a.band) * ((a.Q + vw - 1) / vw) * (a.Cs >> 5);
+    if (items < 4096 && a.P > 8) { a.band = 8; items = (long long)a.N * ((a.P + a.band - 1) / a.band) * ((a.Q + vw - 1) / vw) * (a.Cs >> 5); }   // < 4 waves per SIMD
     const unsigned grid = (unsigned)((items + 3) / 4);
-    if (a.stride == 1) { if (fq) hipLaunchKernelGGL((dwconv3x3_mma_kernel<1, true>), dim3(grid), dim3(256), 0, s, a); else hipLaunchKernelGGL((dwconv3x3_mma_kernel<1, false>), dim3(grid), dim3(256), 0, s, a); }
-    else { if (fq) hipLaunchKernelGGL((dwconv3x3_mma_kernel<2, true>), dim3(grid), dim3(256), 0, s, a); else hipLaunchKernelGGL((dwconv3x3_mma_kernel<2, false>), dim3(grid), dim3(256), 0, s, a); }
+#define F8_DWM(S_, FQ_, SB_) hipLaunchKernelGGL((dwconv3x3_mma_kernel<S_, FQ_, SB_>), dim3(grid), dim3(256), 0, s, a)
+    if (a.stride == 1) { if (subs == 1) { if (fq) F8_DWM(1, true, 1); else F8_DWM(1, false, 1); } else { if (fq) F8_DWM(1, true, 2); else F8_DWM(1, false, 2); } }
+    else               { if (subs == 1) { if (fq) F8_DWM(2, true, 1); else F8_DWM(2, false, 1); } else { if (fq) F8_DWM(2, true, 2); else F8_DWM(2, false, 2); } }
+#undef F8_DWM
     return hipGetLastError();
 }
 

@@ -114,6 +114,7 @@ struct DwArgs {
     QuantOut q[2];
     int32_t use_dot4;                      // Options::dw_dot4
     int32_t use_mma;                       // Options::dw_mma
+    int32_t band;                          // f8_dwmma.hip: output rows per wave (set by its launcher)
 };
 
 struct PoolArgs {                          // max-pool, NHWC

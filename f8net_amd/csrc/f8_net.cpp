@@ -722,9 +722,9 @@ static void label_conv_step(f8_net* net, Step& st, const Node& nd) {
         bool fq = d.relu;
         int n8 = 0;
         for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) { const Form& F = od.forms[st.out.f8[k]]; ++n8; if (!(F.n > 0 && !F.sgn)) fq = false; }
-        const bool mma = net->opt.dw_mma && st.out.f32 < 0 && n8 > 0 && d.pad == 1 && (d.stride == 1 || d.stride == 2) && od.W >= 28 &&
+        const bool mma = net->opt.dw_mma && st.out.f32 < 0 && n8 > 0 && d.pad == 1 && (d.stride == 1 || d.stride == 2) && (od.W >= 28 || od.W == 14) &&
                          (d.stride == 1 ? (od.H == s.H && od.W == s.W) : (s.H == 2 * od.H && s.W == 2 * od.W));
-        if (mma) snprintf(buf, sizeof buf, "f8::dwconv3x3_mma_kernel<%d, %s>", d.stride, fq ? "true" : "false");
+        if (mma) snprintf(buf, sizeof buf, "f8::dwconv3x3_mma_kernel<%d, %s, %d>", d.stride, fq ? "true" : "false", od.W >= 28 ? 1 : 2);
         else snprintf(buf, sizeof buf, "f8::dwconv3x3_dot4_kernel<%d, 2>", d.stride);
     }
     else if (nd.p3_R > 0) snprintf(buf, sizeof buf, "f8::conv3x3_patch_kernel<%d, %d, %d, %d, %d, %d, %s>", d.cin, s.W, nd.p3_R, nd.p3_imgs, nd.p3_bn,
