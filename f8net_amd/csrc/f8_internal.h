@@ -28,6 +28,7 @@ struct Options {
     int fuse_chain = 1;          // all consecutive bottleneck blocks of a stage in ONE launch, int32 residual stream in registers (f8_chain.hip)
     int chain_timeout_ms = 2000; // bound of its halo-exchange spins
     int fuse_p12 = 1;            // 7x7 identity blocks: body.0 + body.2 in one launch, split over a workgroup pair per image (f8_p12.hip)
+    int fuse_head2 = 1;          // MobileNet-V2 head (3x3 / 2 conv, depthwise 3x3, 1x1) as one row-walking launch (f8_stem.hip, H2)
     int fuse_ir = 1;             // MobileNet-V2 inverted residual (expand -> depthwise -> project) in one launch: 1 = where it wins, 2 = always
     int patch3x3 = 1;            // LDS-patch 3x3 kernel
     int dual_wide = 2048;        // dual-GEMM joins with at least this many couts use the 128x128 tile
@@ -254,6 +255,10 @@ struct StemPoolArgs {
     int32_t wpc;                           // Options::stem_wpc
     int32_t rows;                          // Options::stem_rows: the row-walking kernel where it has an instance
     int32_t grid_div;                      // Options::stem_grid_div: that kernel runs on 1 / grid_div of the CUs (0 = by output form)
+    // h2 != 0: the MobileNet-V2 head instead (3x3 / 2 conv 3 -> 32 ReLU, depthwise 3x3 ReLU, 1x1 32 -> <= 32): w / bias = the head conv
+    // ([32][3][32 B], single class), wd / bd = depthwise ([9][32] tap-major, bias + 128 sum(w)), w1 / b1 = the 1x1 ([32][32]); na / nb =
+    // right shifts head -> depthwise input / depthwise -> 1x1 input (both unsigned 8-bit behind a ReLU); Pc = P, Qc = Q = its map; q[] only
+    int32_t h2; const int8_t* wd; const int32_t* bd; const int8_t* w1; const int32_t* b1; int32_t na, nb;
     // raw network input read by the stem launch itself (no input launch, no haloed NHWC4 copy): NCHW planes, raw_kind 0 = int32 (xi),
     // 1 = fp32 quantised on the fly (xf, scale, qlo, qhi), 2 = uint8 through `lut`; raw_kind < 0: the haloed form `x`
     int32_t raw_kind, rC, rH, rW;
@@ -319,6 +324,7 @@ hipError_t launch_fused_ir(const IRArgs& a, int cinS, int coutS, hipStream_t s);
 // 3x3 / stride 1 / pad 1 with the input patch resident in LDS (f8_conv3x3.hip); config = false: no instance
 bool conv3x3_patch_config(int cin, int H, int W, int coutP, int* R, int* IMGS, int* BN);
 hipError_t launch_conv3x3_patch(const ConvArgs& a, int cin, hipStream_t s);
+bool head2_supported(int H, int W);
 bool dwconv_mma_supported(const DwArgs& a);
 hipError_t launch_dwconv_mma(const DwArgs& a, hipStream_t s);
 bool stem_pool_supported(int cin, int cout, int k, int stride, int pad, int pool_k, int pool_s, int pool_p, int P, int Q, int rows, int H, int W);

@@ -91,6 +91,7 @@ struct Node {
     int bchain_into = -1;                // ... the host (second conv) of the chain's LAST block
     std::vector<int> bchain;             // host of the last block of a BasicBlock chain: the hosts of all its blocks (f8_bchain.hip)
     int p12_a = -1;                      // 3x3 conv hosting "1x1 -> 3x3 in one launch" (f8_p12.hip): its 1x1 producer
+    int h2_head = -1, h2_dw = -1;        // 1x1 conv that ends the MobileNet-V2 head launch (f8_stem.hip, H2): its 3x3 / 2 head conv and its depthwise conv
     int ir_a = -1, ir_b = -1, ir_R = 0, ir_G = 0;   // project conv of a fused inverted-residual block: its expand / depthwise convs, tile
     int dual = -1;                     // 1x1 conv hosting a join whose other operand is ANOTHER 1x1 conv (node id): one dual-GEMM launch
     int dual_host = -1;                // ... and that other conv: the node that carries it
@@ -101,7 +102,7 @@ struct Node {
     size_t rc_off = 0, cc_off = 0; int ncc = 0;      // border-class tables (0 = single class)
     ConvTile tile{};
 };
-enum StepKind { S_INPUT, S_CONV, S_DW, S_ADD, S_MAXPOOL, S_AVGPOOL, S_REQUANT, S_OUTPUT, S_FUSED, S_STEMPOOL, S_IR, S_P12, S_CHAIN, S_BCHAIN };
+enum StepKind { S_INPUT, S_CONV, S_DW, S_ADD, S_MAXPOOL, S_AVGPOOL, S_REQUANT, S_OUTPUT, S_FUSED, S_STEMPOOL, S_IR, S_P12, S_CHAIN, S_BCHAIN, S_HEAD2 };
 struct OutSel { int t = -1; int f32 = -1; int f8[2] = {-1, -1}; };
 struct Step {
     int kind; int node;
@@ -223,6 +224,7 @@ static const OptKey kOptKeys[] = {
     {"fuse_stem", "F8_FUSE_STEM", &Options::fuse_stem, 0, 1, true},
     {"fuse_input", "F8_FUSE_INPUT", &Options::fuse_input, 0, 1, true},
     {"fuse_ir", "F8_FUSE_IR", &Options::fuse_ir, 0, 2, true},
+    {"fuse_head2", "F8_FUSE_HEAD2", &Options::fuse_head2, 0, 1, true},
     {"fuse_p12", "F8_FUSE_P12", &Options::fuse_p12, 0, 1, true},
     {"fuse_chain", "F8_FUSE_CHAIN", &Options::fuse_chain, 0, 1, true},
     {"fuse_bchain", "F8_FUSE_BCHAIN", &Options::fuse_bchain, 0, 2, true},
@@ -1043,6 +1045,36 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         c.ir_a = ta.prod; c.ir_b = tb.prod; c.ir_R = R; c.ir_G = G;
     }
 
+    // ---- 1h. MobileNet-V2 head: network input -> 3x3 / 2 conv (cin <= 4 -> 32, ReLU) -> depthwise 3x3 (ReLU) -> 1x1 (32 -> <= 32), each read
+    //          by nobody else  ->  ONE row-walking launch (f8_stem.hip, stem_rows_kernel<KIND, true>): the three convs hand their rows to
+    //          each other in registers, the launch reads the caller's buffer itself
+    for (int i = 0; opt.fuse_head2 && opt.fuse_stem && i < nn; ++i) {
+        Node& c = ND[i];
+        if (c.kind != N_CONV || c.cd.groups != 1 || c.cd.kernel != 1 || c.cd.stride != 1 || c.cd.pad != 0 || c.cd.relu || !c.cd.quant_input ||
+            c.cd.input_signed || c.fused_add >= 0 || c.absorbed_by >= 0 || c.ir_a >= 0 || c.dual >= 0 || c.dual_host >= 0 || c.out == net->out_t) continue;
+        if (c.cd.cin != 32 || round_up(c.cd.cout, 32) != 32) continue;
+        const Tensor& tb = T[c.a];
+        if (tb.consumers.size() != 1 || c.a == net->out_t) continue;
+        Node& b = ND[tb.prod];
+        if (b.kind != N_CONV || b.cd.groups != b.cd.cin || b.cd.cin != 32 || b.cd.cout != 32 || b.cd.kernel != 3 || b.cd.stride != 1 || b.cd.pad != 1 ||
+            !b.cd.relu || !b.cd.quant_input || b.cd.input_signed || b.fused_add >= 0 || b.absorbed_by >= 0) continue;
+        const Tensor& ta = T[b.a];
+        if (ta.consumers.size() != 1 || b.a == net->out_t) continue;
+        Node& h = ND[ta.prod];
+        if (h.kind != N_CONV || h.cd.groups != 1 || h.cd.kernel != 3 || h.cd.stride != 2 || h.cd.pad != 1 || h.cd.cin > 4 || h.cd.cout != 32 || !h.cd.relu ||
+            h.fused_add >= 0 || h.absorbed_by >= 0 || h.a == net->out_t) continue;
+        const Tensor& x = T[h.a];
+        if (x.prod < 0 || ND[x.prod].kind != N_INPUT || x.consumers.size() != 1 || !(!h.cd.quant_input || x.fl == h.cd.input_fl)) continue;
+        if (!head2_supported(x.H, x.W) || ta.H * 2 != x.H || ta.W * 2 != x.W) continue;
+        int na = 0, nb2 = 0;
+        if (consumer_format(ta, b.cd, &na, "finalize") || consumer_format(tb, c.cd, &nb2, "finalize") || na < 1 || nb2 < 1) continue;
+        bool int8_readers = !T[c.out].consumers.empty() && T[c.out].consumers.size() <= 2;
+        for (int u : T[c.out].consumers) if (ND[u].kind != N_CONV || !ND[u].cd.quant_input) int8_readers = false;
+        if (!int8_readers) continue;
+        h.absorbed_by = i; b.absorbed_by = i;
+        c.h2_head = ta.prod; c.h2_dw = tb.prod;
+    }
+
     // ---- 2. which forms does each tensor need?  (reverse order: consumers before producers)
     {
         Tensor& O = T[net->out_t];
@@ -1064,6 +1096,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 nd.depthwise = nd.cd.groups != 1;
                 if ((nd.absorbed_by >= 0 && ND[nd.absorbed_by].fbd_b == i) || (nd.dual_host >= 0 && ND[nd.dual_host].fbd_a >= 0)) break;   // DS: in LDS
                 if (nd.p12_a >= 0) break;                    // the 1x1's output lives in LDS inside the launch
+                if (nd.h2_head >= 0 || (nd.absorbed_by >= 0 && ND[nd.absorbed_by].h2_dw == i)) break;   // 1x1 / depthwise of the MobileNet-V2 head launch: rows in registers
                 if (nd.absorbed_by >= 0 && ND[nd.absorbed_by].bds_b == i) break;   // second 3x3 of the opening block of a bchain launch: `mid` lives in LDS
                                                                  // (its 3x3 / 2 and its shortcut conv each ask for their int8 form of the block input below)
                 if (nd.bb_a >= 0) {                          // second conv of a chained BasicBlock: its source (`mid`) lives in LDS
@@ -1100,9 +1133,10 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     const int f = add_form(s, FORM_STEM, 0, 0);
                     Form& F = s.forms[f];
                     F.sgn = nd.cd.input_signed ? 1 : 0;
-                    F.pad = nd.cd.pad + (nd.sp_pool >= 0 ? 2 : 0);      // fused stem + pool: 2 more halo pixels keep every tile's patch in memory
+                    const bool h2 = nd.absorbed_by >= 0 && ND[nd.absorbed_by].h2_head == i;
+                    F.pad = nd.cd.pad + (nd.sp_pool >= 0 ? 2 : 0) + (h2 ? 4 : 0);      // fused stem + pool: 2 more halo pixels keep every tile's patch in memory (head launch of MobileNet-V2: 5 in all)
                     F.Hp = s.H + 2 * F.pad;
-                    F.Wp = round_up(std::max(s.W + 2 * F.pad, nd.cd.stride * (Q - 1) + 8), nd.sp_pool >= 0 ? 4 : 2);
+                    F.Wp = round_up(std::max(s.W + 2 * F.pad, nd.cd.stride * (Q - 1) + 8), (nd.sp_pool >= 0 || h2) ? 4 : 2);
                 } else {
                     add_form(s, FORM_I8, n, nd.cd.input_signed ? 1 : 0);
                 }
@@ -1188,6 +1222,25 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 break;
             }
             case N_CONV: case N_LINEAR: {
+                if (nd.h2_head >= 0) {
+                    // ---- MobileNet-V2 head: 3x3 / 2 conv + depthwise 3x3 + this 1x1 in one launch
+                    Node& hh = ND[nd.h2_head]; Node& hb = ND[nd.h2_dw];
+                    Tensor& s = T[hh.a];
+                    st.kind = S_HEAD2;
+                    st.src_t = hh.a; st.src_f = find_form(s, FORM_STEM, 0, 0);
+                    pack_conv_weights(net, hh, s, T[hh.out]);
+                    pack_dw_weights(net, hb, T[hb.a]);
+                    pack_conv_weights(net, nd, T[nd.a], T[nd.out]);
+                    select_outputs(net, out_t, &st.out, &extra);
+                    Tensor& o = T[out_t];
+                    const double cpx = (double)o.H * o.W;
+                    st.ops_per_img = 2.0 * cpx * (32.0 * hh.cd.cin * 9 + 32.0 * 9 + 32.0 * nd.cd.cout);
+                    st.bytes_per_img = (double)s.H * s.W * 4 + cpx * o.Cs * ((st.out.f8[0] >= 0) + (st.out.f8[1] >= 0));
+                    st.bytes_const = 32.0 * 100 + 32.0 * 13 + 32.0 * 36;
+                    st.name = "head3x3s2+dw3x3+1x1:" + tname(net, hh.out) + "+" + tname(net, hb.out) + "+" + tname(net, nd.out);
+                    st.kernel = "f8::stem_rows_kernel";
+                    break;
+                }
                 if (nd.sp_pool >= 0 && nd.stem) {
                     // ---- ResNet head: stem conv + max-pool in one launch
                     const Node& pl = ND[nd.sp_pool];
@@ -1597,7 +1650,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
             // the fused stem launch can read the raw input itself: the input step then launches nothing (run_step)
             if (only_stem && o.C == 3 && net->opt.fuse_input) {
                 Step* stem = nullptr; int users = 0;
-                for (auto& s2 : net->steps) if (s2.src_t == st.out.t) { ++users; if (s2.kind == S_STEMPOOL) stem = &s2; }
+                for (auto& s2 : net->steps) if (s2.src_t == st.out.t) { ++users; if (s2.kind == S_STEMPOOL || s2.kind == S_HEAD2) stem = &s2; }
                 if (stem && users == 1) {
                     st.raw_input = stem->raw_input = true;
                     stem->bytes_per_img += (double)o.C * o.H * o.W * 4 - (double)o.H * o.W * 4;      // int32 planes instead of the NHWC4 copy
@@ -1883,6 +1936,36 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
                 e = launch_conv1x1_wstat(a, net->num_cu, s);
             } else if (nd.wreg) { a.w = (const int8_t*)(net->d_w + nd.wf_off); e = launch_conv1x1_wreg(a, s); }
             else e = nd.p3_R > 0 ? launch_conv3x3_patch(a, d.cin, s) : launch_conv(a, nd.tile, s);
+            break;
+        }
+        case S_HEAD2: {
+            const Node& hh = net->nodes[nd.h2_head]; const Node& hb = net->nodes[nd.h2_dw];
+            const Tensor& sT = T[st.src_t]; const Form& sF = sT.forms[st.src_f];
+            const Tensor& oT = T[nd.out];
+            StemPoolArgs a{};
+            a.h2 = 1;
+            a.x = (const int8_t*)fp(sF); a.x_bytes = (uint32_t)(sF.bytes_per_img * N);
+            a.w = (const int8_t*)(net->d_w + hh.w_off); a.w_bytes = (uint32_t)((size_t)hh.coutP * hh.ktot);
+            a.bias = (const int32_t*)(net->d_w + hh.b_off);
+            a.wd = (const int8_t*)(net->d_w + hb.w_off); a.bd = (const int32_t*)(net->d_w + hb.cc_off);
+            a.w1 = (const int8_t*)(net->d_w + nd.w_off); a.b1 = (const int32_t*)(net->d_w + nd.b_off);
+            { int v = 0; consumer_format(T[hb.a], hb.cd, &v, "run"); a.na = v; consumer_format(T[nd.a], nd.cd, &v, "run"); a.nb = v; }
+            a.N = N; a.Hp = sF.Hp; a.Wp = sF.Wp; a.org = sF.pad - hh.cd.pad;
+            a.Pc = oT.H; a.Qc = oT.W; a.P = oT.H; a.Q = oT.W;
+            a.relu0 = 1; a.grid_div = net->opt.stem_grid_div;
+            a.rC = sT.C; a.rH = sT.H; a.rW = sT.W; a.xor8 = sF.sgn ? 0u : 0x80808080u;
+            a.raw_kind = -1;
+            if (st.raw_input && !(net->in_u8 && net->in_u8_nhwc)) {
+                const size_t img = (size_t)sT.C * sT.H * sT.W;
+                if (net->in_u8) { a.raw_kind = 2; a.xu8 = net->in_u8 + (size_t)n0 * img; memcpy(a.lut, net->in_lut, sizeof a.lut); }
+                else if (net->in_f32) { a.raw_kind = 1; a.xf = net->in_f32 + (size_t)n0 * img; a.scale = net->in_scale; a.qlo = net->in_lo; a.qhi = net->in_hi; }
+                else {
+                    a.raw_kind = 0; a.xi = input + (size_t)n0 * img;
+                    if (net->opt.check_input_range) { a.err = net->d_err; a.chk_lo = sF.sgn ? -127 : 0; a.chk_hi = sF.sgn ? 127 : 255; }
+                }
+            }
+            fill_out(&a.out32, a.q);
+            e = launch_stem_pool(a, s);
             break;
         }
         case S_STEMPOOL: {

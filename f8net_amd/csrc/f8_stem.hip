@@ -271,6 +271,7 @@ namespace {
 constexpr int RB = 7;                               // pooled rows per band
 constexpr int SW = 28;                              // pooled columns per strip (lane 28 of a strip only provides O for lane 27)
 constexpr int RB_ROWS = 4 * RB + 7;                 // input rows of a band
+constexpr int H2_RB = 14;                           // MobileNet-V2 head: output rows per band (2 * 14 + 5 = 33 input rows)
 
 __device__ __forceinline__ int dpp_next_lane(int v) {   // lane i <- lane i + 1 (across the 16-lane DPP rows; lane 63 keeps its value)
     return __builtin_amdgcn_update_dpp(v, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
@@ -295,15 +296,19 @@ __device__ __forceinline__ v4i stem_quant16(const Y& y, int n, int lo, int hi, u
 }
 }
 
-template <int KIND>
+// H2: the same skeleton (loader waves, double-buffered patch, persistent bands) with a different body for the compute waves: the
+// MobileNet-V2 head — 3x3 / 2 conv (3 -> 32, ReLU) -> depthwise 3x3 (ReLU) -> 1x1 (32 -> <= 32) — see the block in front of that body.
+template <int KIND, bool H2 = false>
 __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) stem_rows_kernel(const StemPoolArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];      // 2 x [RB_ROWS][PWB pixels][4 B] (patch column pc = input column pc - 5) | 64 biases
     const int tid = threadIdx.x;
     const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0 .. 7 compute, 8 .. 11 loaders
-    const int PWB = 4 * a.Q + 8, ROWB = PWB * 4, SPR = PWB / 4;     // patch row: pixels, bytes, 16-byte slots
+    const int QW = H2 ? a.rW >> 2 : a.Q;                            // input width / 4
+    const int PWB = 4 * QW + 8, ROWB = PWB * 4, SPR = PWB / 4;      // patch row: pixels, bytes, 16-byte slots
     const int PBUF = RB_ROWS * ROWB;
-    const int bands = (a.P + RB - 1) / RB, ntiles = a.N * bands;
+    constexpr int RBK = H2 ? H2_RB : RB;                            // output rows per band
+    const int bands = (a.P + RBK - 1) / RBK, ntiles = a.N * bands;
     // XCD-aware order: dispatch slot d (d % 8 = the XCD of a persistent workgroup's every slot) -> band tile; the bands of one image,
     // which share input rows, run on one XCD
     auto tile_of = [&](int d) {
@@ -314,14 +319,15 @@ __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))
     // inside the image, 16-byte aligned in memory, so every load is one unconditional b128 / b32 — no branch, hence no wait, between
     // the loads of a band) and land 5 pixels to the right in the patch (four dword stores); the patch columns left and right of the
     // image are written once, below.  Haloed form: slots are patch-aligned (a plain copy).
-    const int SPI = KIND < 0 ? SPR : a.Q;                           // slots per input row (raw: rW / 4 = Q)
+    const int SPI = KIND < 0 ? SPR : QW;                            // slots per input row (raw: rW / 4)
     struct Band { int n, p0, rp, r0, nslot; };
     auto band_of = [&](int d) {
         const int t = tile_of(d);
         Band B;
-        B.n = t / bands; B.p0 = (t - B.n * bands) * RB;
-        B.rp = (a.P - B.p0) < RB ? (a.P - B.p0) : RB;               // pooled rows of this band
-        B.r0 = 4 * B.p0 - 5; B.nslot = (4 * B.rp + 7) * SPI;        // input rows r0 .. r0 + 4 rp + 6
+        B.n = t / bands; B.p0 = (t - B.n * bands) * RBK;
+        B.rp = (a.P - B.p0) < RBK ? (a.P - B.p0) : RBK;             // output rows of this band
+        if constexpr (H2) { B.r0 = 2 * B.p0 - 3; B.nslot = (2 * B.rp + 5) * SPI; }     // conv rows p0 - 1 .. p0 + rp: input rows 2 p0 - 3 .. 2 (p0 + rp) + 1
+        else { B.r0 = 4 * B.p0 - 5; B.nslot = (4 * B.rp + 7) * SPI; }                  // input rows r0 .. r0 + 4 rp + 6
         return B;
     };
     constexpr int NR = KIND < 0 ? 4 : (KIND == 2 ? 3 : 12);
@@ -373,7 +379,7 @@ __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))
                     int x;
                     if constexpr (KIND == 0) { x = raw[c * 4 + q]; bad |= (ok && c < a.rC && (unsigned)(x - a.chk_lo) > (unsigned)(a.chk_hi - a.chk_lo)) ? 1u : 0u; }
                     else if constexpr (KIND == 1) x = quant_in_stem(__builtin_bit_cast(float, raw[c * 4 + q]), a.scale, a.qlo, a.qhi);
-                    else x = (int)((const short*)(lds + 2 * PBUF + 256))[c * 256 + ((raw[c] >> (8 * q)) & 0xff)];
+                    else x = (int)((const short*)(lds + 2 * PBUF + 512))[c * 256 + ((raw[c] >> (8 * q)) & 0xff)];
                     v[c][q] = (ok && c < a.rC) ? x : 0;         // rows outside the image: (biased) zero
                 }
             if (sl < B.nslot) {
@@ -394,14 +400,14 @@ __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))
         }
     };
     if constexpr (KIND == 2) {   // the u8 -> head-format table: LDS (a dynamically indexed kernel argument would live in scratch)
-        for (int i = tid; i < 3 * 256; i += 768) ((short*)(lds + 2 * PBUF + 256))[i] = a.lut[i];
+        for (int i = tid; i < 3 * 256; i += 768) ((short*)(lds + 2 * PBUF + 512))[i] = a.lut[i];
         __syncthreads();
     }
     if constexpr (KIND >= 0) {   // patch columns outside the image (5 on the left, 3 + padding on the right) of both buffers: biased zero, once
-        const int nside = PWB - 4 * a.Q;                            // 8
+        const int nside = PWB - 4 * QW;                             // 8
         for (int i = tid; i < 2 * RB_ROWS * nside; i += 768) {
             const int r = i / nside, c = i - r * nside;
-            *(unsigned*)(lds + r * ROWB + (c < 5 ? c : 4 * a.Q + c) * 4) = a.xor8;
+            *(unsigned*)(lds + r * ROWB + (c < 5 ? c : 4 * QW + c) * 4) = a.xor8;
         }
     }
 
@@ -409,7 +415,8 @@ __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))
     int d = blockIdx.x;
     if (d >= ntiles) return;
     load_band(band_of(d), lds, tid, 768);                           // the first band: every wave loads
-    if (tid < 64) *(int*)(lds + 2 * PBUF + tid * 4) = a.bias[tid];
+    if constexpr (H2) { if (tid < 96) *(int*)(lds + 2 * PBUF + tid * 4) = tid < 32 ? a.bias[tid] : tid < 64 ? a.bd[tid - 32] : a.b1[tid - 64]; }
+    else if (tid < 64) *(int*)(lds + 2 * PBUF + tid * 4) = a.bias[tid];
     __syncthreads();
 
     if (wave >= 8) {
@@ -423,6 +430,116 @@ __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))
     }
     if constexpr (KIND == 0) { if (a.err && bad) atomicOr(a.err, 1u); }   // (the first band's share of the check)
 
+    if constexpr (H2) {
+        // ======================================================= compute waves, MobileNet-V2 head: (strip of 28 columns, half-band of 7 rows)
+        // The three convs run on ONE register file per wave, row by row, with nothing but the input patch in LDS:
+        //   * head conv 3x3 / 2 (`ref:models/fix_mobilenet_v2.py` head: 3 -> 32, ReLU): lane l <-> conv column c0 - 1 + l; a kernel row is
+        //     16 bytes (4 pixels x 4 channels, the 4th pixel's weights are zero), two kernel rows make one 32-byte K step: TWO MFMAs
+        //     per conv row; requantised (5 operations) and turned by the permlane swap into 16 channels per lane half — which IS the
+        //     B operand of a K = 32-channel MFMA step;
+        //   * depthwise 3x3 (ReLU): nine MFMAs with diagonal weight fragments (f8_dwmma.hip); horizontal taps = the conv row fragment and
+        //     two DPP lane shifts of it, vertical taps = the last three conv rows, sliding; its padding (conv column -1 / 112, conv row
+        //     -1 / 112) is the biased zero, written over the lanes / rows that fall outside;
+        //   * 1x1 (32 -> <= 32, no ReLU): its B operand is the depthwise row after the same requant + swap: ONE MFMA.
+        const int strip = wave & 3, sb = wave >> 2;
+        const int cq = strip * SW - 1 + l31;                         // conv column of this lane = depthwise input column
+        const bool cq_in = cq >= 0 && cq < a.Qc;
+        const int cqa = cq < 0 ? 0 : (cq > a.Qc ? a.Qc : cq);       // for addresses only
+        const unsigned offc = (unsigned)(8 * cqa + 16);             // input column 2 cq - 1 = patch column 2 cq + 4
+        const int col = strip * SW + l31;                            // output column (lanes 0 .. 27)
+        const bool lane_out = l31 < SW && col < a.Q;
+        const v4i wh0 = *(const v4i*)(a.w + l31 * 96 + lh * 32);                                   // kernel rows 0 | 1
+        const v4i wh1 = lh == 0 ? *(const v4i*)(a.w + l31 * 96 + 64) : v4i{0, 0, 0, 0};            // kernel row 2 | nothing
+        v4i wd[9];                                                   // depthwise: diagonal fragments
+        {
+            const bool mine = (l31 >> 4) == lh;
+            const int dsel = (l31 & 15) >> 2, bsh = 8 * (l31 & 3);
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const unsigned wv = (unsigned)(unsigned char)a.wd[tp * 32 + l31];
+                const int piece = mine ? (int)(wv << bsh) : 0;
+                wd[tp] = v4i{dsel == 0 ? piece : 0, dsel == 1 ? piece : 0, dsel == 2 ? piece : 0, dsel == 3 ? piece : 0};
+            }
+        }
+        const v4i w1f = *(const v4i*)(a.w1 + l31 * 32 + lh * 16);
+        const char* const bl = lds + 2 * PBUF + 16 * lh;            // head | depthwise | 1x1 biases, 32 ints each
+        const unsigned halfa = 1u << (a.na - 1), halfb = 1u << (a.nb - 1);
+        const v4i zq = {(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u};
+        auto bias_acc = [&](int which) {
+            v16i acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const v4i b = *(const v4i*)(bl + which * 128 + 8 * g * 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[4 * g + q] = b[q];
+            }
+            return acc;
+        };
+        auto quant_row = [&](const v16i& acc, int n, unsigned hf) {  // ReLU + right shift into unsigned 8-bit, 16 channels per lane half
+            unsigned dd[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                dd[g] = pack4(requant_shr(acc[4 * g], n, hf, 0u, 0, 255), requant_shr(acc[4 * g + 1], n, hf, 0u, 0, 255),
+                              requant_shr(acc[4 * g + 2], n, hf, 0u, 0, 255), requant_shr(acc[4 * g + 3], n, hf, 0u, 0, 255)) ^ 0x80808080u;
+            auto s0 = __builtin_amdgcn_permlane32_swap(dd[0], dd[2], false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(dd[1], dd[3], false, false);
+            return v4i{(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
+        };
+        struct Row3 { v4i f[3]; };
+        for (int it = 0; d < ntiles; d += G, ++it) {
+            const Band B = band_of(d);
+            const char* const patch = lds + (it & 1) * PBUF;
+            const int p0 = B.p0;
+            auto conv_row = [&](int cp) {                            // conv row cp -> the three horizontal tap fragments of the depthwise conv
+                Row3 R;
+                v4i x = zq;
+                if (cp >= 0 && cp < a.Pc) {                          // wave-uniform
+                    const char* const r0p = patch + (2 * cp - 1 - B.r0) * ROWB + offc;
+                    const char* const rA = r0p + lh * ROWB, * const rB = r0p + 2 * ROWB;
+                    const v2i a0 = *(const v2i*)rA, a1 = *(const v2i*)(rA + 8), b0 = *(const v2i*)rB, b1 = *(const v2i*)(rB + 8);
+                    v16i acc = bias_acc(0);
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wh0, v4i{a0.x, a0.y, a1.x, a1.y}, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wh1, v4i{b0.x, b0.y, b1.x, b1.y}, acc, 0, 0, 0);
+                    x = quant_row(acc, a.na, halfa);
+                    if (!cq_in) x = zq;
+                }
+                R.f[0] = x;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) R.f[1][k] = dpp_next_lane(x[k]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) R.f[2][k] = dpp_next_lane(R.f[1][k]);
+                return R;
+            };
+            const int rps = (B.rp + 1) / 2;
+            const int pb = sb * rps, pe = (pb + rps) < B.rp ? (pb + rps) : B.rp;
+            if (pb < pe) {
+                Row3 R0 = conv_row(p0 + pb - 1), R1 = conv_row(p0 + pb);
+                for (int p = pb; p < pe; ++p) {
+                    const int P = p0 + p;
+                    const Row3 R2 = conv_row(P + 1);
+                    v16i acc = bias_acc(1);
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wd[kx], R0.f[kx], acc, 0, 0, 0);
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wd[3 + kx], R1.f[kx], acc, 0, 0, 0);
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wd[6 + kx], R2.f[kx], acc, 0, 0, 0);
+                    const v4i xb = quant_row(acc, a.nb, halfb);
+                    v16i acc1 = bias_acc(2);
+                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1f, xb, acc1, 0, 0, 0);
+                    const size_t m = ((size_t)B.n * a.P + P) * a.Q + (lane_out ? col : 0);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+                        if (a.q[k].ptr) {
+                            const v4i v = stem_quant16(acc1, a.q[k].n, a.q[k].lo, a.q[k].hi, a.q[k].bias_xor);
+                            if (lane_out) *(v4i*)(a.q[k].ptr + m * 32 + lh * 16) = v;
+                        }
+                    R0 = R1; R1 = R2;
+                }
+            }
+            __syncthreads();                                        // patch `it` is consumed, patch `it + 1` is complete
+        }
+    } else {
     // ======================================================= compute waves: (cout half, strip, sub-band)
     const int half = wave & 1;
     // weights -> registers: A fragment (kernel row r): lane (cout of this wave's half, half of the row's 8 taps)
@@ -506,6 +623,8 @@ __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))
         }
         __syncthreads();                                            // patch `it` is consumed, patch `it + 1` is complete
     }
+
+    }
 }
 
 // instances of the row-walking kernel: pooled width <= 56 (two strips), any height; a haloed form must carry 5 halo pixels
@@ -521,9 +640,30 @@ bool stem_pool_supported(int cin, int cout, int k, int stride, int pad, int pool
     return (P % TP == 0 && Q % TQ == 0) || (rows && Q >= 2 && Q <= 2 * SW && H == 4 * P && W == 4 * Q);
 }
 
+// MobileNet-V2 head (stem_rows_kernel<KIND, true>): input sides multiples of 4, at most 4 strips of 28 output columns
+bool head2_supported(int H, int W) { return H >= 8 && W >= 8 && H % 4 == 0 && W % 4 == 0 && W / 2 <= 4 * SW; }
+
 hipError_t launch_stem_pool(const StemPoolArgs& a, hipStream_t s) {
+    if (a.h2) {
+        if (!head2_supported(a.rH, a.rW) || a.P != a.rH / 2 || a.Q != a.rW / 2 || a.Pc != a.P || a.Qc != a.Q || a.na < 1 || a.nb < 1 || a.out32 ||
+            (a.raw_kind < 0 && !(a.org == 4 && a.Wp % 4 == 0))) return hipErrorInvalidValue;
+        const int lds_bytes = 2 * RB_ROWS * (a.rW + 8) * 4 + 512 + 1536;
+        static int ncu3 = 0;
+        if (!ncu3) { int dev = 0; hipDeviceProp_t p; ncu3 = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+        const int ntiles = a.N * ((a.P + H2_RB - 1) / H2_RB);
+        const int gdiv = a.grid_div > 0 ? a.grid_div : 1;
+        const int gmax = (ncu3 / gdiv + 7) / 8 * 8;
+        const int grid = ntiles < gmax ? ntiles : gmax;
+        switch (a.raw_kind) {
+            case 0: hipLaunchKernelGGL((stem_rows_kernel<0, true>), dim3(grid), dim3(768), lds_bytes, s, a); break;
+            case 1: hipLaunchKernelGGL((stem_rows_kernel<1, true>), dim3(grid), dim3(768), lds_bytes, s, a); break;
+            case 2: hipLaunchKernelGGL((stem_rows_kernel<2, true>), dim3(grid), dim3(768), lds_bytes, s, a); break;
+            default: hipLaunchKernelGGL((stem_rows_kernel<-1, true>), dim3(grid), dim3(768), lds_bytes, s, a); break;
+        }
+        return hipGetLastError();
+    }
     if (a.rows && stem_rows_ok(a)) {
-        const int lds_bytes = 2 * RB_ROWS * (4 * a.Q + 8) * 4 + 256 + 1536;   // 67 KB at 224 x 224: patches, biases, the u8 table
+        const int lds_bytes = 2 * RB_ROWS * (4 * a.Q + 8) * 4 + 512 + 1536;   // 67 KB at 224 x 224: patches, biases, the u8 table
         static int ncu2 = 0;
         if (!ncu2) { int dev = 0; hipDeviceProp_t p; ncu2 = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
         const int ntiles = a.N * ((a.P + RB - 1) / RB);
