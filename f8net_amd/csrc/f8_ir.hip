@@ -27,12 +27,15 @@ namespace f8 {
 // FQ: both inner requantisations are right shifts into UNSIGNED 8-bit behind a ReLU (every block of MobileNet-V2): the ReLU is the clamp's
 // lower bound (requant is monotone and maps 0 to 0), the bias rides in the accumulators' start value, the shift is requant_shr: 5 vector
 // operations per expanded value instead of 9 — and the expanded values are what this kernel is bound by (VALU, not memory)
-template <int CIN_S, int COUT_S, bool FQ, bool P2MMA = (COUT_S <= 96)>
-__global__ void __launch_bounds__(256) fused_ir_kernel(const IRArgs a) {
+// NW: waves per workgroup.  8 for the <32, 32> instance (stages 1 - 2 of MobileNet-V2: 122 registers, so two workgroups = 16 waves fit a CU):
+// the launch is bound by vector work between barriers, and at 4 waves x 2 workgroups a SIMD had two waves to hide them with.
+template <int CIN_S, int COUT_S, bool FQ, bool P2MMA = (COUT_S <= 96), int NW = (CIN_S == 32 && COUT_S == 32 ? 8 : 4)>
+__global__ void __launch_bounds__(NW * 64, (COUT_S <= 64 ? 4 : COUT_S <= 96 ? 3 : COUT_S <= 160 ? 2 : 1)) fused_ir_kernel(const IRArgs a) {
+    constexpr int NT = NW * 64;
     constexpr int KK1 = CIN_S / 32, NCO = COUT_S / 32;
     constexpr int W0_BYTES = 64 * CIN_S, W4_BYTES = COUT_S * 64;
     constexpr int W0_SLOTS = W0_BYTES / 16, W4_SLOTS = W4_BYTES / 16, SM_SLOTS = 36 + 16 + 16;   // dw weights (576 B), dw bias, expand bias
-    constexpr int W0_L = (W0_SLOTS + 255) / 256, W4_L = (W4_SLOTS + 255) / 256;
+    constexpr int W0_L = (W0_SLOTS + NT - 1) / NT, W4_L = (W4_SLOTS + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const X = lds;                                   // [KK1][xp][32 B]
     char* const patch = lds + a.off_patch;                 // [G][PR][PW][64 B]
@@ -41,7 +44,7 @@ __global__ void __launch_bounds__(256) fused_ir_kernel(const IRArgs a) {
     constexpr int OFF_W4 = W0_BYTES, OFF_DW = OFF_W4 + W4_BYTES, OFF_DWB = OFF_DW + 640, OFF_B0 = OFF_DWB + 256, WBUF = OFF_B0 + 256;
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 3;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & (NW - 1);
     const int l31 = lane & 31, lh = lane >> 5;
     const int s = a.stride, R = a.R, W = a.W, H = a.H, Wo = a.Wo, PW = W + 2;
     const int PR = (R - 1) * s + 3;
@@ -76,7 +79,7 @@ __global__ void __launch_bounds__(256) fused_ir_kernel(const IRArgs a) {
     // ---- block input tile -> X (k-blocked: [kk][px][32 B], so a fragment read is 1 KB contiguous per wave)
     {
         const int nslot = a.xp * KK1 * 2;
-        for (int sl = tid; sl < nslot; sl += 256) {
+        for (int sl = tid; sl < nslot; sl += NT) {
             const int kk = KK1 == 1 ? 0 : sl / (a.xp * 2), rem = sl - kk * (a.xp * 2), px = rem >> 1, half = rem & 1;
             v4i v = {0, 0, 0, 0};
             if (px < P1_PX) {
@@ -92,7 +95,7 @@ __global__ void __launch_bounds__(256) fused_ir_kernel(const IRArgs a) {
     {
         const v4i zv = {(int)a.xor1, (int)a.xor1, (int)a.xor1, (int)a.xor1};
         const int pb = a.G * PR * PW * 64;
-        for (int o = tid * 16; o < pb; o += 256 * 16) *(v4i*)(patch + o) = zv;
+        for (int o = tid * 16; o < pb; o += NT * 16) *(v4i*)(patch + o) = zv;
     }
 
     // ---- weight slices of one chunk: global -> registers (early) -> LDS (late)
@@ -101,7 +104,7 @@ __global__ void __launch_bounds__(256) fused_ir_kernel(const IRArgs a) {
         const int rows_ok = a.E32 - 64 * e;                // expanded channels left from this chunk on (>= 32)
 #pragma unroll
         for (int i = 0; i < W0_L; ++i) {                   // W0 rows 64e .. 64e+63 -> [kk][row][32 B]
-            const int sl = tid + i * 256;
+            const int sl = tid + i * NT;
             const int kk = sl / 128, row = (sl >> 1) & 63, half = sl & 1;
             v4i v = {0, 0, 0, 0};
             if (sl < W0_SLOTS && row < rows_ok) v = *(const v4i*)(a.w0 + (size_t)(64 * e + row) * CIN_S + kk * 32 + half * 16);
@@ -109,7 +112,7 @@ __global__ void __launch_bounds__(256) fused_ir_kernel(const IRArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < W4_L; ++i) {                   // W4 columns 64e .. 64e+63 of every row -> [kk][row][32 B]
-            const int sl = tid + i * 256;
+            const int sl = tid + i * NT;
             const int kk = sl / (COUT_S * 2), row = (sl >> 1) % COUT_S, half = sl & 1;
             v4i v = {0, 0, 0, 0};
             if (sl < W4_SLOTS && kk * 32 < rows_ok) v = *(const v4i*)(a.w4 + (size_t)row * a.E32 + 64 * e + kk * 32 + half * 16);
@@ -126,9 +129,9 @@ __global__ void __launch_bounds__(256) fused_ir_kernel(const IRArgs a) {
     auto store_w = [&](int buf) {
         char* wb = wbuf + buf * WBUF;
 #pragma unroll
-        for (int i = 0; i < W0_L; ++i) { const int sl = tid + i * 256; if (sl < W0_SLOTS) *(v4i*)(wb + sl * 16) = rw0[i]; }
+        for (int i = 0; i < W0_L; ++i) { const int sl = tid + i * NT; if (sl < W0_SLOTS) *(v4i*)(wb + sl * 16) = rw0[i]; }
 #pragma unroll
-        for (int i = 0; i < W4_L; ++i) { const int sl = tid + i * 256; if (sl < W4_SLOTS) *(v4i*)(wb + OFF_W4 + sl * 16) = rw4[i]; }
+        for (int i = 0; i < W4_L; ++i) { const int sl = tid + i * NT; if (sl < W4_SLOTS) *(v4i*)(wb + OFF_W4 + sl * 16) = rw4[i]; }
         if (tid < 36) *(v4i*)(wb + OFF_DW + tid * 16) = rsm;
         else if (tid < 52) *(v4i*)(wb + OFF_DWB + (tid - 36) * 16) = rsm;
         else if (tid < SM_SLOTS) *(v4i*)(wb + OFF_B0 + (tid - 52) * 16) = rsm;
@@ -154,7 +157,7 @@ __global__ void __launch_bounds__(256) fused_ir_kernel(const IRArgs a) {
                                                            // every wave is done with the previous chunk's P3 (mid2) and P2 (patch)
         if (e + 1 < nchunk) load_w(e + 1);                 // in flight during P1 .. P3
         // ================= P1: expand -> patch
-        for (int pt = wave; pt < np1; pt += 4) {
+        for (int pt = wave; pt < np1; pt += NW) {
             v16i acc[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -217,8 +220,8 @@ __global__ void __launch_bounds__(256) fused_ir_kernel(const IRArgs a) {
             // every conv in the library turns into a 16-byte row (permlane32 swap).  The VALU version below spends 8 v_perm_b32 + 4 v_dot4
             // per quad and tap group on transposing 4 taps x 4 channels: ~9 vector operations per output against 9 MFMAs per 1024.
             const int npo = (OUT_PX + 31) >> 5;
-            for (int ctd = 0; ctd < nct; ++ctd) {
-                if (wave >= npo) break;
+            for (int pr = wave; pr < npo * nct; pr += NW) {           // (channel tile, pixel tile) pairs over the waves
+                const int ctd = pr / npo, pt = pr - ctd * npo;
                 v4i wa[9];                                       // the nine diagonal fragments of this 32-channel tile
                 {
                     const int cch = ctd * 32 + l31;              // channel (of the chunk) this lane's A row belongs to
@@ -233,7 +236,7 @@ __global__ void __launch_bounds__(256) fused_ir_kernel(const IRArgs a) {
                         wa[t] = v4i{dsel == 0 ? piece : 0, dsel == 1 ? piece : 0, dsel == 2 ? piece : 0, dsel == 3 ? piece : 0};
                     }
                 }
-                for (int pt = wave; pt < npo; pt += 4) {
+                {
                     const int op = pt * 32 + l31;
                     const bool ok2 = op < OUT_PX;
                     int g, orow, ocol;
@@ -271,7 +274,7 @@ __global__ void __launch_bounds__(256) fused_ir_kernel(const IRArgs a) {
             }
         } else {
         //                  (VALU: one item = one output pixel x 16 channels)
-        for (int it = tid; it < OUT_PX * 4; it += 256) {
+        for (int it = tid; it < OUT_PX * 4; it += NT) {
             const int op = it >> 2, cg = it & 3;
             if (cg >= nct * 2) continue;
             int g, orow, ocol;
@@ -440,7 +443,7 @@ static hipError_t launch_ir_t(const IRArgs& a, int lds, hipStream_t s) {
         if (dev >= 0) attr_lds[dev] = lds;
     }
     const int grid = a.G > 1 ? (a.N + a.G - 1) / a.G : a.N * a.tiles_per_img;
-    hipLaunchKernelGGL((fused_ir_kernel<CIN_S, COUT_S, FQ>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((fused_ir_kernel<CIN_S, COUT_S, FQ>), dim3(grid), dim3(CIN_S == 32 && COUT_S == 32 ? 512 : 256), lds, s, a);
     return hipGetLastError();
 }
 
