@@ -31,7 +31,7 @@ __device__ __forceinline__ v4i dw_next_lane(const v4i& v) {   // lane i <- lane 
 // S: stride.  FQ: every int8 output format is a right shift into unsigned 8-bit behind a ReLU (4-operation requantisation, ReLU = the clamp).
 // SUBS: output rows per MFMA pixel tile: 1 = 32 lanes along one row (28 outputs), 2 = two rows of 16 lanes (14 outputs each: 14-wide maps)
 template <int S, bool FQ, int SUBS>
-__global__ void __launch_bounds__(256) dwconv3x3_mma_kernel(const DwArgs a) {
+__global__ void __launch_bounds__(256, S == 1 ? 4 : 3) dwconv3x3_mma_kernel(const DwArgs a) {
     constexpr int VW = SUBS == 2 ? 14 : DW_SW;                      // output columns per sub-row
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 3;

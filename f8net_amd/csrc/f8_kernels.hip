@@ -102,8 +102,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, v16i (&acc)[TCO
 // DUAL: a second 1x1 conv (x2, w2, bias2; its own strides, no padding) is accumulated after the first in the
 // same DMA ring and takes the place of the residual operand:  out = join(acc + bias, acc2 + bias2).  This is the
 // downsample block's `body.4 + shortcut` pair: the int32 tensor between them never exists in HBM.
+// (Minimum occupancy for the 128 x 128 tile: left alone the compiler parks the 64 accumulator registers in AGPRs AND keeps ~94 VGPRs —
+// 158 registers, 2 - 3 waves per SIMD; bounded it needs 94 - 162 without scratch.  Same finding as f8_ir.hip, round 3.)
 template <int BM, int BN, int BK, int WPX, int WCO, bool HAS_PAD, bool HAS_RES, int STAGES, bool DUAL = false>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
+__global__ void __launch_bounds__(256, BM * BN >= 128 * 128 ? (DUAL ? 2 : HAS_RES ? 3 : 4) : 1) conv_igemm_kernel(const ConvArgs a) {
     static_assert(WPX * WCO == 4, "4 waves");
     static_assert(!DUAL || (HAS_RES && !HAS_PAD), "dual GEMM: the second product is the residual operand; 1x1 convs only");
     static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
