@@ -231,7 +231,8 @@ int f8_net_check(f8_net* net);
  *               f8_net_set_pipelined(2) with pipeline_depth), fuse_blocks, fuse_stages (bit mask, -1 = auto), fuse_dual,
  *               fuse_ds, fuse_opener, fuse_fc (the classifier writes the caller's logits buffer itself), fuse_stem, fuse_input (the fused stem launch reads the caller's NCHW buffer itself), fuse_ir (1 = where it wins, 2 = every block), fuse_chain (all consecutive bottleneck blocks of a stage in one launch, the int32 residual stream in registers),
  *               fuse_bchain (the same for BasicBlock stages: 1 = consecutive identity blocks, 2 = with the stage-opening block in front), stem_rows (ResNet head:
- *               row-walking kernel, pool in registers), fuse_p12 (7x7 block: first two
+ *               row-walking kernel, pool in registers), fuse_head2 (MobileNet-V2: head conv + depthwise + 1x1 as one row-walking launch), dw_mma (depthwise
+ *               3x3 on the matrix cores), shared_streams (internal streams are one set per device for all handles), fuse_p12 (7x7 block: first two
  *               convs in one launch), wstat (weight-stationary 1x1 kernel: plain, dual-GEMM and residual-join instances) with
  *               wstat_min_tiles (pixel tiles per workgroup a launch must offer; 0 = always) and wstat_fast (0 = general epilogue), wreg (weights-streamed 1x1 kernel for the
  *               512 -> 256 / 1024 -> 512 reductions of smaller launches),
