@@ -211,3 +211,22 @@ def test_stream_evaluator_matches_oracle_on_host_fed_batches():
     assert abs(r['top1'] - hit1 / sum(sizes)) < 1e-12 and abs(r['top3'] - hit3 / sum(sizes)) < 1e-12
     r2 = ev.run(feed[:2])                       # a second epoch on the same evaluator
     assert r2['images'] == 8
+
+
+@pytest.mark.parametrize('arch', ['mobilenet_v2', 'resnet18'])
+@pytest.mark.parametrize('nhwc', [False, True])
+def test_uint8_entry_through_the_fused_heads(dev, arch, nhwc):
+    """f8_net_run_u8 on whole nets whose head is a row-walking launch (f8_stem.hip): uint8 NCHW planes are read by its loader waves
+    through the 3 x 256 table, uint8 NHWC goes through the input launch and the haloed form (the launch's KIND -1 loader).  An unsigned
+    fraclen-8 head sees the pixel values themselves: the logits equal those of f8_net_run on the same integers, at 224 (bands, strips)
+    and 64 pixels."""
+    from f8net_amd.net import build_net
+    spec = topology.get(arch, num_classes=20)
+    params = synth.make_params(spec, seed=41)
+    for hw, n in ((224, 3), (64, 2)):
+        u8 = synth.rand_uniform_int(43, f'u8{arch}{hw}', (n, 3, hw, hw), 0, 255).astype(np.uint8)
+        net = build_net(spec, params, max_batch=n, hw=hw)
+        want = net.run(torch.from_numpy(u8.astype(np.int32)).to(dev)).cpu().numpy()
+        img = torch.from_numpy(np.ascontiguousarray(u8.transpose(0, 2, 3, 1)) if nhwc else u8).to(dev)
+        got = net.run_u8(img, nhwc=nhwc).cpu().numpy()
+        np.testing.assert_array_equal(got, want)
