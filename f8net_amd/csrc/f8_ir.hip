@@ -16,9 +16,9 @@
 // registers while this chunk computes).  Two barriers per chunk.  Epilogue: bias, [align + int32 residual + clamp], int32 (I32T)
 // and / or requantised int8 copies.
 //
-// Work unit: R output rows x full width of one image (R * Wo <= 128), or G whole images when a map has <= 64 pixels.
-// 256 threads = 4 waves; wave w owns output pixel tile w in P3 / the epilogue and every 4th pixel tile in P1.  All shapes are
-// run-time values (the kernel is instantiated per (CIN, COUT) channel pair only): the 64x64 test nets run the same code.
+// Work unit: R output rows x full width of one image (R * Wo <= 128; 256 for the <32, 32> instance), or G whole images when a map has
+// <= 64 pixels.  4 or 8 waves (NW below); a wave owns one output pixel tile in P3 / the epilogue and every PXW-th pixel tile in P1.  All
+// shapes are run-time values (the kernel is instantiated per (CIN, COUT) channel pair only): the 64x64 test nets run the same code.
 #include "f8_device.h"
 
 namespace f8 {
@@ -28,24 +28,38 @@ namespace f8 {
 // lower bound (requant is monotone and maps 0 to 0), the bias rides in the accumulators' start value, the shift is requant_shr: 5 vector
 // operations per expanded value instead of 9 — and the expanded values are what this kernel is bound by (VALU, not memory)
 // NW: waves per workgroup.  8 for the <32, 32> instance (stages 1 - 2 of MobileNet-V2: 122 registers, so two workgroups = 16 waves fit a CU):
-// the launch is bound by vector work between barriers, and at 4 waves x 2 workgroups a SIMD had two waves to hide them with.
-template <int CIN_S, int COUT_S, bool FQ, bool P2MMA = (COUT_S <= 96), int NW = (CIN_S == 32 && COUT_S == 32 ? 8 : 4)>
+// the launch is bound by vector work between barriers, and at 4 waves x 2 workgroups a SIMD had two waves to hide them with; its 8 waves
+// carry 8 pixel tiles (256 output pixels: more output rows per tile, fewer expand rows computed twice).
+// SPLIT (the other 8-wave instances, 14x14 maps: 256 workgroups on 256 CUs, so a 4-wave workgroup leaves ONE wave per SIMD and every phase
+// runs at the latency of its own dependency chain): waves 4 - 7 take the second half of the channels of the same four pixel tiles — P1's
+// second 32 expanded channels, P3's and the epilogue's upper output-channel tiles; P2 already iterates (channel tile, pixel tile) pairs
+#ifndef F8_IR_SPLIT
+#define F8_IR_SPLIT 1
+#endif
+constexpr int ir_nw(int cinS, int coutS) { return (cinS == 32 && coutS == 32) || (F8_IR_SPLIT && coutS <= 96) ? 8 : 4; }
+template <int CIN_S, int COUT_S, bool FQ, bool P2MMA = (COUT_S <= 96), int NW = ir_nw(CIN_S, COUT_S)>
 __global__ void __launch_bounds__(NW * 64, (COUT_S <= 64 ? 4 : COUT_S <= 96 ? 3 : COUT_S <= 160 ? 2 : 1)) fused_ir_kernel(const IRArgs a) {
     constexpr int NT = NW * 64;
+    constexpr bool SPLIT = NW == 8 && !(CIN_S == 32 && COUT_S == 32);
+    constexpr int PXW = SPLIT ? 4 : NW;                    // waves that own a pixel tile of their own
+    constexpr int MID2_CT = PXW * 1024;                    // bytes of one 32-channel plane of mid2: PXW pixel tiles x 32 px x 32 B
     constexpr int KK1 = CIN_S / 32, NCO = COUT_S / 32;
+    constexpr int JSPLIT = (NCO + 1) / 2;                  // SPLIT: output-channel tiles [0, JSPLIT) on waves 0 - 3, the rest on waves 4 - 7
     constexpr int W0_BYTES = 64 * CIN_S, W4_BYTES = COUT_S * 64;
     constexpr int W0_SLOTS = W0_BYTES / 16, W4_SLOTS = W4_BYTES / 16, SM_SLOTS = 36 + 16 + 16;   // dw weights (576 B), dw bias, expand bias
     constexpr int W0_L = (W0_SLOTS + NT - 1) / NT, W4_L = (W4_SLOTS + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const X = lds;                                   // [KK1][xp][32 B]
     char* const patch = lds + a.off_patch;                 // [G][PR][PW][64 B]
-    char* const mid2 = lds + a.off_mid2;                   // [2][128][32 B]
+    char* const mid2 = lds + a.off_mid2;                   // [2][NW * 32][32 B]
     char* const wbuf = lds + a.off_w;                      // 2 x { W0 [KK1][64][32] | W4 [2][COUT_S][32] | dw 576 B (+64 pad) | dw bias 256 B | b0 256 B }
     constexpr int OFF_W4 = W0_BYTES, OFF_DW = OFF_W4 + W4_BYTES, OFF_DWB = OFF_DW + 640, OFF_B0 = OFF_DWB + 256, WBUF = OFF_B0 + 256;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & (NW - 1);
     const int l31 = lane & 31, lh = lane >> 5;
+    const int pw = SPLIT ? wave & 3 : wave, ch = SPLIT ? wave >> 2 : 0;
+    auto my_j = [&](int j) { return !SPLIT || (ch == 0 ? j < JSPLIT : j >= JSPLIT); };
     const int s = a.stride, R = a.R, W = a.W, H = a.H, Wo = a.Wo, PW = W + 2;
     const int PR = (R - 1) * s + 3;
     int t;
@@ -157,7 +171,7 @@ __global__ void __launch_bounds__(NW * 64, (COUT_S <= 64 ? 4 : COUT_S <= 96 ? 3 
                                                            // every wave is done with the previous chunk's P3 (mid2) and P2 (patch)
         if (e + 1 < nchunk) load_w(e + 1);                 // in flight during P1 .. P3
         // ================= P1: expand -> patch
-        for (int pt = wave; pt < np1; pt += NW) {
+        for (int pt = pw; pt < np1; pt += PXW) {
             v16i acc[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -173,7 +187,7 @@ __global__ void __launch_bounds__(NW * 64, (COUT_S <= 64 ? 4 : COUT_S <= 96 ? 3 
                 const v4i xf = *(const v4i*)(X + ((size_t)kk * a.xp + pt * 32 + l31) * 32 + lh * 16);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-                    if (i < nct) {
+                    if (i < nct && (!SPLIT || i == ch)) {
                         const v4i wf = *(const v4i*)(wb + (kk * 64 + i * 32 + l31) * 32 + lh * 16);
                         acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, xf, acc[i], 0, 0, 0);
                     }
@@ -186,7 +200,7 @@ __global__ void __launch_bounds__(NW * 64, (COUT_S <= 64 ? 4 : COUT_S <= 96 ? 3 
             const int ent = (g * PR + (vr0 + vr - in_row0)) * PW + c + 1;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                if (i >= nct) continue;
+                if (i >= nct || (SPLIT && i != ch)) continue;
                 unsigned d[4];
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
@@ -268,7 +282,7 @@ __global__ void __launch_bounds__(NW * 64, (COUT_S <= 64 ? 4 : COUT_S <= 96 ? 3 
                     auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
                     if (ok2) {
                         const v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
-                        *(v4i*)(mid2 + ctd * 4096 + op * 32 + lh * 16) = o;
+                        *(v4i*)(mid2 + ctd * MID2_CT + op * 32 + lh * 16) = o;
                     }
                 }
             }
@@ -316,20 +330,21 @@ __global__ void __launch_bounds__(NW * 64, (COUT_S <= 64 ? 4 : COUT_S <= 96 ? 3 
                                 requant1(max(ac[2], floor_b), a.n2, a.lo2, a.hi2), requant1(max(ac[3], floor_b), a.n2, a.lo2, a.hi2)) ^ a.xor2;
             }
             const v4i o = {(int)outw[0], (int)outw[1], (int)outw[2], (int)outw[3]};
-            *(v4i*)(mid2 + (cg >> 1) * 4096 + op * 32 + (cg & 1) * 16) = o;
+            *(v4i*)(mid2 + (cg >> 1) * MID2_CT + op * 32 + (cg & 1) * 16) = o;
         }
         }
         (void)padv;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                      // mid2 complete
         // ================= P3: project, accumulate over the chunks (wave = output pixel tile)
-        if (wave * 32 < OUT_PX) {
+        if (pw * 32 < OUT_PX) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 if (kk >= nct) continue;
-                const v4i xf = *(const v4i*)(mid2 + kk * 4096 + (wave * 32 + l31) * 32 + lh * 16);
+                const v4i xf = *(const v4i*)(mid2 + kk * MID2_CT + (pw * 32 + l31) * 32 + lh * 16);
 #pragma unroll
                 for (int j = 0; j < NCO; ++j) {
+                    if (!my_j(j)) continue;
                     const v4i wf = *(const v4i*)(wb + OFF_W4 + ((kk * COUT_S) + j * 32 + l31) * 32 + lh * 16);
                     acc3[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, xf, acc3[j], 0, 0, 0);
                 }
@@ -339,8 +354,8 @@ __global__ void __launch_bounds__(NW * 64, (COUT_S <= 64 ? 4 : COUT_S <= 96 ? 3 
     }
 
     // ================= epilogue: bias, [align + int32 residual + clamp], int32 (I32T) and / or int8 copies
-    const int opx = wave * 32 + l31;
-    if (wave * 32 >= OUT_PX) return;
+    const int opx = pw * 32 + l31;
+    if (pw * 32 >= OUT_PX) return;
     const bool ok = opx < OUT_PX;
     const int oc = ok ? opx : 0;
     int g, orow, ocol;
@@ -349,6 +364,7 @@ __global__ void __launch_bounds__(NW * 64, (COUT_S <= 64 ? 4 : COUT_S <= 96 ? 3 
     const int floor0 = a.relu0 ? 0 : INT32_MIN, floor1 = a.relu1 ? 0 : -2147483647;
 #pragma unroll
     for (int j = 0; j < NCO; ++j) {
+        if (!my_j(j)) continue;
         const int cot = j * 32;
         int y[4][4];
 #pragma unroll
@@ -397,6 +413,9 @@ static bool ir_instance(int cinS, int coutS) {
     return false;
 }
 
+// output pixels of a tile: one 32-pixel tile per wave in P3 (8 waves for the <32, 32> instance, else 4)
+static int ir_max_px(int cinS, int coutS) { return cinS == 32 && coutS == 32 ? 256 : 128; }
+
 // LDS layout of a tile (bytes); false if it does not fit
 static bool ir_layout(int cinS, int coutS, int H, int W, int stride, int R, int G, IRArgs* a, int* lds_bytes) {
     const int PR = (R - 1) * stride + 3, PW = W + 2;
@@ -405,8 +424,9 @@ static bool ir_layout(int cinS, int coutS, int H, int W, int stride, int R, int 
     const int x_bytes = xp * cinS;
     const int patch = (G * PR * PW * 64 + 255) / 256 * 256;
     const int wbuf = 64 * cinS + coutS * 64 + 640 + 256 + 256;
-    const int total = x_bytes + patch + 8192 + 2 * wbuf;
-    if (a) { a->xp = xp; a->off_patch = x_bytes; a->off_mid2 = x_bytes + patch; a->off_w = x_bytes + patch + 8192; }
+    const int mid2 = 2 * ir_max_px(cinS, coutS) * 32;
+    const int total = x_bytes + patch + mid2 + 2 * wbuf;
+    if (a) { a->xp = xp; a->off_patch = x_bytes; a->off_mid2 = x_bytes + patch; a->off_w = x_bytes + patch + mid2; }
     if (lds_bytes) *lds_bytes = total;
     return total <= 160 * 1024;
 }
@@ -415,13 +435,16 @@ static bool ir_layout(int cinS, int coutS, int H, int W, int stride, int R, int 
 bool fused_ir_config(int cinS, int coutS, int H, int W, int stride, int* R, int* G) {
     if (!ir_instance(cinS, coutS) || (stride != 1 && stride != 2) || H < 1 || W < 1) return false;
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-    if (Wo > 128) return false;
-    int r = 128 / Wo;
+    const int cap = ir_max_px(cinS, coutS);
+    if (Wo > cap) return false;
+    int r = cap / Wo;
     if (r > Ho) r = Ho;
     while (r > 1 && Ho % r != 0) --r;
     int g = 1;
     if (r == Ho) { g = 128 / (Ho * Wo); if (g < 1) g = 1; if (g > 8) g = 8; }
-    while (!ir_layout(cinS, coutS, H, W, stride, r, g, nullptr, nullptr)) {
+    // the 8-wave instance wants two workgroups per CU (16 waves at occupancy 4): prefer tiles of at most 80 KB
+    int lds = 0;
+    while (!ir_layout(cinS, coutS, H, W, stride, r, g, nullptr, &lds) || (cap > 128 && lds > 80 * 1024 && g == 1 && r > 1)) {
         if (g > 1) { --g; continue; }
         if (r <= 1) return false;
         --r;
@@ -443,7 +466,7 @@ static hipError_t launch_ir_t(const IRArgs& a, int lds, hipStream_t s) {
         if (dev >= 0) attr_lds[dev] = lds;
     }
     const int grid = a.G > 1 ? (a.N + a.G - 1) / a.G : a.N * a.tiles_per_img;
-    hipLaunchKernelGGL((fused_ir_kernel<CIN_S, COUT_S, FQ>), dim3(grid), dim3(CIN_S == 32 && COUT_S == 32 ? 512 : 256), lds, s, a);
+    hipLaunchKernelGGL((fused_ir_kernel<CIN_S, COUT_S, FQ>), dim3(grid), dim3(ir_nw(CIN_S, COUT_S) * 64), lds, s, a);
     return hipGetLastError();
 }
 

@@ -1441,7 +1441,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                         int n1 = 0, n2 = 0;
                         consumer_format(T[nb.a], nb.cd, &n1, "finalize"); consumer_format(T[nd.a], nd.cd, &n2, "finalize");
                         const bool fq = na.cd.relu && nb.cd.relu && !nb.cd.input_signed && !nd.cd.input_signed && n1 > 0 && n2 > 0 && nd.coutP <= 96;
-                        snprintf(kb, sizeof kb, "f8::fused_ir_kernel<%d, %d, %s, %s, %d>", x.Cs, nd.coutP, fq ? "true" : "false", nd.coutP <= 96 ? "true" : "false", (x.Cs == 32 && nd.coutP == 32) ? 8 : 4);
+                        snprintf(kb, sizeof kb, "f8::fused_ir_kernel<%d, %d, %s, %s, %d>", x.Cs, nd.coutP, fq ? "true" : "false", nd.coutP <= 96 ? "true" : "false", nd.coutP <= 96 ? 8 : 4);
                     }
                     st.kernel = kb;
                     break;
