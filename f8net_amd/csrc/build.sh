@@ -27,6 +27,8 @@ for f in f8_kernels f8_fused f8_conv3x3 f8_stem f8_opener f8_ir f8_p12 f8_wreg f
 if grep -lE "(^|[^a-z])error( generated|:)" ../../build/f8_*.log; then echo "ERROR: compile errors (logs above)"; exit 1; fi
 $HIPCC --offload-arch=gfx950 -shared -fPIC ../../build/f8_kernels.o ../../build/f8_fused.o ../../build/f8_conv3x3.o ../../build/f8_stem.o ../../build/f8_opener.o ../../build/f8_ir.o ../../build/f8_p12.o ../../build/f8_wreg.o ../../build/f8_wstat.o ../../build/f8_s2conv.o ../../build/f8_fc.o ../../build/f8_chain.o ../../build/f8_bchain.o ../../build/f8_dwmma.o ../../build/f8_net.o -o $OUT
 echo "built $(readlink -f $OUT)"
+# device probe of the float requantisation (f8_device.h requant_u8x4): a stand-alone binary, run by tests/test_gpu_requant_probe.py
+$HIPCC --offload-arch=gfx950 -O2 ../../tools/ubench/cvt_u8_probe.hip -o ../../tools/ubench/cvt_u8_probe.bin 2> ../../build/cvt_u8_probe.log || { echo "ERROR: cvt_u8_probe"; exit 1; }
 # occupancy 1 = a kernel that spilled its accumulators into AGPRs on top of a full VGPR file (round 3: fused_ir_kernel ran like that)
 grep -B8 "Occupancy \[waves/SIMD\]: 1" ../../build/f8_*.log 2>/dev/null | grep "Function Name" | sed -E "s/.*Function Name: ([^ ]+).*/NOTE: occupancy 1: \1/" | sort -u | head -20 || true
 # a kernel whose host stub was silently dropped would only fail at dlopen time: catch it here

@@ -40,16 +40,18 @@ struct BChainCfg {
     static_assert(ROWB / 16 <= 256 && (size_t)256 * 4 * ROWB <= kChainXchgBytes, "one 16-byte piece of a halo row per thread of a half workgroup");
 };
 
-template <bool FAST, class Y>
+template <bool FAST, bool ACC = false, class Y>
 __device__ __forceinline__ v4i bquant_tile16(const Y& y, int n, int lo, int hi, unsigned x_or) {
     unsigned d[4];
+    // FAST: lo == 0, hi == 255, 1 <= n <= 16.  ACC: y is a conv accumulator (bounded: BChainArgs::acc_ok) -> 3 operations per value (f8_device.h);
+    // the stream can hold any int32, its `v + 2^(n-1)` may wrap like the reference's: the 4-operation float form (no packing operations)
+    const float sc = FAST ? requant_u8_scale(n) : 0.0f;
     const unsigned half = FAST ? (1u << (n - 1)) : 0u;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        int q[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) q[e] = FAST ? requant_shr(y[4 * g + e], n, half, 0u, lo, hi) : requant1(y[4 * g + e], n, lo, hi);
-        d[g] = pack4(q[0], q[1], q[2], q[3]) ^ x_or;
+        if constexpr (FAST && !ACC) d[g] = requant_u8x4_wrap(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], sc, half) ^ x_or;
+        else if constexpr (FAST) d[g] = requant_u8x4(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], sc) ^ x_or;
+        else d[g] = pack4(requant1(y[4 * g], n, lo, hi), requant1(y[4 * g + 1], n, lo, hi), requant1(y[4 * g + 2], n, lo, hi), requant1(y[4 * g + 3], n, lo, hi)) ^ x_or;
     }
     auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
     auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
@@ -383,7 +385,7 @@ bchain_kernel(const BChainArgs a) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[j][r] = max(acc[j][r], floor0);
                     }
-                    const v4i o = bquant_tile16<FAST>(acc[j], n1, lo1, hi1, xor1);
+                    const v4i o = bquant_tile16<FAST, true>(acc[j], n1, lo1, hi1, xor1);
                     if (pix < npx) *(v4i*)(patchM + ((pr + 1) * PW + pc + 1) * CS + ct * 32 + lh * 16) = o;
                 } }
             }
@@ -469,13 +471,14 @@ bool bchain_ds_supported(int C, int H, int W) { return bchain_rows(C, H, W) > 0 
 int bchain_tiles_per_img(int C, int H, int W) { const int r = bchain_rows(C, H, W); return r ? (H + r - 1) / r : 0; }
 
 bool bchain_fast(const BChainArgs& a) {
+    if (!a.acc_ok) return false;
     for (int k = 0; k < a.nblk; ++k) {
         const BChainBlk& B = a.blk[k];
-        if (!(B.relu_a && B.relu1 && B.n1 > 0 && B.lo1 == 0)) return false;
+        if (!(B.relu_a && B.relu1 && B.n1 > 0 && B.n1 <= kRequantU8MaxShift && B.lo1 == 0)) return false;
         if (k == 0 && a.x8in) continue;                      // opening block: its input arrives as int8, its join shifts either operand
-        if (!(B.nq > 0 && B.loq == 0 && B.res_shl == 0)) return false;
+        if (!(B.nq > 0 && B.nq <= kRequantU8MaxShift && B.loq == 0 && B.res_shl == 0)) return false;
     }
-    if (a.q[0].ptr && !(a.q[0].n > 0 && a.q[0].lo == 0)) return false;
+    if (a.q[0].ptr && !(a.q[0].n > 0 && a.q[0].n <= kRequantU8MaxShift && a.q[0].lo == 0)) return false;
     return true;
 }
 

@@ -57,17 +57,19 @@ struct ChainCfg {
 
 // 16 accumulator values of one 32x32 tile (this lane: one pixel, channels 8g + 4 lh + e) -> this lane's 16 bytes of the int8 row:
 // channels [16 lh, 16 lh + 16) of the tile (two v_permlane32_swap put a lane's four dwords side by side).
-// FAST: n > 0 is known (4-operation requant, f8_device.h); otherwise either direction.
-template <bool FAST>
+// FAST: unsigned 8-bit behind a ReLU with 1 <= n <= 16 (3-operation requant, f8_device.h); otherwise either direction, any clamp.
+template <bool FAST, bool ACC = false>
 __device__ __forceinline__ v4i quant_tile16(const v16i& y, int n, int lo, int hi, unsigned x_or) {
     unsigned d[4];
+    // FAST: lo == 0, hi == 255, 1 <= n <= 16.  ACC: y is a conv accumulator (bounded: ChainArgs::acc_ok) -> 3 operations per value (f8_device.h);
+    // the stream can hold any int32, its `v + 2^(n-1)` may wrap like the reference's: the 4-operation float form (no packing operations)
+    const float sc = FAST ? requant_u8_scale(n) : 0.0f;
     const unsigned half = FAST ? (1u << (n - 1)) : 0u;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        int q[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) q[e] = FAST ? requant_shr(y[4 * g + e], n, half, 0u, lo, hi) : requant1(y[4 * g + e], n, lo, hi);
-        d[g] = pack4(q[0], q[1], q[2], q[3]) ^ x_or;
+        if constexpr (FAST && !ACC) d[g] = requant_u8x4_wrap(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], sc, half) ^ x_or;
+        else if constexpr (FAST) d[g] = requant_u8x4(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], sc) ^ x_or;
+        else d[g] = pack4(requant1(y[4 * g], n, lo, hi), requant1(y[4 * g + 1], n, lo, hi), requant1(y[4 * g + 2], n, lo, hi), requant1(y[4 * g + 3], n, lo, hi)) ^ x_or;
     }
     auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
     auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
@@ -318,7 +320,7 @@ chain_kernel(const ChainArgs a) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) acc[j][r] = max(acc[j][r], floor0);
                         }
-                        const v4i o = quant_tile16<FAST>(acc[j], n1, lo1, hi1, xor1);   // FAST: lo1 == 0 is the ReLU
+                        const v4i o = quant_tile16<FAST, true>(acc[j], n1, lo1, hi1, xor1);   // FAST: lo1 == 0 is the ReLU
                         if (pix < npx) *(v4i*)(patch + ent * MS + mt * 32 + lh * 16) = o;
                     }
                 }
@@ -442,7 +444,7 @@ chain_kernel(const ChainArgs a) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) acc[j][r] = max(acc[j][r], floor0);
                         }
-                        *(v4i*)(mid2 + p12m[j] + mt * 32) = quant_tile16<FAST>(acc[j], n2, lo2, hi2, xor2);
+                        *(v4i*)(mid2 + p12m[j] + mt * 32) = quant_tile16<FAST, true>(acc[j], n2, lo2, hi2, xor2);
                     }
                 }
                 F8_CT(3);
@@ -660,12 +662,13 @@ static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t s) {
 #endif
 // FAST instance: see chain_kernel
 bool chain_fast(const ChainArgs& a) {
+    if (!a.acc_ok) return false;
     for (int k = 0; k < a.nblk; ++k) {
         const ChainBlk& B = a.blk[k];
-        if (!(B.relu_a && B.relu_b && B.relu1 && B.n1 > 0 && B.n2 > 0 && B.nq > 0 && B.lo1 == 0 && B.lo2 == 0 && B.loq == 0)) return false;
+        if (!(B.relu_a && B.relu_b && B.relu1 && B.n1 > 0 && B.n2 > 0 && B.nq > 0 && B.n1 <= kRequantU8MaxShift && B.n2 <= kRequantU8MaxShift && B.nq <= kRequantU8MaxShift && B.lo1 == 0 && B.lo2 == 0 && B.loq == 0)) return false;
         if (B.wsc == nullptr && B.res_shl != 0) return false;
     }
-    if (a.q[0].ptr && !(a.q[0].n > 0 && a.q[0].lo == 0)) return false;
+    if (a.q[0].ptr && !(a.q[0].n > 0 && a.q[0].n <= kRequantU8MaxShift && a.q[0].lo == 0)) return false;
     return true;
 }
 

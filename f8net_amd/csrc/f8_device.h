@@ -48,6 +48,31 @@ __device__ __forceinline__ int requant1(int v, int n, int lo, int hi) {
     return med3i(r >> shr, lo, hi);
 }
 
+// ReLU -> UNSIGNED 8-bit by a right shift of 1 <= n <= 16 (fix_quant_ops.py:99-112 with the clamp [0, 255]; the ReLU is the clamp's lower
+// bound) in THREE vector operations per value, packing included: v_cvt_f32_i32 (exact below 2^24; above it the quotient saturates whatever
+// that rounding did, because n <= 16), v_mul_f32 by 2^-n (exact), v_cvt_pk_u8_f32 (round to nearest EVEN, saturate to [0, 255], insert into
+// byte k of the dword).  Compared on the device with the integer form for EVERY int32 value and every n in 1 .. 16: identical
+// (tools/ubench/cvt_u8_probe.hip, tests/test_gpu_requant_probe.py; n >= 17 differs from 2^24 on, as predicted) — the hosts select the
+// instances that use this only when every shift involved is in 1 .. 16 (kRequantU8MaxShift).
+constexpr int kRequantU8MaxShift = 16;
+__device__ __forceinline__ float requant_u8_scale(int n) { return __builtin_ldexpf(1.0f, -n); }   // wave-uniform, hoisted
+__device__ __forceinline__ unsigned requant_u8x4(int a, int b, int c, int d, float scale) {
+    unsigned r = __builtin_amdgcn_cvt_pk_u8_f32((float)a * scale, 0u, 0u);
+    r = __builtin_amdgcn_cvt_pk_u8_f32((float)b * scale, 1u, r);
+    r = __builtin_amdgcn_cvt_pk_u8_f32((float)c * scale, 2u, r);
+    return __builtin_amdgcn_cvt_pk_u8_f32((float)d * scale, 3u, r);
+}
+// The same for ANY int32 value, the reference's wrap included, in FOUR operations: s = v + 2^(n-1) (v_add_u32: wraps exactly where the
+// reference's int32 add does, and a wrapped s is negative -> 0 like the reference's clamp), v_cvt_f32_i32, v_fma_f32 (s * 2^-n - 0.5 =
+// v / 2^n, exact below 2^24, saturating above), v_cvt_pk_u8_f32.  Same probe (mode 1: against the wrapping integer form, every int32 value,
+// n in 1 .. 16).  For the int32 STREAM of the chain kernels, which may hold anything.
+__device__ __forceinline__ unsigned requant_u8x4_wrap(int a, int b, int c, int d, float scale, unsigned half) {
+    unsigned r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)(int)((unsigned)a + half), scale, -0.5f), 0u, 0u);
+    r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)(int)((unsigned)b + half), scale, -0.5f), 1u, r);
+    r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)(int)((unsigned)c + half), scale, -0.5f), 2u, r);
+    return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)(int)((unsigned)d + half), scale, -0.5f), 3u, r);
+}
+
 // q = n / d for a divisor known on the host: q = (t + ((n - t) >> sh1)) >> sh2, t = mulhi(n, magic)
 // (round-up method, exact for every 32-bit n; host: f8_net.cpp make_magic)
 __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic, int sh1, int sh2) {

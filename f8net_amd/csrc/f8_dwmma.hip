@@ -28,7 +28,7 @@ __device__ __forceinline__ v4i dw_next_lane(const v4i& v) {   // lane i <- lane 
 }
 }
 
-// S: stride.  FQ: every int8 output format is a right shift into unsigned 8-bit behind a ReLU (4-operation requantisation, ReLU = the clamp).
+// S: stride.  FQ: every int8 output format is a right shift into unsigned 8-bit behind a ReLU (shift 1 .. 16: 3-operation requantisation, f8_device.h; ReLU = the clamp).
 // SUBS: output rows per MFMA pixel tile: 1 = 32 lanes along one row (28 outputs), 2 = two rows of 16 lanes (14 outputs each: 14-wide maps)
 template <int S, bool FQ, int SUBS>
 __global__ void __launch_bounds__(256, S == 1 ? 4 : 3) dwconv3x3_mma_kernel(const DwArgs a) {
@@ -101,12 +101,9 @@ __global__ void __launch_bounds__(256, S == 1 ? 4 : 3) dwconv3x3_mma_kernel(cons
             if (!a.q[k].ptr) continue;                              // wave-uniform
             unsigned d[4];
             if constexpr (FQ) {
-                const int qn = a.q[k].n;
-                const unsigned half = 1u << (qn - 1);
+                const float sc = requant_u8_scale(a.q[k].n);
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    d[g] = pack4(requant_shr(acc[4 * g], qn, half, 0u, 0, 255), requant_shr(acc[4 * g + 1], qn, half, 0u, 0, 255),
-                                 requant_shr(acc[4 * g + 2], qn, half, 0u, 0, 255), requant_shr(acc[4 * g + 3], qn, half, 0u, 0, 255)) ^ 0x80808080u;
+                for (int g = 0; g < 4; ++g) d[g] = requant_u8x4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], sc) ^ 0x80808080u;
             } else {
                 const int floor0 = a.relu0 ? 0 : INT32_MIN;
 #pragma unroll
@@ -179,9 +176,9 @@ bool dwconv_mma_supported(const DwArgs& a) {
 
 hipError_t launch_dwconv_mma(const DwArgs& a0, hipStream_t s) {
     DwArgs a = a0; a.bias = a0.bias4;                               // bias + 128 * sum(w) for unsigned inputs
-    bool fq = a.relu0 != 0;
+    bool fq = a.relu0 != 0 && a.acc_ok != 0;
     for (int k = 0; k < 2; ++k)
-        if (a.q[k].ptr && !(a.q[k].n > 0 && a.q[k].lo == 0 && a.q[k].hi == 255 && a.q[k].bias_xor == 0x80808080u)) fq = false;
+        if (a.q[k].ptr && !(a.q[k].n > 0 && a.q[k].n <= kRequantU8MaxShift && a.q[k].lo == 0 && a.q[k].hi == 255 && a.q[k].bias_xor == 0x80808080u)) fq = false;
     const int subs = a.Q >= DW_SW ? 1 : 2, vw = subs == 2 ? 14 : DW_SW;
     a.band = DW_BAND;
     long long items = (long long)a.N * ((a.P + a.band - 1) / a.band) * ((a.Q + vw - 1) / vw) * (a.Cs >> 5);

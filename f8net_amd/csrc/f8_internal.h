@@ -116,6 +116,8 @@ struct DwArgs {
     int32_t use_dot4;                      // Options::dw_dot4
     int32_t use_mma;                       // Options::dw_mma
     int32_t band;                          // f8_dwmma.hip: output rows per wave (set by its launcher)
+    int32_t acc_ok;                        // every accumulator is provably below 2^31 - 2^16 in magnitude (planner: conv_acc_bounded): the
+                                           // float requantisation (requant_u8x4, f8_device.h) equals the wrapping integer one
 };
 
 struct PoolArgs {                          // max-pool, NHWC
@@ -188,6 +190,8 @@ struct ChainBlk {
 constexpr int kChainMaxBlocks = 6;
 struct ChainArgs {
     ChainBlk blk[kChainMaxBlocks]; int32_t nblk;
+    int32_t acc_ok;                        // body.0 / body.2 accumulators of every block bounded (see DwArgs::acc_ok); the stream is not
+
     const int32_t* xr;                     // first block an identity block: the stage's int32 stream (I32T) — its int8 form is computed in the launch
     const int8_t* x8in;                    // first block a stage-opening block: its int8 NHWC input [N*H*W][CIN0] in body.0's / the shortcut's format
     int32_t N, NG;                         // images; image groups resident at once (grid = NG * tiles per image)
@@ -213,6 +217,8 @@ struct BChainBlk {
 constexpr int kBChainMaxBlocks = 6;
 struct BChainArgs {
     BChainBlk blk[kBChainMaxBlocks]; int32_t nblk;
+    int32_t acc_ok;                        // first-conv accumulators of every block bounded (see DwArgs::acc_ok)
+
     const int32_t* xr;                     // the stage's int32 stream (I32T): chains of identity blocks
     // chains that start with the stage-opening block (blk[0]: wa = 3x3 / 2 over C/2 channels, wb = 3x3, the stream = its 1x1 / 2 shortcut):
     const int8_t* x8in;                    // int8 NHWC input [N][2H][2W][C/2] in the format blk[0].wa reads
@@ -226,6 +232,7 @@ struct BChainArgs {
 
 // One launch for a MobileNet-V2 inverted-residual block: 1x1 expand -> depthwise 3x3 -> 1x1 project [+ int32 residual] (f8_ir.hip).
 struct IRArgs {
+    int32_t acc_ok;                        // expand / depthwise accumulators bounded (see DwArgs::acc_ok)
     const int8_t* x8;                      // block input, int8 NHWC [N*H*W][CIN_S] in the expand conv's input format
     const int32_t* xr;                     // block input, int32 I32T (residual operand) or nullptr
     const int8_t* w0; const int32_t* b0;   // expand  [E32][CIN_S], offset-corrected bias [E32]
@@ -244,6 +251,7 @@ struct IRArgs {
 
 // ResNet head in one launch: 7x7/2 conv + ReLU + requant (unsigned 8-bit) + 3x3/2 max-pool (f8_stem.hip).
 struct StemPoolArgs {
+    int32_t acc_ok;                        // conv accumulators bounded (see DwArgs::acc_ok)
     const int8_t* x; uint32_t x_bytes;     // haloed NHWC4 input [N][Hp][Wp][4], halo = conv pad + org pixels
     const int8_t* w; uint32_t w_bytes;     // [64][7][32 B]
     const int32_t* bias;                   // [64], offset-corrected (single class: the halo is biased zero)

@@ -25,8 +25,8 @@ namespace f8 {
 
 // P2MMA: the depthwise phase on the matrix cores (instances whose project accumulators leave 52 registers for it)
 // FQ: both inner requantisations are right shifts into UNSIGNED 8-bit behind a ReLU (every block of MobileNet-V2): the ReLU is the clamp's
-// lower bound (requant is monotone and maps 0 to 0), the bias rides in the accumulators' start value, the shift is requant_shr: 5 vector
-// operations per expanded value instead of 9 — and the expanded values are what this kernel is bound by (VALU, not memory)
+// lower bound (requant is monotone and maps 0 to 0), the bias rides in the accumulators' start value, the shift (1 .. 16) is requant_u8x4: 3 vector
+// operations per expanded value, packing included, instead of 9 + packing — and the expanded values are what this kernel is bound by (VALU, not memory)
 // NW: waves per workgroup.  8 for the <32, 32> instance (stages 1 - 2 of MobileNet-V2: 122 registers, so two workgroups = 16 waves fit a CU):
 // the launch is bound by vector work between barriers, and at 4 waves x 2 workgroups a SIMD had two waves to hide them with; its 8 waves
 // carry 8 pixel tiles (256 output pixels: more output rows per tile, fewer expand rows computed twice).
@@ -159,8 +159,8 @@ __global__ void __launch_bounds__(NW * 64, (COUT_S <= 64 ? 4 : COUT_S <= 96 ? 3 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc3[j][r] = 0;
     const int floor_a = a.relu_a ? 0 : INT32_MIN, floor_b = a.relu_b ? 0 : INT32_MIN;
-    const unsigned half1 = FQ ? 1u << (a.n1 - 1) : 0u, half2 = FQ ? 1u << (a.n2 - 1) : 0u;
-    (void)floor_a; (void)half1; (void)half2;
+    const float sc1 = FQ ? requant_u8_scale(a.n1) : 0.0f, sc2 = FQ ? requant_u8_scale(a.n2) : 0.0f;
+    (void)floor_a; (void)sc1; (void)sc2;
     const unsigned padv = a.xor1;
 
     for (int e = 0; e < nchunk; ++e) {
@@ -206,9 +206,7 @@ __global__ void __launch_bounds__(NW * 64, (COUT_S <= 64 ? 4 : COUT_S <= 96 ? 3 
                 for (int gq = 0; gq < 4; ++gq) {
                     int y[4];
                     if constexpr (FQ) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) y[q] = requant_shr(acc[i][4 * gq + q], a.n1, half1, 0u, 0, 255);
-                        d[gq] = pack4(y[0], y[1], y[2], y[3]) ^ 0x80808080u;
+                        d[gq] = requant_u8x4(acc[i][4 * gq], acc[i][4 * gq + 1], acc[i][4 * gq + 2], acc[i][4 * gq + 3], sc1) ^ 0x80808080u;
                     } else {
                         const v4i bv = *(const v4i*)(wb + OFF_B0 + (i * 32 + 8 * gq + 4 * lh) * 4);
 #pragma unroll
@@ -272,8 +270,7 @@ __global__ void __launch_bounds__(NW * 64, (COUT_S <= 64 ? 4 : COUT_S <= 96 ? 3 
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         if constexpr (FQ)
-                            d[gq] = pack4(requant_shr(acc2[4 * gq], a.n2, half2, 0u, 0, 255), requant_shr(acc2[4 * gq + 1], a.n2, half2, 0u, 0, 255),
-                                          requant_shr(acc2[4 * gq + 2], a.n2, half2, 0u, 0, 255), requant_shr(acc2[4 * gq + 3], a.n2, half2, 0u, 0, 255)) ^ 0x80808080u;
+                            d[gq] = requant_u8x4(acc2[4 * gq], acc2[4 * gq + 1], acc2[4 * gq + 2], acc2[4 * gq + 3], sc2) ^ 0x80808080u;
                         else
                             d[gq] = pack4(requant1(max(acc2[4 * gq], floor_b), a.n2, a.lo2, a.hi2), requant1(max(acc2[4 * gq + 1], floor_b), a.n2, a.lo2, a.hi2),
                                           requant1(max(acc2[4 * gq + 2], floor_b), a.n2, a.lo2, a.hi2), requant1(max(acc2[4 * gq + 3], floor_b), a.n2, a.lo2, a.hi2)) ^ a.xor2;
@@ -475,7 +472,7 @@ hipError_t launch_fused_ir(const IRArgs& a0, int cinS, int coutS, hipStream_t s)
     int lds = 0;
     if (!ir_layout(cinS, coutS, a.H, a.W, a.stride, a.R, a.G, &a, &lds)) return hipErrorInvalidValue;
     // FQ: ReLU + right shift into unsigned 8-bit after the expand AND the depthwise conv (the VALU depthwise path keeps its general epilogue)
-    const bool fq = a.relu_a && a.relu_b && a.n1 > 0 && a.n2 > 0 && a.lo1 == 0 && a.lo2 == 0 && a.hi1 == 255 && a.hi2 == 255 &&
+    const bool fq = a.acc_ok && a.relu_a && a.relu_b && a.n1 > 0 && a.n2 > 0 && a.n1 <= kRequantU8MaxShift && a.n2 <= kRequantU8MaxShift && a.lo1 == 0 && a.lo2 == 0 && a.hi1 == 255 && a.hi2 == 255 &&
                     a.xor1 == 0x80808080u && a.xor2 == 0x80808080u && coutS <= 96;
 #define F8_IR(C_, O_) if (cinS == C_ && coutS == O_) return fq ? launch_ir_t<C_, O_, true>(a, lds, s) : launch_ir_t<C_, O_, false>(a, lds, s);
     F8_IR(32, 32) F8_IR(32, 64) F8_IR(64, 64) F8_IR(64, 96) F8_IR(96, 96) F8_IR(96, 160) F8_IR(160, 160) F8_IR(160, 320)

@@ -69,6 +69,7 @@ struct Node {
     int kind; int a = -1, b = -1; int out = -1;
     f8_conv_desc cd{};                 // conv / linear (as 1x1 conv)
     std::vector<int8_t> w; std::vector<int32_t> bias;   // raw OIHW int8 + bias
+    mutable int acc_ok = -1;           // conv_acc_bounded(), cached
     int relu = 0;                      // add
     int pk = 0, pstride = 0, ppad = 0; // maxpool
     int shift = 0;                     // avgpool
@@ -179,6 +180,27 @@ int new_tensor(f8_net* net, int C, int H, int W, int fl, int prod) {
     Tensor t; t.C = C; t.H = H; t.W = W; t.Cs = round_up(C, 32); t.fl = fl; t.prod = prod;
     net->tensors.push_back(t);
     return (int)net->tensors.size() - 1;
+}
+
+// Is every accumulator of this conv provably below 2^31 - 2^16 in magnitude?  |sum w x + b| <= sum |w| * max |x| + |b| with the 8-bit input
+// range (255 unsigned / raw, 127 signed).  Then `v + 2^(n-1)` of the reference's int32 arithmetic (fix_quant_ops.py:100-104) cannot wrap for
+// n <= 16 and the three-operation float requantisation (requant_u8x4, f8_device.h) is the same function; real nets are 10^2 - 10^3 below
+// the limit, a net that is not keeps the integer form (generic kernel instances).  Cached per node.
+static bool conv_acc_bounded(const Node& nd) {
+    if (nd.acc_ok >= 0) return nd.acc_ok != 0;
+    bool ok = nd.cd.cout > 0 && !nd.w.empty() && nd.w.size() % (size_t)nd.cd.cout == 0;
+    if (ok) {
+        const size_t per = nd.w.size() / (size_t)nd.cd.cout;
+        const int64_t xmax = (nd.cd.quant_input && nd.cd.input_signed) ? 127 : 255, limit = (int64_t(1) << 31) - (int64_t(1) << 16) - 1;
+        for (int o = 0; o < nd.cd.cout && ok; ++o) {
+            int64_t s = 0;
+            for (size_t k = 0; k < per; ++k) { const int v = nd.w[(size_t)o * per + k]; s += v < 0 ? -v : v; }
+            const int64_t b = o < (int)nd.bias.size() ? (int64_t)nd.bias[o] : 0;
+            if (s * xmax + (b < 0 ? -b : b) > limit) ok = false;
+        }
+    }
+    nd.acc_ok = ok ? 1 : 0;
+    return ok;
 }
 
 // shift / clamp of a consumer's int_op_only_fix_quant; validates what the reference asserts
@@ -721,9 +743,9 @@ static void label_conv_step(f8_net* net, Step& st, const Node& nd) {
     st.name = buf;
     if (nd.depthwise) {
         const Tensor& od = net->tensors[nd.out];         // keep in sync with launch_dwconv / dwconv_mma_supported / launch_dwconv_mma (FQ)
-        bool fq = d.relu;
+        bool fq = d.relu && conv_acc_bounded(nd);
         int n8 = 0;
-        for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) { const Form& F = od.forms[st.out.f8[k]]; ++n8; if (!(F.n > 0 && !F.sgn)) fq = false; }
+        for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) { const Form& F = od.forms[st.out.f8[k]]; ++n8; if (!(F.n > 0 && F.n <= 16 && !F.sgn)) fq = false; }
         const bool mma = net->opt.dw_mma && st.out.f32 < 0 && n8 > 0 && d.pad == 1 && (d.stride == 1 || d.stride == 2) && (od.W >= 28 || od.W == 14) &&
                          (d.stride == 1 ? (od.H == s.H && od.W == s.W) : (s.H == 2 * od.H && s.W == 2 * od.W));
         if (mma) snprintf(buf, sizeof buf, "f8::dwconv3x3_mma_kernel<%d, %s, %d>", d.stride, fq ? "true" : "false", od.W >= 28 ? 1 : 2);
@@ -1067,7 +1089,8 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         if (x.prod < 0 || ND[x.prod].kind != N_INPUT || x.consumers.size() != 1 || !(!h.cd.quant_input || x.fl == h.cd.input_fl)) continue;
         if (!head2_supported(x.H, x.W) || ta.H * 2 != x.H || ta.W * 2 != x.W) continue;
         int na = 0, nb2 = 0;
-        if (consumer_format(ta, b.cd, &na, "finalize") || consumer_format(tb, c.cd, &nb2, "finalize") || na < 1 || nb2 < 1) continue;
+        if (consumer_format(ta, b.cd, &na, "finalize") || consumer_format(tb, c.cd, &nb2, "finalize") || na < 1 || nb2 < 1 || na > 16 || nb2 > 16 ||
+            !conv_acc_bounded(h) || !conv_acc_bounded(b) || !conv_acc_bounded(c)) continue;   // 16: kRequantU8MaxShift; bounded: requant_u8x4 (f8_device.h)
         bool int8_readers = !T[c.out].consumers.empty() && T[c.out].consumers.size() <= 2;
         for (int u : T[c.out].consumers) if (ND[u].kind != N_CONV || !ND[u].cd.quant_input) int8_readers = false;
         if (!int8_readers) continue;
@@ -1440,7 +1463,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     {   // keep in sync with launch_fused_ir (FQ) and f8_ir.hip (P2MMA)
                         int n1 = 0, n2 = 0;
                         consumer_format(T[nb.a], nb.cd, &n1, "finalize"); consumer_format(T[nd.a], nd.cd, &n2, "finalize");
-                        const bool fq = na.cd.relu && nb.cd.relu && !nb.cd.input_signed && !nd.cd.input_signed && n1 > 0 && n2 > 0 && nd.coutP <= 96;
+                        const bool fq = na.cd.relu && nb.cd.relu && !nb.cd.input_signed && !nd.cd.input_signed && n1 > 0 && n2 > 0 && n1 <= 16 && n2 <= 16 && nd.coutP <= 96 && conv_acc_bounded(na) && conv_acc_bounded(nb);
                         snprintf(kb, sizeof kb, "f8::fused_ir_kernel<%d, %d, %s, %s, %d>", x.Cs, nd.coutP, fq ? "true" : "false", nd.coutP <= 96 ? "true" : "false", nd.coutP <= 96 ? 8 : 4);
                     }
                     st.kernel = kb;
@@ -1953,6 +1976,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             a.N = N; a.Hp = sF.Hp; a.Wp = sF.Wp; a.org = sF.pad - hh.cd.pad;
             a.Pc = oT.H; a.Qc = oT.W; a.P = oT.H; a.Q = oT.W;
             a.relu0 = 1; a.grid_div = net->opt.stem_grid_div;
+            a.acc_ok = conv_acc_bounded(hh) && conv_acc_bounded(hb) && conv_acc_bounded(nd);
             a.rC = sT.C; a.rH = sT.H; a.rW = sT.W; a.xor8 = sF.sgn ? 0u : 0x80808080u;
             a.raw_kind = -1;
             if (st.raw_input && !(net->in_u8 && net->in_u8_nhwc)) {
@@ -1979,6 +2003,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             a.N = N; a.Hp = sF.Hp; a.Wp = sF.Wp; a.org = sF.pad - nd.cd.pad;
             a.Pc = cT.H; a.Qc = cT.W; a.P = oT.H; a.Q = oT.W;
             a.relu0 = st.relu0; a.wpc = net->opt.stem_wpc; a.rows = net->opt.stem_rows; a.grid_div = net->opt.stem_grid_div;
+            a.acc_ok = conv_acc_bounded(nd);
             a.raw_kind = -1;
             if (st.raw_input && !(net->in_u8 && net->in_u8_nhwc)) {
                 const size_t img = (size_t)sT.C * sT.H * sT.W;
@@ -2069,6 +2094,8 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
                 fmt(nb, T[nb.a], &B.n1, &B.lo1, &B.hi1, &B.xor1);
                 fmt(ng, T[ng.a], &B.n2, &B.lo2, &B.hi2, &B.xor2);
                 B.relu_a = na.cd.relu; B.relu_b = nb.cd.relu; B.relu1 = net->nodes[hh.fused_add].relu;
+                if (k == 0) a.acc_ok = 1;
+                a.acc_ok = a.acc_ok && conv_acc_bounded(na) && conv_acc_bounded(nb);
                 // identity: (body.4 << acc_shl) + (block input << res_shl); opening block: (shortcut << acc_shl) + (body.4 << res_shl)
                 const int dfl = T[hh.out].fl - (hds ? T[ng.out].fl : xin.fl);
                 B.acc_shl = dfl < 0 ? -dfl : 0; B.res_shl = dfl > 0 ? dfl : 0;
@@ -2111,6 +2138,8 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
                 fmt(c1, xin, &B.nq, &B.loq, &B.hiq, &B.xorq);
                 fmt(c2, T[c2.a], &B.n1, &B.lo1, &B.hi1, &B.xor1);
                 B.relu_a = c1.cd.relu; B.relu1 = net->nodes[hk.fused_add].relu;
+                if (k == 0) a.acc_ok = 1;
+                a.acc_ok = a.acc_ok && conv_acc_bounded(c1);
                 // identity: (second conv << acc_shl) + (block input << res_shl); opening block: (second conv << acc_shl) + (shortcut << res_shl)
                 const int dfl = T[c2.out].fl - (hds ? T[hk.out].fl : xin.fl);
                 B.acc_shl = dfl < 0 ? -dfl : 0; B.res_shl = dfl > 0 ? dfl : 0;
@@ -2167,6 +2196,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             fmt(nb, T[nb.a], &a.n1, &a.lo1, &a.hi1, &a.xor1);
             fmt(nd, T[nd.a], &a.n2, &a.lo2, &a.hi2, &a.xor2);
             a.relu_a = na.cd.relu; a.relu_b = nb.cd.relu; a.relu0 = st.relu0;
+            a.acc_ok = conv_acc_bounded(na) && conv_acc_bounded(nb);
             a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1;
             make_magic((uint32_t)x.W, &a.mW, &a.s1W, &a.s2W);
             make_magic((uint32_t)(x.H * x.W), &a.mHW, &a.s1HW, &a.s2HW);
@@ -2183,7 +2213,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             a.x = (const int8_t*)fp(sF); a.w = (const int8_t*)(net->d_w + nd.w_off); a.bias = (const int32_t*)(net->d_w + nd.b_off);
             a.w4 = (const int8_t*)(net->d_w + nd.rc_off); a.bias4 = (const int32_t*)(net->d_w + nd.cc_off);
             a.N = N; a.H = sT.H; a.W = sT.W; a.P = oT.H; a.Q = oT.W; a.Cs = sT.Cs; a.stride = nd.cd.stride; a.pad = nd.cd.pad;
-            a.in_signed = nd.cd.input_signed; a.relu0 = st.relu0; a.use_dot4 = net->opt.dw_dot4; a.use_mma = net->opt.dw_mma;
+            a.in_signed = nd.cd.input_signed; a.relu0 = st.relu0; a.use_dot4 = net->opt.dw_dot4; a.use_mma = net->opt.dw_mma; a.acc_ok = conv_acc_bounded(nd);
             fill_out(&a.out32, a.q);
             e = launch_dwconv(a, s);
             break;

@@ -277,9 +277,13 @@ __device__ __forceinline__ int dpp_next_lane(int v) {   // lane i <- lane i + 1 
     return __builtin_amdgcn_update_dpp(v, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
 }
 template <class Y>
-__device__ __forceinline__ v4i stem_quant16(const Y& y, int n, int lo, int hi, unsigned x_or) {
+__device__ __forceinline__ v4i stem_quant16(const Y& y, int n, int lo, int hi, unsigned x_or, bool acc_ok) {
     unsigned d[4];
-    if (n > 0) {                                     // the usual case, a right shift: four VALU operations per value (wave-uniform branch)
+    if (acc_ok && n > 0 && n <= kRequantU8MaxShift && lo == 0 && hi == 255) {   // the usual case: unsigned 8-bit, three VALU operations per value (wave-uniform branch)
+        const float sc = requant_u8_scale(n);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) d[g] = requant_u8x4(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], sc) ^ x_or;
+    } else if (n > 0) {                              // another right shift: four
         const unsigned hf = 1u << (n - 1);
 #pragma unroll
         for (int g = 0; g < 4; ++g) d[g] = pack4(requant_shr(y[4 * g], n, hf, 0u, lo, hi), requant_shr(y[4 * g + 1], n, hf, 0u, lo, hi),
@@ -463,7 +467,7 @@ __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))
         }
         const v4i w1f = *(const v4i*)(a.w1 + l31 * 32 + lh * 16);
         const char* const bl = lds + 2 * PBUF + 16 * lh;            // head | depthwise | 1x1 biases, 32 ints each
-        const unsigned halfa = 1u << (a.na - 1), halfb = 1u << (a.nb - 1);
+        const float sca = requant_u8_scale(a.na), scb = requant_u8_scale(a.nb);
         const v4i zq = {(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u};
         auto bias_acc = [&](int which) {
             v16i acc;
@@ -475,12 +479,10 @@ __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))
             }
             return acc;
         };
-        auto quant_row = [&](const v16i& acc, int n, unsigned hf) {  // ReLU + right shift into unsigned 8-bit, 16 channels per lane half
+        auto quant_row = [&](const v16i& acc, float sc) {  // ReLU + right shift (1 .. 16) into unsigned 8-bit, 16 channels per lane half
             unsigned dd[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                dd[g] = pack4(requant_shr(acc[4 * g], n, hf, 0u, 0, 255), requant_shr(acc[4 * g + 1], n, hf, 0u, 0, 255),
-                              requant_shr(acc[4 * g + 2], n, hf, 0u, 0, 255), requant_shr(acc[4 * g + 3], n, hf, 0u, 0, 255)) ^ 0x80808080u;
+            for (int g = 0; g < 4; ++g) dd[g] = requant_u8x4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], sc) ^ 0x80808080u;
             auto s0 = __builtin_amdgcn_permlane32_swap(dd[0], dd[2], false, false);
             auto s1 = __builtin_amdgcn_permlane32_swap(dd[1], dd[3], false, false);
             return v4i{(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
@@ -500,7 +502,7 @@ __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))
                     v16i acc = bias_acc(0);
                     acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wh0, v4i{a0.x, a0.y, a1.x, a1.y}, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wh1, v4i{b0.x, b0.y, b1.x, b1.y}, acc, 0, 0, 0);
-                    x = quant_row(acc, a.na, halfa);
+                    x = quant_row(acc, sca);
                     if (!cq_in) x = zq;
                 }
                 R.f[0] = x;
@@ -524,14 +526,14 @@ __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))
                     for (int kx = 0; kx < 3; ++kx) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wd[3 + kx], R1.f[kx], acc, 0, 0, 0);
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wd[6 + kx], R2.f[kx], acc, 0, 0, 0);
-                    const v4i xb = quant_row(acc, a.nb, halfb);
+                    const v4i xb = quant_row(acc, scb);
                     v16i acc1 = bias_acc(2);
                     acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1f, xb, acc1, 0, 0, 0);
                     const size_t m = ((size_t)B.n * a.P + P) * a.Q + (lane_out ? col : 0);
 #pragma unroll
                     for (int k = 0; k < 2; ++k)
                         if (a.q[k].ptr) {
-                            const v4i v = stem_quant16(acc1, a.q[k].n, a.q[k].lo, a.q[k].hi, a.q[k].bias_xor);
+                            const v4i v = stem_quant16(acc1, a.q[k].n, a.q[k].lo, a.q[k].hi, a.q[k].bias_xor, true);
                             if (lane_out) *(v4i*)(a.q[k].ptr + m * 32 + lh * 16) = v;
                         }
                     R0 = R1; R1 = R2;
@@ -616,7 +618,7 @@ __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
                     if (a.q[k].ptr) {
-                        const v4i v = stem_quant16(pm, a.q[k].n, a.q[k].lo, a.q[k].hi, a.q[k].bias_xor);
+                        const v4i v = stem_quant16(pm, a.q[k].n, a.q[k].lo, a.q[k].hi, a.q[k].bias_xor, a.acc_ok != 0);
                         if (lane_out) *(v4i*)(a.q[k].ptr + (size_t)m * 64 + half * 32 + lh * 16) = v;
                     }
             }
@@ -645,7 +647,7 @@ bool head2_supported(int H, int W) { return H >= 8 && W >= 8 && H % 4 == 0 && W 
 
 hipError_t launch_stem_pool(const StemPoolArgs& a, hipStream_t s) {
     if (a.h2) {
-        if (!head2_supported(a.rH, a.rW) || a.P != a.rH / 2 || a.Q != a.rW / 2 || a.Pc != a.P || a.Qc != a.Q || a.na < 1 || a.nb < 1 || a.out32 ||
+        if (!head2_supported(a.rH, a.rW) || a.P != a.rH / 2 || a.Q != a.rW / 2 || a.Pc != a.P || a.Qc != a.Q || a.na < 1 || a.nb < 1 || a.na > kRequantU8MaxShift || a.nb > kRequantU8MaxShift || !a.acc_ok || a.out32 ||
             (a.raw_kind < 0 && !(a.org == 4 && a.Wp % 4 == 0))) return hipErrorInvalidValue;
         const int lds_bytes = 2 * RB_ROWS * (a.rW + 8) * 4 + 512 + 1536;
         static int ncu3 = 0;

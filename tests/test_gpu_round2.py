@@ -393,3 +393,32 @@ def test_graph_switched_on_after_the_first_runs(dev):
         net.run(xd, out=out)
         assert np.array_equal(other.run(xd).cpu().numpy(), want)
         assert np.array_equal(out.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('big', [False, True], ids=['bounded', 'bias_near_2^31'])
+def test_depthwise_requant_where_the_rounding_add_wraps(dev, big):
+    """The float requantisation (requant_u8x4) is only selected for convs whose accumulators are provably below 2^31 - 2^16
+    (f8_net.cpp conv_acc_bounded).  With a bias next to 2^31 the reference's `v + 2^(n-1)` wraps in int32 (fix_quant_ops.py:100-104:
+    the value turns negative, the clamp makes it 0); the library must keep the integer form there — and give the oracle's values."""
+    from f8net_amd.net import F8Net
+    N, C, H = 2, 32, 28
+    x = synth.rand_uniform_int(81, 'wrapx', (N, C, H, H), 0, 255).astype(np.int32)
+    w = np.clip(synth.rand_normal_int(82, 'wrapw', (C, 1, 3, 3), 40.0), -127, 127).astype(np.int32)
+    b = synth.rand_normal_int(83, 'wrapb', (C,), 2.0 ** 9).astype(np.int32)
+    if big:
+        b[3], b[17] = 2 ** 31 - 50, 2 ** 31 - 2 ** 14        # accumulators within 2^(n-1) of 2^31: the rounding add wraps
+    w2 = np.clip(synth.rand_normal_int(84, 'wrapw2', (32, C, 1, 1), 30.0), -127, 127).astype(np.int32)
+    in_fl, w_fl, nfl = 8, 5, 4                                # shift 9
+    net = F8Net()
+    t = net.input(C, H, H, in_fl)
+    c = net.conv(t, w, b, stride=1, pad=1, groups=C, weight_fl=w_fl, input_fl=in_fl, input_signed=False, quant_input=False, relu=True)
+    o = net.conv(c, w2, None, stride=1, pad=0, groups=1, weight_fl=6, input_fl=nfl, input_signed=False, quant_input=True, relu=False)
+    net.output(o, as_float=False)
+    net.finalize(N)
+    y = oracle.relu(oracle.conv2d(x, w, b, 1, 1, C))
+    q = oracle.requant(y, nfl, in_fl + w_fl, False)
+    if big:
+        assert (y[:, 3] > 2 ** 31 - 2 ** 8).any() and (q[:, 3] == 0).any()       # the wrap really happens in the oracle
+    want = oracle.conv2d(q, w2, np.zeros(32, np.int32), 1, 0)
+    got = net.run(_t(x, dev)).cpu().numpy().reshape(N, 32, H, H)
+    np.testing.assert_array_equal(got, want)
