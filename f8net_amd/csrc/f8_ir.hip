@@ -50,7 +50,8 @@ __global__ void __launch_bounds__(NW * 64, (COUT_S <= 64 ? 4 : COUT_S <= 96 ? 3 
     constexpr int W0_L = (W0_SLOTS + NT - 1) / NT, W4_L = (W4_SLOTS + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const X = lds;                                   // [KK1][xp][32 B]
-    char* const patch = lds + a.off_patch;                 // [G][PR][PW][64 B]
+    char* const patch = lds + a.off_patch;                 // [2][G][PR][PW][32 B]: channel-tile planes, so that a wave's fragment read (one
+                                                           // 32-channel tile of 32 pixels) is 1 KB contiguous — at [px][64 B] it used half of every bank row
     char* const mid2 = lds + a.off_mid2;                   // [2][NW * 32][32 B]
     char* const wbuf = lds + a.off_w;                      // 2 x { W0 [KK1][64][32] | W4 [2][COUT_S][32] | dw 576 B (+64 pad) | dw bias 256 B | b0 256 B }
     constexpr int OFF_W4 = W0_BYTES, OFF_DW = OFF_W4 + W4_BYTES, OFF_DWB = OFF_DW + 640, OFF_B0 = OFF_DWB + 256, WBUF = OFF_B0 + 256;
@@ -62,6 +63,7 @@ __global__ void __launch_bounds__(NW * 64, (COUT_S <= 64 ? 4 : COUT_S <= 96 ? 3 
     auto my_j = [&](int j) { return !SPLIT || (ch == 0 ? j < JSPLIT : j >= JSPLIT); };
     const int s = a.stride, R = a.R, W = a.W, H = a.H, Wo = a.Wo, PW = W + 2;
     const int PR = (R - 1) * s + 3;
+    const int pct = a.G * PR * PW * 32;                    // bytes of one 32-channel plane of the patch
     int t;
     {   // XCD-aware order: vertically adjacent row tiles share their halo rows in one XCD's L2
         const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
@@ -218,7 +220,7 @@ __global__ void __launch_bounds__(NW * 64, (COUT_S <= 64 ? 4 : COUT_S <= 96 ? 3 
                 auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
                 if (ok) {
                     const v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
-                    *(v4i*)(patch + (size_t)ent * 64 + i * 32 + lh * 16) = o;
+                    *(v4i*)(patch + (size_t)i * pct + (size_t)ent * 32 + lh * 16) = o;
                 }
             }
         }
@@ -253,7 +255,7 @@ __global__ void __launch_bounds__(NW * 64, (COUT_S <= 64 ? 4 : COUT_S <= 96 ? 3 
                     const bool ok2 = op < OUT_PX;
                     int g, orow, ocol;
                     split_out(ok2 ? op : 0, g, orow, ocol);
-                    const char* pp = patch + ((size_t)((g * PR + orow * s) * PW + ocol * s)) * 64 + ctd * 32 + lh * 16;
+                    const char* pp = patch + (size_t)ctd * pct + ((size_t)((g * PR + orow * s) * PW + ocol * s)) * 32 + lh * 16;
                     v16i acc2;
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
@@ -263,7 +265,7 @@ __global__ void __launch_bounds__(NW * 64, (COUT_S <= 64 ? 4 : COUT_S <= 96 ? 3 
                     }
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
-                        const v4i xf = *(const v4i*)(pp + ((t / 3) * PW + t % 3) * 64);
+                        const v4i xf = *(const v4i*)(pp + ((t / 3) * PW + t % 3) * 32);
                         acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wa[t], xf, acc2, 0, 0, 0);
                     }
                     unsigned d[4];
@@ -290,12 +292,12 @@ __global__ void __launch_bounds__(NW * 64, (COUT_S <= 64 ? 4 : COUT_S <= 96 ? 3 
             if (cg >= nct * 2) continue;
             int g, orow, ocol;
             split_out(op, g, orow, ocol);
-            const char* pp = patch + ((size_t)((g * PR + orow * s) * PW + ocol * s)) * 64 + cg * 16;
+            const char* pp = patch + (size_t)(cg >> 1) * pct + ((size_t)((g * PR + orow * s) * PW + ocol * s)) * 32 + (cg & 1) * 16;
             v4i xw[3][3];
 #pragma unroll
             for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-                for (int cc = 0; cc < 3; ++cc) xw[rr][cc] = *(const v4i*)(pp + (rr * PW + cc) * 64);
+                for (int cc = 0; cc < 3; ++cc) xw[rr][cc] = *(const v4i*)(pp + (rr * PW + cc) * 32);
             unsigned outw[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {                  // 4-channel quad inside the 16
