@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))
         // The three convs run on ONE register file per wave, row by row, with nothing but the input patch in LDS:
         //   * head conv 3x3 / 2 (`ref:models/fix_mobilenet_v2.py` head: 3 -> 32, ReLU): lane l <-> conv column c0 - 1 + l; a kernel row is
         //     16 bytes (4 pixels x 4 channels, the 4th pixel's weights are zero), two kernel rows make one 32-byte K step: TWO MFMAs
-        //     per conv row; requantised (5 operations) and turned by the permlane swap into 16 channels per lane half — which IS the
+        //     per conv row; requantised (3 operations, requant_u8x4) and turned by the permlane swap into 16 channels per lane half — which IS the
         //     B operand of a K = 32-channel MFMA step;
         //   * depthwise 3x3 (ReLU): nine MFMAs with diagonal weight fragments (f8_dwmma.hip); horizontal taps = the conv row fragment and
         //     two DPP lane shifts of it, vertical taps = the last three conv rows, sliding; its padding (conv column -1 / 112, conv row
