@@ -40,17 +40,20 @@ struct BChainCfg {
     static_assert(ROWB / 16 <= 256 && (size_t)256 * 4 * ROWB <= kChainXchgBytes, "one 16-byte piece of a halo row per thread of a half workgroup");
 };
 
-template <bool FAST, bool ACC = false, class Y>
+// FAST: 0 generic, 1 float-converter requantisation, 2 integer requantisation (f8_chain.hip: quant_tile16)
+template <int FAST, bool ACC = false, class Y>
 __device__ __forceinline__ v4i bquant_tile16(const Y& y, int n, int lo, int hi, unsigned x_or) {
     unsigned d[4];
     // FAST: lo == 0, hi == 255, 1 <= n <= 16.  ACC: y is a conv accumulator (bounded: BChainArgs::acc_ok) -> 3 operations per value (f8_device.h);
     // the stream can hold any int32, its `v + 2^(n-1)` may wrap like the reference's: the 4-operation float form (no packing operations)
-    const float sc = FAST ? requant_u8_scale(n) : 0.0f;
+    const float sc = FAST == 1 ? requant_u8_scale(n) : 0.0f;
     const unsigned half = FAST ? (1u << (n - 1)) : 0u;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        if constexpr (FAST && !ACC) d[g] = requant_u8x4_wrap(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], sc, half) ^ x_or;
-        else if constexpr (FAST) d[g] = requant_u8x4(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], sc) ^ x_or;
+        if constexpr (FAST == 1 && !ACC) d[g] = requant_u8x4_wrap(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], sc, half) ^ x_or;
+        else if constexpr (FAST == 1) d[g] = requant_u8x4(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], sc) ^ x_or;
+        else if constexpr (FAST == 2) d[g] = pack4(requant_shr(y[4 * g], n, half, 0u, 0, 255), requant_shr(y[4 * g + 1], n, half, 0u, 0, 255),
+                                                   requant_shr(y[4 * g + 2], n, half, 0u, 0, 255), requant_shr(y[4 * g + 3], n, half, 0u, 0, 255)) ^ x_or;
         else d[g] = pack4(requant1(y[4 * g], n, lo, hi), requant1(y[4 * g + 1], n, lo, hi), requant1(y[4 * g + 2], n, lo, hi), requant1(y[4 * g + 3], n, lo, hi)) ^ x_or;
     }
     auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
@@ -62,7 +65,7 @@ __device__ __forceinline__ int bopaque(int v) { asm volatile("" : "+s"(v)); retu
 
 // FAST: ReLU after the first conv and after the join, every int8 format of the chain unsigned with a right shift, the stream never shifted
 // DS: the chain starts with the stage-opening block (3x3 / 2 -> 3x3, 1x1 / 2 shortcut; C / 2 input channels at twice the resolution)
-template <int C, int W, int H, int R, int NB, int NBUF, bool FAST, bool DS>
+template <int C, int W, int H, int R, int NB, int NBUF, int FAST, bool DS>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 bchain_kernel(const BChainArgs a) {
     using Cfg = BChainCfg<C, W, H, R, DS>;
@@ -119,10 +122,14 @@ bchain_kernel(const BChainArgs a) {
     v16i res[NPW];                                              // the stream: this wave's channel tile x its pixel tiles (a missing tile repeats the last one)
     v4i wbuf[NBUF][NB];
     unsigned seq = 0;
-    bool failed = false;
 
 #ifndef F8_BCH_ABL_NOW
-    auto ldw = [](const int8_t* base, int soff, unsigned voff) { return *(const v4i*)(base + bopaque(soff) + voff); };
+    // buffer loads: scalar step offset in soffset, ONE per-lane offset register (f8_chain.hip: as flat loads the optimiser hoisted 64-bit
+    // address pairs per stream and added two 64-bit vector adds per load)
+    auto ldw = [](const int8_t* base, int soff, unsigned voff) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7ffffff0, 0x00020000);
+        return __builtin_amdgcn_raw_buffer_load_b128(r, voff, bopaque(soff), 0);
+    };
 #else
     auto ldw = [](const int8_t* base, int soff, unsigned voff) { const int q = (int)(size_t)base + soff + (int)voff; const v4i r = {q, q, q, q}; return r; };
 #endif
@@ -175,14 +182,16 @@ bchain_kernel(const BChainArgs a) {
                 unsigned* const f = flags + (t2 == 0 ? L - 1 : L + 1);
                 const unsigned long long t0 = wall_clock64();
                 bool ok = true;
+                // a neighbour that never arrives: the sticky error word is set and the launch runs on WITHOUT waiting any more, here and in
+                // every other workgroup (they see the word in their own polls) — no second exit from the block loop (f8_chain.hip)
                 while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
                     __builtin_amdgcn_s_sleep(1);
                     if (wall_clock64() - t0 > t_limit) { ok = false; break; }
+                    if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
                 }
-                if (!ok) { misc[1] = 1; __hip_atomic_store(a.err, 0x200u + (unsigned)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                if (!ok) __hip_atomic_store(a.err, 0x200u + (unsigned)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
-            if (misc[1]) failed = true;
             const int side = t2 >> 8, idx = t2 & 255;
             if (idx < RCH && (side == 0 ? has_up : has_dn)) {
                 const __amdgpu_buffer_rsrc_t rxc = __builtin_amdgcn_make_buffer_rsrc((void*)a.xchg, 0, (unsigned)kChainXchgBytes, 0x00020000);
@@ -432,7 +441,6 @@ bchain_kernel(const BChainArgs a) {
                 }
             }
             __syncthreads();                                    // patchX interior is complete; patchM may be zeroed again
-            if (failed) return;                                 // a neighbour never arrived (uniform: misc[1] is shared)
             if (!last) publish(patchX);
             F8_BT(2);
         }
@@ -470,19 +478,25 @@ bool bchain_supported(int C, int H, int W) { return bchain_rows(C, H, W) > 0; }
 bool bchain_ds_supported(int C, int H, int W) { return bchain_rows(C, H, W) > 0 && C >= 128; }
 int bchain_tiles_per_img(int C, int H, int W) { const int r = bchain_rows(C, H, W); return r ? (H + r - 1) / r : 0; }
 
-bool bchain_fast(const BChainArgs& a) {
-    if (!a.acc_ok) return false;
+// 0 = generic instance, 1 = constant formats + float-converter requantisation, 2 = constant formats + integer requantisation (f8_chain.hip: chain_fast)
+int bchain_fast(const BChainArgs& a) {
+    bool f16 = true;
     for (int k = 0; k < a.nblk; ++k) {
         const BChainBlk& B = a.blk[k];
-        if (!(B.relu_a && B.relu1 && B.n1 > 0 && B.n1 <= kRequantU8MaxShift && B.lo1 == 0)) return false;
+        if (!(B.relu_a && B.relu1 && B.n1 > 0 && B.n1 <= 30 && B.lo1 == 0)) return 0;
+        f16 = f16 && B.n1 <= kRequantU8MaxShift;
         if (k == 0 && a.x8in) continue;                      // opening block: its input arrives as int8, its join shifts either operand
-        if (!(B.nq > 0 && B.nq <= kRequantU8MaxShift && B.loq == 0 && B.res_shl == 0)) return false;
+        if (!(B.nq > 0 && B.nq <= 30 && B.loq == 0 && B.res_shl == 0)) return 0;
+        f16 = f16 && B.nq <= kRequantU8MaxShift;
     }
-    if (a.q[0].ptr && !(a.q[0].n > 0 && a.q[0].n <= kRequantU8MaxShift && a.q[0].lo == 0)) return false;
-    return true;
+    if (a.q[0].ptr) {
+        if (!(a.q[0].n > 0 && a.q[0].n <= 30 && a.q[0].lo == 0)) return 0;
+        f16 = f16 && a.q[0].n <= kRequantU8MaxShift;
+    }
+    return (a.rq_int || !a.acc_ok || !f16) ? 2 : 1;
 }
 
-template <int C, int W, int H, int R, int NB, int NBUF, bool FAST, bool DS>
+template <int C, int W, int H, int R, int NB, int NBUF, int FAST, bool DS>
 static hipError_t launch_bchain_t(const BChainArgs& a, hipStream_t s) {
     using Cfg = BChainCfg<C, W, H, R, DS>;
     static unsigned long long attr_done = 0; int attr_dev = -1;
@@ -529,11 +543,11 @@ static hipError_t launch_bchain_t(const BChainArgs& a, hipStream_t s) {
 #endif
 hipError_t launch_bchain(const BChainArgs& a, int C, int H, int W, hipStream_t s) {
     if (a.nblk < 1 || a.nblk > kBChainMaxBlocks) return hipErrorInvalidValue;
-    const bool fast = bchain_fast(a);
+    const int fast = bchain_fast(a);
     const bool ds = a.x8in != nullptr;
     if (ds ? !(a.x8sc && a.wsc && a.bsc && bchain_ds_supported(C, H, W)) : !a.xr) return hipErrorInvalidValue;
-#define F8_BCH(...) (fast ? launch_bchain_t<__VA_ARGS__, true, false>(a, s) : launch_bchain_t<__VA_ARGS__, false, false>(a, s))
-#define F8_BCHD(...) (fast ? launch_bchain_t<__VA_ARGS__, true, true>(a, s) : launch_bchain_t<__VA_ARGS__, false, true>(a, s))
+#define F8_BCH(...) (fast == 1 ? launch_bchain_t<__VA_ARGS__, 1, false>(a, s) : fast == 2 ? launch_bchain_t<__VA_ARGS__, 2, false>(a, s) : launch_bchain_t<__VA_ARGS__, 0, false>(a, s))
+#define F8_BCHD(...) (fast == 1 ? launch_bchain_t<__VA_ARGS__, 1, true>(a, s) : fast == 2 ? launch_bchain_t<__VA_ARGS__, 2, true>(a, s) : launch_bchain_t<__VA_ARGS__, 0, true>(a, s))
     if (C == 64 && H == 56 && W == 56) return F8_BCH(64, 56, 56, 8, F8_BCH_S0);
     if (C == 128 && H == 28 && W == 28) return ds ? F8_BCHD(128, 28, 28, 7, F8_BCH_S1) : F8_BCH(128, 28, 28, 7, F8_BCH_S1);
     if (C == 256 && H == 14 && W == 14) return ds ? F8_BCHD(256, 14, 14, 7, F8_BCH_S2) : F8_BCH(256, 14, 14, 7, F8_BCH_S2);

@@ -57,18 +57,23 @@ struct ChainCfg {
 
 // 16 accumulator values of one 32x32 tile (this lane: one pixel, channels 8g + 4 lh + e) -> this lane's 16 bytes of the int8 row:
 // channels [16 lh, 16 lh + 16) of the tile (two v_permlane32_swap put a lane's four dwords side by side).
-// FAST: unsigned 8-bit behind a ReLU with 1 <= n <= 16 (3-operation requant, f8_device.h); otherwise either direction, any clamp.
-template <bool FAST, bool ACC = false>
+// FAST: unsigned 8-bit behind a ReLU with a right shift; otherwise either direction, any clamp.  FAST == 1: through the float converter
+// (1 <= n <= 16: 3 / 4 operations per value, f8_device.h; planned unless the handle's option `requant_float` is 0); FAST == 2: the
+// INTEGER form of the same function (requant_shr: v_bfe_u32, v_add3_u32, v_ashrrev_i32, v_med3_i32 + packing — no float instruction;
+// exact for every int32, the reference's wrap included, and any shift).
+template <int FAST, bool ACC = false>
 __device__ __forceinline__ v4i quant_tile16(const v16i& y, int n, int lo, int hi, unsigned x_or) {
     unsigned d[4];
     // FAST: lo == 0, hi == 255, 1 <= n <= 16.  ACC: y is a conv accumulator (bounded: ChainArgs::acc_ok) -> 3 operations per value (f8_device.h);
     // the stream can hold any int32, its `v + 2^(n-1)` may wrap like the reference's: the 4-operation float form (no packing operations)
-    const float sc = FAST ? requant_u8_scale(n) : 0.0f;
+    const float sc = FAST == 1 ? requant_u8_scale(n) : 0.0f;
     const unsigned half = FAST ? (1u << (n - 1)) : 0u;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        if constexpr (FAST && !ACC) d[g] = requant_u8x4_wrap(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], sc, half) ^ x_or;
-        else if constexpr (FAST) d[g] = requant_u8x4(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], sc) ^ x_or;
+        if constexpr (FAST == 1 && !ACC) d[g] = requant_u8x4_wrap(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], sc, half) ^ x_or;
+        else if constexpr (FAST == 1) d[g] = requant_u8x4(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], sc) ^ x_or;
+        else if constexpr (FAST == 2) d[g] = pack4(requant_shr(y[4 * g], n, half, 0u, 0, 255), requant_shr(y[4 * g + 1], n, half, 0u, 0, 255),
+                                                   requant_shr(y[4 * g + 2], n, half, 0u, 0, 255), requant_shr(y[4 * g + 3], n, half, 0u, 0, 255)) ^ x_or;
         else d[g] = pack4(requant1(y[4 * g], n, lo, hi), requant1(y[4 * g + 1], n, lo, hi), requant1(y[4 * g + 2], n, lo, hi), requant1(y[4 * g + 3], n, lo, hi)) ^ x_or;
     }
     auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
@@ -83,7 +88,7 @@ __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+s"(v)); retur
 // FAST: every block has ReLU after body.0 / body.2 / the join, every int8 format of the chain is unsigned with a right shift, and the
 // stream itself is never shifted (res_shl == 0) — true for the real fraclen tables; the generic instance takes everything else.
 // ROT: rotate the K order per (workgroup, wave) in coarse groups (L2-bound instance: all workgroups stream the same weights).
-template <int C, int MID, int W, int H, int R, int CIN0, int NB, int NBUF, bool FAST, bool ROT>
+template <int C, int MID, int W, int H, int R, int CIN0, int NB, int NBUF, int FAST, bool ROT>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 chain_kernel(const ChainArgs a) {
     using Cfg = ChainCfg<C, MID, W, H, R, CIN0>;
@@ -169,7 +174,13 @@ chain_kernel(const ChainArgs a) {
     auto tap_of = [&](int t) { if (!ROT) return t; int q = t + (int)((unsigned)opaque(rot) % 9u); return q >= 9 ? q - 9 : q; };   // body.2: whole taps
     // A-operand loads: uniform base (+ a SCALAR step offset, kept scalar by `opaque`: as a constant it gets folded into a per-step
     // per-lane offset register that is hoisted out of the block loop and spilled) + ONE per-lane offset register per stream
-    auto ldw = [](const int8_t* base, int soff, unsigned voff) { return *(const v4i*)(base + opaque(soff) + voff); };
+    // Round 4: BUFFER loads (resource = the weight pointer, scalar step offset in soffset, the per-lane offset in voffset).  As a flat
+    // `base + soff + voff` the optimiser re-associated to (base + voff) + soff: a hoisted 64-bit VGPR pair per stream plus two 64-bit
+    // vector adds per load — the pairs were what the opening-block instance spilled.
+    auto ldw = [](const int8_t* base, int soff, unsigned voff) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7ffffff0, 0x00020000);
+        return __builtin_amdgcn_raw_buffer_load_b128(r, voff, opaque(soff), 0);
+    };
     auto w1_load = [&](const int8_t* w0, auto nkc, v4i (&dst)[NB], int bi, unsigned wl) {
         constexpr int NK = decltype(nkc)::value;
         const unsigned w1off = (unsigned)(mt * NK * 1024) + wl;
@@ -231,7 +242,8 @@ chain_kernel(const ChainArgs a) {
                     *(v4i*)(x8 + xlane + pt * 32 * XS + (wave * CTW + i) * 32) = quant_tile16<FAST>(res[pt][i], B0.nq, FAST ? 0 : B0.loq, FAST ? 255 : B0.hiq, FAST ? 0x80808080u : B0.xorq);
         } else {
             constexpr int CH = CIN0 / 16;                       // 16-byte chunks per pixel
-            for (int idx = tid; idx < NPT * 32 * CH; idx += 512) {
+            int tq0 = tid; asm volatile("" : "+v"(tq0));         // (nothing derived from the thread id is hoisted out of the image loop: it would spill)
+            for (int idx = tq0; idx < NPT * 32 * CH; idx += 512) {
                 const int row = idx / CH, c16 = idx % CH;
                 v4i v = {0, 0, 0, 0};
                 if (row < npx) v = *(const v4i*)(a.x8in + (size_t)(m_tile + row) * CIN0 + c16 * 16);
@@ -242,11 +254,14 @@ chain_kernel(const ChainArgs a) {
         __syncthreads();
         F8_CT(0);
 
-        for (int b = 0; b < a.nblk; ++b) {
-            ++seq;
-            const ChainBlk& B = a.blk[b];
-            const int* const bl = bias_lds + b * BIAS_INTS;
-            auto block = [&](auto dsc) {
+        // One block of the chain.  The stage-opening block is PEELED off the block loop below: inside the loop the stream registers are
+        // loop-carried, i.e. allocated (though dead) throughout the opening block's P1 / P2 on top of its own live set — round 3's
+        // opening-block instance spilled 144 bytes per lane that way (179 MB of scratch write-back per launch at the counters).
+        auto block = [&](const int b, auto dsc) {
+            {
+                ++seq;
+                const ChainBlk& B = a.blk[b];
+                const int* const bl = bias_lds + b * BIAS_INTS;
                 constexpr bool DSB = decltype(dsc)::value;      // this block is the stage-opening block (first block of a DS0 chain)
                 constexpr int NK1B = DSB ? KS : NK1;
                 constexpr bool ROT1 = ROT && !DSB;
@@ -269,7 +284,7 @@ chain_kernel(const ChainArgs a) {
                     F8_LANES_P12;
                     {   // the whole patch <- biased zero: border columns, rows outside the image; everything else is overwritten below
                         const v4i zv = {(int)xor1, (int)xor1, (int)xor1, (int)xor1};
-                        for (int o = tid * 16; o < Cfg::PATCH_BYTES; o += 512 * 16) *(v4i*)(patch + o) = zv;
+                        for (int o = tq_ * 16; o < Cfg::PATCH_BYTES; o += 512 * 16) *(v4i*)(patch + o) = zv;
                     }
                     v16i acc[NPW];
 #pragma unroll
@@ -332,7 +347,8 @@ chain_kernel(const ChainArgs a) {
                 if constexpr (T > 1) {
                     constexpr int RCH = ROWB / 16, CPE = MID / 16;              // 16-byte pieces per row / per patch entry
                     const __amdgpu_buffer_rsrc_t rxc = __builtin_amdgcn_make_buffer_rsrc((void*)a.xchg, 0, (unsigned)kChainXchgBytes, 0x00020000);
-                    const int side = tid >> 8, idx = tid & 255;                 // threads 0..255: top row / upper neighbour; 256..511: bottom / lower
+                    int th = tid; asm volatile("" : "+v"(th));                   // re-derived per block, not hoisted and spilled
+                    const int side = th >> 8, idx = th & 255;                   // threads 0..255: top row / upper neighbour; 256..511: bottom / lower
                     const bool mine = idx < RCH && (side == 0 ? has_up : has_dn);
                     const int col = idx / CPE, c16 = idx % CPE;
                     const unsigned par = seq & 1u;
@@ -351,15 +367,19 @@ chain_kernel(const ChainArgs a) {
                         unsigned* const f = flags + (tid == 0 ? L - 1 : L + 1);
                         const unsigned long long t0 = wall_clock64();
                         bool ok = true;
+                        // A neighbour that never arrives: the error word is set (sticky; f8_net_check and the logits' poison report it) and the
+                        // launch RUNS ON without waiting any more — here and in every other workgroup, which see the word in their own polls.
+                        // (An early return from the middle of the block loop gave the loop a second exit and the opening-block instance a
+                        // second copy of the 112 stream registers at the loop header: 56 v_mov_b64 per block and its spills.)
                         while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
                             __builtin_amdgcn_s_sleep(2);
                             if (wall_clock64() - t0 > t_limit) { ok = false; break; }
+                            if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
                         }
-                        if (!ok) { misc[1] = 1; __hip_atomic_store(a.err, 0x100u + (unsigned)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                        if (!ok) __hip_atomic_store(a.err, 0x100u + (unsigned)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     F8_CT(12);
                     __syncthreads();
-                    if (misc[1]) return false;                                  // a neighbour never arrived: give up (uniform)
                     if (mine) {
                         const int nb_wg = side == 0 ? L - 1 : L + 1;            // upper neighbour's BOTTOM row / lower neighbour's TOP row
                         const v4i v = __builtin_amdgcn_raw_buffer_load_b128(rxc, (unsigned)(((nb_wg * 2 + (int)par) * 2 + (1 - side)) * ROWB + idx * 16), 0, 17);
@@ -567,18 +587,16 @@ chain_kernel(const ChainArgs a) {
                 }
                 F8_CT(4);
                 __syncthreads();                                // x8 is complete (the next block's P1 reads it); mid2 may be rewritten
-                return true;
-            };
-            bool ok;
-            if constexpr (DS0) { if (b == 0) ok = block(std::true_type{}); else ok = block(std::false_type{}); }
-            else ok = block(std::false_type{});
-            if (!ok) return;
-        }
+            }
+        };
+        if constexpr (DS0) block(0, std::true_type{});
+        for (int b = DS0 ? 1 : 0; b < a.nblk; ++b) block(b, std::false_type{});
 
         // ---- the int8 copy of the stage output: LDS rows -> whole NHWC rows in HBM
         if (a.q[0].ptr) {
             constexpr int CH = C / 16;
-            for (int idx = tid; idx < npx * CH; idx += 512) {
+            int tq1 = tid; asm volatile("" : "+v"(tq1));
+            for (int idx = tq1; idx < npx * CH; idx += 512) {
                 const int row = idx / CH, c16 = idx % CH;
                 const v4i v = *(const v4i*)(x8 + row * XS + c16 * 16);
                 *(v4i*)(a.q[0].ptr + (size_t)(m_tile + row) * C + c16 * 16) = v;
@@ -604,7 +622,7 @@ bool chain_supported(int C, int MID, int H, int W, int cin0) {
 }
 int chain_tiles_per_img(int H, int W) { (void)W; return (H + 3) / 4; }
 
-template <int C, int MID, int W, int H, int R, int CIN0, int NB, int NBUF, bool FAST, bool ROT>
+template <int C, int MID, int W, int H, int R, int CIN0, int NB, int NBUF, int FAST, bool ROT>
 static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t s) {
     using Cfg = ChainCfg<C, MID, W, H, R, CIN0>;
     static unsigned long long attr_done = 0; int attr_dev = -1;
@@ -660,22 +678,27 @@ static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t s) {
 #ifndef F8_CH_S2
 #define F8_CH_S2 2, 4
 #endif
-// FAST instance: see chain_kernel
-bool chain_fast(const ChainArgs& a) {
-    if (!a.acc_ok) return false;
+// FAST instance (see chain_kernel): 0 = generic, 1 = constant formats + float-converter requantisation, 2 = constant formats + integer requantisation
+// (option requant_float = 0, accumulators the planner cannot bound, or a shift beyond the converter form's 16)
+int chain_fast(const ChainArgs& a) {
+    bool f16 = true;
     for (int k = 0; k < a.nblk; ++k) {
         const ChainBlk& B = a.blk[k];
-        if (!(B.relu_a && B.relu_b && B.relu1 && B.n1 > 0 && B.n2 > 0 && B.nq > 0 && B.n1 <= kRequantU8MaxShift && B.n2 <= kRequantU8MaxShift && B.nq <= kRequantU8MaxShift && B.lo1 == 0 && B.lo2 == 0 && B.loq == 0)) return false;
-        if (B.wsc == nullptr && B.res_shl != 0) return false;
+        if (!(B.relu_a && B.relu_b && B.relu1 && B.n1 > 0 && B.n2 > 0 && B.nq > 0 && B.n1 <= 30 && B.n2 <= 30 && B.nq <= 30 && B.lo1 == 0 && B.lo2 == 0 && B.loq == 0)) return 0;
+        if (B.wsc == nullptr && B.res_shl != 0) return 0;
+        f16 = f16 && B.n1 <= kRequantU8MaxShift && B.n2 <= kRequantU8MaxShift && B.nq <= kRequantU8MaxShift;
     }
-    if (a.q[0].ptr && !(a.q[0].n > 0 && a.q[0].n <= kRequantU8MaxShift && a.q[0].lo == 0)) return false;
-    return true;
+    if (a.q[0].ptr) {
+        if (!(a.q[0].n > 0 && a.q[0].n <= 30 && a.q[0].lo == 0)) return 0;
+        f16 = f16 && a.q[0].n <= kRequantU8MaxShift;
+    }
+    return (a.rq_int || !a.acc_ok || !f16) ? 2 : 1;
 }
 
 hipError_t launch_chain(const ChainArgs& a, int C, int MID, int H, int W, int cin0, hipStream_t s) {
     if (a.nblk < 1 || a.nblk > kChainMaxBlocks) return hipErrorInvalidValue;
-    const bool fast = chain_fast(a);
-#define F8_CHAIN_INST(...) (fast ? launch_chain_t<__VA_ARGS__, true, F8_CHAIN_ROT>(a, s) : launch_chain_t<__VA_ARGS__, false, F8_CHAIN_ROT>(a, s))
+    const int fast = chain_fast(a);
+#define F8_CHAIN_INST(...) (fast == 1 ? launch_chain_t<__VA_ARGS__, 1, F8_CHAIN_ROT>(a, s) : fast == 2 ? launch_chain_t<__VA_ARGS__, 2, F8_CHAIN_ROT>(a, s) : launch_chain_t<__VA_ARGS__, 0, F8_CHAIN_ROT>(a, s))
 #define F8_CHAIN_ROT false
     if (C == 256 && MID == 64 && H == 56 && W == 56 && cin0 == 64) return F8_CHAIN_INST(256, 64, 56, 56, 4, 64, F8_CH_S0);
     if (C == 256 && MID == 64 && H == 56 && W == 56 && cin0 == 256) return F8_CHAIN_INST(256, 64, 56, 56, 4, 256, F8_CH_S0);

@@ -87,6 +87,18 @@ __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d) {
     return __builtin_amdgcn_perm(hi, lo, 0x05040100u);                                    // {lo.b0, lo.b1, hi.b0, hi.b1}
 }
 
+// The same function — ReLU -> unsigned 8-bit, right shift n >= 1 — by compile-time choice of arithmetic.  RQ == 1: the float-converter form
+// above (n <= 16, bounded accumulators); RQ == 2: INTEGER ONLY (requant_shr + v_perm packing: 4 3/4 operations per value, exact for every
+// int32 and shift; what the handle's option `requant_float = 0` plans everywhere).
+template <int RQ>
+__device__ __forceinline__ unsigned requant_u8x4_sel(int a, int b, int c, int d, int n, float scale) {
+    if constexpr (RQ == 1) return requant_u8x4(a, b, c, d, scale);
+    else {
+        const unsigned half = 1u << (n - 1);
+        return pack4(requant_shr(a, n, half, 0u, 0, 255), requant_shr(b, n, half, 0u, 0, 255), requant_shr(c, n, half, 0u, 0, 255), requant_shr(d, n, half, 0u, 0, 255));
+    }
+}
+
 // int32 tensors live in an MFMA-fragment-tiled layout ("I32T"), not NHWC: blocks of 32 pixels x 32
 // channels (4 KB), inside a block the order is [g = (c%32)/8][lane = ((c/4)&1)*32 + m%32][c%4] — exactly
 // the accumulator layout of v_mfma_i32_32x32x32_i8 — so that a wave's residual read / int32 write of

@@ -30,7 +30,7 @@ __device__ __forceinline__ v4i dw_next_lane(const v4i& v) {   // lane i <- lane 
 
 // S: stride.  FQ: every int8 output format is a right shift into unsigned 8-bit behind a ReLU (shift 1 .. 16: 3-operation requantisation, f8_device.h; ReLU = the clamp).
 // SUBS: output rows per MFMA pixel tile: 1 = 32 lanes along one row (28 outputs), 2 = two rows of 16 lanes (14 outputs each: 14-wide maps)
-template <int S, bool FQ, int SUBS>
+template <int S, int FQ, int SUBS>
 __global__ void __launch_bounds__(256, S == 1 ? 4 : 3) dwconv3x3_mma_kernel(const DwArgs a) {
     constexpr int VW = SUBS == 2 ? 14 : DW_SW;                      // output columns per sub-row
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
@@ -101,9 +101,9 @@ __global__ void __launch_bounds__(256, S == 1 ? 4 : 3) dwconv3x3_mma_kernel(cons
             if (!a.q[k].ptr) continue;                              // wave-uniform
             unsigned d[4];
             if constexpr (FQ) {
-                const float sc = requant_u8_scale(a.q[k].n);
+                const float sc = FQ == 1 ? requant_u8_scale(a.q[k].n) : 0.0f;     // FQ == 2: integer requantisation (f8_device.h)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) d[g] = requant_u8x4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], sc) ^ 0x80808080u;
+                for (int g = 0; g < 4; ++g) d[g] = requant_u8x4_sel<FQ == 2 ? 2 : 1>(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], a.q[k].n, sc) ^ 0x80808080u;
             } else {
                 const int floor0 = a.relu0 ? 0 : INT32_MIN;
 #pragma unroll
@@ -176,17 +176,22 @@ bool dwconv_mma_supported(const DwArgs& a) {
 
 hipError_t launch_dwconv_mma(const DwArgs& a0, hipStream_t s) {
     DwArgs a = a0; a.bias = a0.bias4;                               // bias + 128 * sum(w) for unsigned inputs
-    bool fq = a.relu0 != 0 && a.acc_ok != 0;
-    for (int k = 0; k < 2; ++k)
-        if (a.q[k].ptr && !(a.q[k].n > 0 && a.q[k].n <= kRequantU8MaxShift && a.q[k].lo == 0 && a.q[k].hi == 255 && a.q[k].bias_xor == 0x80808080u)) fq = false;
+    int fq = a.relu0 != 0 ? ((a.acc_ok != 0 && !a.rq_int) ? 1 : 2) : 0;      // 1: float converter; 2: integer form of the same requantisation
+    for (int k = 0; k < 2; ++k) {
+        if (!a.q[k].ptr) continue;
+        if (!(a.q[k].n > 0 && a.q[k].n <= 30 && a.q[k].lo == 0 && a.q[k].hi == 255 && a.q[k].bias_xor == 0x80808080u)) fq = 0;
+        else if (fq == 1 && a.q[k].n > kRequantU8MaxShift) fq = 2;
+    }
     const int subs = a.Q >= DW_SW ? 1 : 2, vw = subs == 2 ? 14 : DW_SW;
     a.band = DW_BAND;
     long long items = (long long)a.N * ((a.P + a.band - 1) / a.band) * ((a.Q + vw - 1) / vw) * (a.Cs >> 5);
     if (items < 4096 && a.P > 8) { a.band = 8; items = (long long)a.N * ((a.P + a.band - 1) / a.band) * ((a.Q + vw - 1) / vw) * (a.Cs >> 5); }   // < 4 waves per SIMD
     const unsigned grid = (unsigned)((items + 3) / 4);
 #define F8_DWM(S_, FQ_, SB_) hipLaunchKernelGGL((dwconv3x3_mma_kernel<S_, FQ_, SB_>), dim3(grid), dim3(256), 0, s, a)
-    if (a.stride == 1) { if (subs == 1) { if (fq) F8_DWM(1, true, 1); else F8_DWM(1, false, 1); } else { if (fq) F8_DWM(1, true, 2); else F8_DWM(1, false, 2); } }
-    else               { if (subs == 1) { if (fq) F8_DWM(2, true, 1); else F8_DWM(2, false, 1); } else { if (fq) F8_DWM(2, true, 2); else F8_DWM(2, false, 2); } }
+#define F8_DWQ(S_, SB_) do { if (fq == 1) F8_DWM(S_, 1, SB_); else if (fq == 2) F8_DWM(S_, 2, SB_); else F8_DWM(S_, 0, SB_); } while (0)
+    if (a.stride == 1) { if (subs == 1) F8_DWQ(1, 1); else F8_DWQ(1, 2); }
+    else               { if (subs == 1) F8_DWQ(2, 1); else F8_DWQ(2, 2); }
+#undef F8_DWQ
 #undef F8_DWM
     return hipGetLastError();
 }

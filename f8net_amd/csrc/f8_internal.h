@@ -53,6 +53,8 @@ struct Options {
     int graph = 0;               // hipGraph capture / replay of a run
     int stagger = -1, stagger_pipelined = 2;
     int check_device = 1;        // f8_net_run fails if the current device is not the one the handle was uploaded to
+    int requant_float = 1;       // 1: ReLU -> unsigned 8-bit right shifts may run through the float converter (v_cvt_f32_i32, v_mul_f32 by 2^-n,
+                                 // v_cvt_pk_u8_f32: exact where planned, f8_device.h); 0: integer shift / round / clamp in every kernel
     int check_input_range = 1;   // int32 inputs that are NARROWED to the head's 8-bit format (no requant) are range-checked on the device; f8_net_check reports
 };
 void options_from_env(Options* o);                       // f8_net.cpp
@@ -118,6 +120,7 @@ struct DwArgs {
     int32_t band;                          // f8_dwmma.hip: output rows per wave (set by its launcher)
     int32_t acc_ok;                        // every accumulator is provably below 2^31 - 2^16 in magnitude (planner: conv_acc_bounded): the
                                            // float requantisation (requant_u8x4, f8_device.h) equals the wrapping integer one
+    int32_t rq_int;                        // Options::requant_float == 0: integer requantisation only
 };
 
 struct PoolArgs {                          // max-pool, NHWC
@@ -191,6 +194,7 @@ constexpr int kChainMaxBlocks = 6;
 struct ChainArgs {
     ChainBlk blk[kChainMaxBlocks]; int32_t nblk;
     int32_t acc_ok;                        // body.0 / body.2 accumulators of every block bounded (see DwArgs::acc_ok); the stream is not
+    int32_t rq_int;                        // Options::requant_float == 0: integer requantisation everywhere (no float-converter instance)
 
     const int32_t* xr;                     // first block an identity block: the stage's int32 stream (I32T) — its int8 form is computed in the launch
     const int8_t* x8in;                    // first block a stage-opening block: its int8 NHWC input [N*H*W][CIN0] in body.0's / the shortcut's format
@@ -218,6 +222,7 @@ constexpr int kBChainMaxBlocks = 6;
 struct BChainArgs {
     BChainBlk blk[kBChainMaxBlocks]; int32_t nblk;
     int32_t acc_ok;                        // first-conv accumulators of every block bounded (see DwArgs::acc_ok)
+    int32_t rq_int;                        // Options::requant_float == 0 (see ChainArgs)
 
     const int32_t* xr;                     // the stage's int32 stream (I32T): chains of identity blocks
     // chains that start with the stage-opening block (blk[0]: wa = 3x3 / 2 over C/2 channels, wb = 3x3, the stream = its 1x1 / 2 shortcut):
@@ -233,6 +238,7 @@ struct BChainArgs {
 // One launch for a MobileNet-V2 inverted-residual block: 1x1 expand -> depthwise 3x3 -> 1x1 project [+ int32 residual] (f8_ir.hip).
 struct IRArgs {
     int32_t acc_ok;                        // expand / depthwise accumulators bounded (see DwArgs::acc_ok)
+    int32_t rq_int;                        // Options::requant_float == 0: integer requantisation only
     const int8_t* x8;                      // block input, int8 NHWC [N*H*W][CIN_S] in the expand conv's input format
     const int32_t* xr;                     // block input, int32 I32T (residual operand) or nullptr
     const int8_t* w0; const int32_t* b0;   // expand  [E32][CIN_S], offset-corrected bias [E32]
@@ -252,6 +258,7 @@ struct IRArgs {
 // ResNet head in one launch: 7x7/2 conv + ReLU + requant (unsigned 8-bit) + 3x3/2 max-pool (f8_stem.hip).
 struct StemPoolArgs {
     int32_t acc_ok;                        // conv accumulators bounded (see DwArgs::acc_ok)
+    int32_t rq_int;                        // Options::requant_float == 0: integer requantisation only
     const int8_t* x; uint32_t x_bytes;     // haloed NHWC4 input [N][Hp][Wp][4], halo = conv pad + org pixels
     const int8_t* w; uint32_t w_bytes;     // [64][7][32 B]
     const int32_t* bias;                   // [64], offset-corrected (single class: the halo is biased zero)

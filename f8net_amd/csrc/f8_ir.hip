@@ -37,7 +37,7 @@ namespace f8 {
 #define F8_IR_SPLIT 1
 #endif
 constexpr int ir_nw(int cinS, int coutS) { return (cinS == 32 && coutS == 32) || (F8_IR_SPLIT && coutS <= 96) ? 8 : 4; }
-template <int CIN_S, int COUT_S, bool FQ, bool P2MMA = (COUT_S <= 96), int NW = ir_nw(CIN_S, COUT_S)>
+template <int CIN_S, int COUT_S, int FQ, bool P2MMA = (COUT_S <= 96), int NW = ir_nw(CIN_S, COUT_S)>
 __global__ void __launch_bounds__(NW * 64, (COUT_S <= 64 ? 4 : COUT_S <= 96 ? 3 : COUT_S <= 160 ? 2 : 1)) fused_ir_kernel(const IRArgs a) {
     constexpr int NT = NW * 64;
     constexpr bool SPLIT = NW == 8 && !(CIN_S == 32 && COUT_S == 32);
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(NW * 64, (COUT_S <= 64 ? 4 : COUT_S <= 96 ? 3 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc3[j][r] = 0;
     const int floor_a = a.relu_a ? 0 : INT32_MIN, floor_b = a.relu_b ? 0 : INT32_MIN;
-    const float sc1 = FQ ? requant_u8_scale(a.n1) : 0.0f, sc2 = FQ ? requant_u8_scale(a.n2) : 0.0f;
+    const float sc1 = FQ == 1 ? requant_u8_scale(a.n1) : 0.0f, sc2 = FQ == 1 ? requant_u8_scale(a.n2) : 0.0f;   // FQ == 2: integer requantisation (f8_device.h)
     (void)floor_a; (void)sc1; (void)sc2;
     const unsigned padv = a.xor1;
 
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(NW * 64, (COUT_S <= 64 ? 4 : COUT_S <= 96 ? 3 
                 for (int gq = 0; gq < 4; ++gq) {
                     int y[4];
                     if constexpr (FQ) {
-                        d[gq] = requant_u8x4(acc[i][4 * gq], acc[i][4 * gq + 1], acc[i][4 * gq + 2], acc[i][4 * gq + 3], sc1) ^ 0x80808080u;
+                        d[gq] = requant_u8x4_sel<FQ == 2 ? 2 : 1>(acc[i][4 * gq], acc[i][4 * gq + 1], acc[i][4 * gq + 2], acc[i][4 * gq + 3], a.n1, sc1) ^ 0x80808080u;
                     } else {
                         const v4i bv = *(const v4i*)(wb + OFF_B0 + (i * 32 + 8 * gq + 4 * lh) * 4);
 #pragma unroll
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(NW * 64, (COUT_S <= 64 ? 4 : COUT_S <= 96 ? 3 
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         if constexpr (FQ)
-                            d[gq] = requant_u8x4(acc2[4 * gq], acc2[4 * gq + 1], acc2[4 * gq + 2], acc2[4 * gq + 3], sc2) ^ 0x80808080u;
+                            d[gq] = requant_u8x4_sel<FQ == 2 ? 2 : 1>(acc2[4 * gq], acc2[4 * gq + 1], acc2[4 * gq + 2], acc2[4 * gq + 3], a.n2, sc2) ^ 0x80808080u;
                         else
                             d[gq] = pack4(requant1(max(acc2[4 * gq], floor_b), a.n2, a.lo2, a.hi2), requant1(max(acc2[4 * gq + 1], floor_b), a.n2, a.lo2, a.hi2),
                                           requant1(max(acc2[4 * gq + 2], floor_b), a.n2, a.lo2, a.hi2), requant1(max(acc2[4 * gq + 3], floor_b), a.n2, a.lo2, a.hi2)) ^ a.xor2;
@@ -453,7 +453,7 @@ bool fused_ir_config(int cinS, int coutS, int H, int W, int stride, int* R, int*
     return true;
 }
 
-template <int CIN_S, int COUT_S, bool FQ>
+template <int CIN_S, int COUT_S, int FQ>
 static hipError_t launch_ir_t(const IRArgs& a, int lds, hipStream_t s) {
     // dynamic LDS above 64 KB must be opted into per kernel AND per device (a process may drive several GPUs): keep the maximum per device
     static int attr_lds[64] = {};
@@ -474,9 +474,11 @@ hipError_t launch_fused_ir(const IRArgs& a0, int cinS, int coutS, hipStream_t s)
     int lds = 0;
     if (!ir_layout(cinS, coutS, a.H, a.W, a.stride, a.R, a.G, &a, &lds)) return hipErrorInvalidValue;
     // FQ: ReLU + right shift into unsigned 8-bit after the expand AND the depthwise conv (the VALU depthwise path keeps its general epilogue)
-    const bool fq = a.acc_ok && a.relu_a && a.relu_b && a.n1 > 0 && a.n2 > 0 && a.n1 <= kRequantU8MaxShift && a.n2 <= kRequantU8MaxShift && a.lo1 == 0 && a.lo2 == 0 && a.hi1 == 255 && a.hi2 == 255 &&
-                    a.xor1 == 0x80808080u && a.xor2 == 0x80808080u && coutS <= 96;
-#define F8_IR(C_, O_) if (cinS == C_ && coutS == O_) return fq ? launch_ir_t<C_, O_, true>(a, lds, s) : launch_ir_t<C_, O_, false>(a, lds, s);
+    // 1: through the float converter (bounded accumulators, shifts <= 16); 2: the integer form (option requant_float = 0, or where 1 is not provably exact)
+    const bool fqf = a.relu_a && a.relu_b && a.n1 > 0 && a.n2 > 0 && a.n1 <= 30 && a.n2 <= 30 && a.lo1 == 0 && a.lo2 == 0 && a.hi1 == 255 && a.hi2 == 255 &&
+                     a.xor1 == 0x80808080u && a.xor2 == 0x80808080u && coutS <= 96;
+    const int fq = !fqf ? 0 : ((a.rq_int || !a.acc_ok || a.n1 > kRequantU8MaxShift || a.n2 > kRequantU8MaxShift) ? 2 : 1);
+#define F8_IR(C_, O_) if (cinS == C_ && coutS == O_) return fq == 1 ? launch_ir_t<C_, O_, 1>(a, lds, s) : fq == 2 ? launch_ir_t<C_, O_, 2>(a, lds, s) : launch_ir_t<C_, O_, 0>(a, lds, s);
     F8_IR(32, 32) F8_IR(32, 64) F8_IR(64, 64) F8_IR(64, 96) F8_IR(96, 96) F8_IR(96, 160) F8_IR(160, 160) F8_IR(160, 320)
 #undef F8_IR
     return hipErrorInvalidValue;

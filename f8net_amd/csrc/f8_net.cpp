@@ -278,6 +278,7 @@ static const OptKey kOptKeys[] = {
     {"stagger_pipelined", "F8_STAGGER_PIPELINED", &Options::stagger_pipelined, 0, 1 << 20, false},
     {"check_device", "F8_CHECK_DEVICE", &Options::check_device, 0, 1, false},
     {"check_input_range", "F8_CHECK_INPUT_RANGE", &Options::check_input_range, 0, 1, false},
+    {"requant_float", "F8_REQUANT_FLOAT", &Options::requant_float, 0, 1, true},
     {"pipeline_depth", "F8_PIPELINE_DEPTH", &Options::pipeline_depth, 2, 4, false},
     {"arena_copies", "F8_ARENA_COPIES", &Options::arena_copies, 0, 4, true},
     {"shared_streams", "F8_SHARED_STREAMS", &Options::shared_streams, 0, 1, true},
@@ -743,12 +744,12 @@ static void label_conv_step(f8_net* net, Step& st, const Node& nd) {
     st.name = buf;
     if (nd.depthwise) {
         const Tensor& od = net->tensors[nd.out];         // keep in sync with launch_dwconv / dwconv_mma_supported / launch_dwconv_mma (FQ)
-        bool fq = d.relu && conv_acc_bounded(nd);
+        int fq = d.relu ? ((conv_acc_bounded(nd) && net->opt.requant_float) ? 1 : 2) : 0;
         int n8 = 0;
-        for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) { const Form& F = od.forms[st.out.f8[k]]; ++n8; if (!(F.n > 0 && F.n <= 16 && !F.sgn)) fq = false; }
+        for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) { const Form& F = od.forms[st.out.f8[k]]; ++n8; if (!(F.n > 0 && F.n <= 30 && !F.sgn)) fq = 0; else if (fq == 1 && F.n > 16) fq = 2; }
         const bool mma = net->opt.dw_mma && st.out.f32 < 0 && n8 > 0 && d.pad == 1 && (d.stride == 1 || d.stride == 2) && (od.W >= 28 || od.W == 14) &&
                          (d.stride == 1 ? (od.H == s.H && od.W == s.W) : (s.H == 2 * od.H && s.W == 2 * od.W));
-        if (mma) snprintf(buf, sizeof buf, "f8::dwconv3x3_mma_kernel<%d, %s, %d>", d.stride, fq ? "true" : "false", od.W >= 28 ? 1 : 2);
+        if (mma) snprintf(buf, sizeof buf, "f8::dwconv3x3_mma_kernel<%d, %d, %d>", d.stride, fq, od.W >= 28 ? 1 : 2);
         else snprintf(buf, sizeof buf, "f8::dwconv3x3_dot4_kernel<%d, 2>", d.stride);
     }
     else if (nd.p3_R > 0) snprintf(buf, sizeof buf, "f8::conv3x3_patch_kernel<%d, %d, %d, %d, %d, %d, %s>", d.cin, s.W, nd.p3_R, nd.p3_imgs, nd.p3_bn,
@@ -1090,7 +1091,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         if (!head2_supported(x.H, x.W) || ta.H * 2 != x.H || ta.W * 2 != x.W) continue;
         int na = 0, nb2 = 0;
         if (consumer_format(ta, b.cd, &na, "finalize") || consumer_format(tb, c.cd, &nb2, "finalize") || na < 1 || nb2 < 1 || na > 16 || nb2 > 16 ||
-            !conv_acc_bounded(h) || !conv_acc_bounded(b) || !conv_acc_bounded(c)) continue;   // 16: kRequantU8MaxShift; bounded: requant_u8x4 (f8_device.h)
+            (opt.requant_float && (!conv_acc_bounded(h) || !conv_acc_bounded(b) || !conv_acc_bounded(c)))) continue;   // 16: kRequantU8MaxShift; bounded: requant_u8x4 (f8_device.h); requant_float = 0: integer form, any accumulator
         bool int8_readers = !T[c.out].consumers.empty() && T[c.out].consumers.size() <= 2;
         for (int u : T[c.out].consumers) if (ND[u].kind != N_CONV || !ND[u].cd.quant_input) int8_readers = false;
         if (!int8_readers) continue;
@@ -1318,7 +1319,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     st.ops_per_img = ops; st.bytes_per_img = b; st.bytes_const = wbytes;
                     st.name = "basic_chain_x" + std::to_string(ch.size()) + (ds ? "_ds:" : ":") + tname(net, f1.out) + ".." + tname(net, nd.out);
                     char kb[160];
-                    snprintf(kb, sizeof kb, "f8::bchain_kernel<%d, %d, %d, %d, 2, 3, true, %s>", o.C, o.W, o.H, o.C == 64 ? 8 : 7, ds ? "true" : "false");   // keep in sync with launch_bchain
+                    snprintf(kb, sizeof kb, "f8::bchain_kernel<%d, %d, %d, %d, 2, 3, %d, %s>", o.C, o.W, o.H, o.C == 64 ? 8 : 7, opt.requant_float ? 1 : 2, ds ? "true" : "false");   // keep in sync with launch_bchain
                     st.kernel = kb;
                     break;
                 }
@@ -1358,7 +1359,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     st.name = "stage_chain_x" + std::to_string(ch.size()) + (ds ? "_ds:" : ":") + tname(net, a0.out) + ".." + tname(net, nd.out);
                     char kb[160];
                     const int C = o.C, MID = a0.cd.cout;
-                    snprintf(kb, sizeof kb, "f8::chain_kernel<%d, %d, %d, %d, 4, %d, %s>", C, MID, x.W, x.H, a0.cd.cin, MID == 256 ? "2, 4, true, false" : (MID == 64 ? "2, 2, true, false" : "2, 3, true, false"));   // keep in sync with launch_chain (the FAST instance: real fraclen tables)
+                    snprintf(kb, sizeof kb, "f8::chain_kernel<%d, %d, %d, %d, 4, %d, %s, %d, false>", C, MID, x.W, x.H, a0.cd.cin, MID == 256 ? "2, 4" : (MID == 64 ? "2, 2" : "2, 3"), opt.requant_float ? 1 : 2);   // keep in sync with launch_chain (the FAST instance: real fraclen tables)
                     st.kernel = kb;
                     break;
                 }
@@ -1463,8 +1464,9 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     {   // keep in sync with launch_fused_ir (FQ) and f8_ir.hip (P2MMA)
                         int n1 = 0, n2 = 0;
                         consumer_format(T[nb.a], nb.cd, &n1, "finalize"); consumer_format(T[nd.a], nd.cd, &n2, "finalize");
-                        const bool fq = na.cd.relu && nb.cd.relu && !nb.cd.input_signed && !nd.cd.input_signed && n1 > 0 && n2 > 0 && n1 <= 16 && n2 <= 16 && nd.coutP <= 96 && conv_acc_bounded(na) && conv_acc_bounded(nb);
-                        snprintf(kb, sizeof kb, "f8::fused_ir_kernel<%d, %d, %s, %s, %d>", x.Cs, nd.coutP, fq ? "true" : "false", nd.coutP <= 96 ? "true" : "false", nd.coutP <= 96 ? 8 : 4);
+                        const bool fqf = na.cd.relu && nb.cd.relu && !nb.cd.input_signed && !nd.cd.input_signed && n1 > 0 && n2 > 0 && n1 <= 30 && n2 <= 30 && nd.coutP <= 96;
+                        const int fq = !fqf ? 0 : ((opt.requant_float && n1 <= 16 && n2 <= 16 && conv_acc_bounded(na) && conv_acc_bounded(nb)) ? 1 : 2);
+                        snprintf(kb, sizeof kb, "f8::fused_ir_kernel<%d, %d, %d, %s, %d>", x.Cs, nd.coutP, fq, nd.coutP <= 96 ? "true" : "false", nd.coutP <= 96 ? 8 : 4);
                     }
                     st.kernel = kb;
                     break;
@@ -1976,7 +1978,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             a.N = N; a.Hp = sF.Hp; a.Wp = sF.Wp; a.org = sF.pad - hh.cd.pad;
             a.Pc = oT.H; a.Qc = oT.W; a.P = oT.H; a.Q = oT.W;
             a.relu0 = 1; a.grid_div = net->opt.stem_grid_div;
-            a.acc_ok = conv_acc_bounded(hh) && conv_acc_bounded(hb) && conv_acc_bounded(nd);
+            a.acc_ok = conv_acc_bounded(hh) && conv_acc_bounded(hb) && conv_acc_bounded(nd); a.rq_int = !net->opt.requant_float;
             a.rC = sT.C; a.rH = sT.H; a.rW = sT.W; a.xor8 = sF.sgn ? 0u : 0x80808080u;
             a.raw_kind = -1;
             if (st.raw_input && !(net->in_u8 && net->in_u8_nhwc)) {
@@ -2003,7 +2005,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             a.N = N; a.Hp = sF.Hp; a.Wp = sF.Wp; a.org = sF.pad - nd.cd.pad;
             a.Pc = cT.H; a.Qc = cT.W; a.P = oT.H; a.Q = oT.W;
             a.relu0 = st.relu0; a.wpc = net->opt.stem_wpc; a.rows = net->opt.stem_rows; a.grid_div = net->opt.stem_grid_div;
-            a.acc_ok = conv_acc_bounded(nd);
+            a.acc_ok = conv_acc_bounded(nd); a.rq_int = !net->opt.requant_float;
             a.raw_kind = -1;
             if (st.raw_input && !(net->in_u8 && net->in_u8_nhwc)) {
                 const size_t img = (size_t)sT.C * sT.H * sT.W;
@@ -2094,7 +2096,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
                 fmt(nb, T[nb.a], &B.n1, &B.lo1, &B.hi1, &B.xor1);
                 fmt(ng, T[ng.a], &B.n2, &B.lo2, &B.hi2, &B.xor2);
                 B.relu_a = na.cd.relu; B.relu_b = nb.cd.relu; B.relu1 = net->nodes[hh.fused_add].relu;
-                if (k == 0) a.acc_ok = 1;
+                if (k == 0) { a.acc_ok = 1; a.rq_int = !net->opt.requant_float; }
                 a.acc_ok = a.acc_ok && conv_acc_bounded(na) && conv_acc_bounded(nb);
                 // identity: (body.4 << acc_shl) + (block input << res_shl); opening block: (shortcut << acc_shl) + (body.4 << res_shl)
                 const int dfl = T[hh.out].fl - (hds ? T[ng.out].fl : xin.fl);
@@ -2138,7 +2140,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
                 fmt(c1, xin, &B.nq, &B.loq, &B.hiq, &B.xorq);
                 fmt(c2, T[c2.a], &B.n1, &B.lo1, &B.hi1, &B.xor1);
                 B.relu_a = c1.cd.relu; B.relu1 = net->nodes[hk.fused_add].relu;
-                if (k == 0) a.acc_ok = 1;
+                if (k == 0) { a.acc_ok = 1; a.rq_int = !net->opt.requant_float; }
                 a.acc_ok = a.acc_ok && conv_acc_bounded(c1);
                 // identity: (second conv << acc_shl) + (block input << res_shl); opening block: (second conv << acc_shl) + (shortcut << res_shl)
                 const int dfl = T[c2.out].fl - (hds ? T[hk.out].fl : xin.fl);
@@ -2196,7 +2198,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             fmt(nb, T[nb.a], &a.n1, &a.lo1, &a.hi1, &a.xor1);
             fmt(nd, T[nd.a], &a.n2, &a.lo2, &a.hi2, &a.xor2);
             a.relu_a = na.cd.relu; a.relu_b = nb.cd.relu; a.relu0 = st.relu0;
-            a.acc_ok = conv_acc_bounded(na) && conv_acc_bounded(nb);
+            a.acc_ok = conv_acc_bounded(na) && conv_acc_bounded(nb); a.rq_int = !net->opt.requant_float;
             a.acc_shl = st.acc_shl; a.res_shl = st.res_shl; a.relu1 = st.relu1;
             make_magic((uint32_t)x.W, &a.mW, &a.s1W, &a.s2W);
             make_magic((uint32_t)(x.H * x.W), &a.mHW, &a.s1HW, &a.s2HW);
@@ -2213,7 +2215,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             a.x = (const int8_t*)fp(sF); a.w = (const int8_t*)(net->d_w + nd.w_off); a.bias = (const int32_t*)(net->d_w + nd.b_off);
             a.w4 = (const int8_t*)(net->d_w + nd.rc_off); a.bias4 = (const int32_t*)(net->d_w + nd.cc_off);
             a.N = N; a.H = sT.H; a.W = sT.W; a.P = oT.H; a.Q = oT.W; a.Cs = sT.Cs; a.stride = nd.cd.stride; a.pad = nd.cd.pad;
-            a.in_signed = nd.cd.input_signed; a.relu0 = st.relu0; a.use_dot4 = net->opt.dw_dot4; a.use_mma = net->opt.dw_mma; a.acc_ok = conv_acc_bounded(nd);
+            a.in_signed = nd.cd.input_signed; a.relu0 = st.relu0; a.use_dot4 = net->opt.dw_dot4; a.use_mma = net->opt.dw_mma; a.acc_ok = conv_acc_bounded(nd); a.rq_int = !net->opt.requant_float;
             fill_out(&a.out32, a.q);
             e = launch_dwconv(a, s);
             break;

@@ -479,10 +479,16 @@ __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))
             }
             return acc;
         };
-        auto quant_row = [&](const v16i& acc, float sc) {  // ReLU + right shift (1 .. 16) into unsigned 8-bit, 16 channels per lane half
+        const bool rqi = a.rq_int != 0;                             // option requant_float = 0: integer requantisation (wave-uniform branch)
+        auto quant_row = [&](const v16i& acc, float sc, int n) {  // ReLU + right shift (1 .. 16) into unsigned 8-bit, 16 channels per lane half
             unsigned dd[4];
+            if (rqi) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) dd[g] = requant_u8x4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], sc) ^ 0x80808080u;
+                for (int g = 0; g < 4; ++g) dd[g] = requant_u8x4_sel<2>(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], n, 0.0f) ^ 0x80808080u;
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) dd[g] = requant_u8x4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], sc) ^ 0x80808080u;
+            }
             auto s0 = __builtin_amdgcn_permlane32_swap(dd[0], dd[2], false, false);
             auto s1 = __builtin_amdgcn_permlane32_swap(dd[1], dd[3], false, false);
             return v4i{(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
@@ -502,7 +508,7 @@ __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))
                     v16i acc = bias_acc(0);
                     acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wh0, v4i{a0.x, a0.y, a1.x, a1.y}, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wh1, v4i{b0.x, b0.y, b1.x, b1.y}, acc, 0, 0, 0);
-                    x = quant_row(acc, sca);
+                    x = quant_row(acc, sca, a.na);
                     if (!cq_in) x = zq;
                 }
                 R.f[0] = x;
@@ -526,14 +532,14 @@ __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))
                     for (int kx = 0; kx < 3; ++kx) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wd[3 + kx], R1.f[kx], acc, 0, 0, 0);
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wd[6 + kx], R2.f[kx], acc, 0, 0, 0);
-                    const v4i xb = quant_row(acc, scb);
+                    const v4i xb = quant_row(acc, scb, a.nb);
                     v16i acc1 = bias_acc(2);
                     acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1f, xb, acc1, 0, 0, 0);
                     const size_t m = ((size_t)B.n * a.P + P) * a.Q + (lane_out ? col : 0);
 #pragma unroll
                     for (int k = 0; k < 2; ++k)
                         if (a.q[k].ptr) {
-                            const v4i v = stem_quant16(acc1, a.q[k].n, a.q[k].lo, a.q[k].hi, a.q[k].bias_xor, true);
+                            const v4i v = stem_quant16(acc1, a.q[k].n, a.q[k].lo, a.q[k].hi, a.q[k].bias_xor, !rqi);
                             if (lane_out) *(v4i*)(a.q[k].ptr + m * 32 + lh * 16) = v;
                         }
                     R0 = R1; R1 = R2;
@@ -618,7 +624,7 @@ __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
                     if (a.q[k].ptr) {
-                        const v4i v = stem_quant16(pm, a.q[k].n, a.q[k].lo, a.q[k].hi, a.q[k].bias_xor, a.acc_ok != 0);
+                        const v4i v = stem_quant16(pm, a.q[k].n, a.q[k].lo, a.q[k].hi, a.q[k].bias_xor, a.acc_ok != 0 && a.rq_int == 0);
                         if (lane_out) *(v4i*)(a.q[k].ptr + (size_t)m * 64 + half * 32 + lh * 16) = v;
                     }
             }
@@ -647,7 +653,7 @@ bool head2_supported(int H, int W) { return H >= 8 && W >= 8 && H % 4 == 0 && W 
 
 hipError_t launch_stem_pool(const StemPoolArgs& a, hipStream_t s) {
     if (a.h2) {
-        if (!head2_supported(a.rH, a.rW) || a.P != a.rH / 2 || a.Q != a.rW / 2 || a.Pc != a.P || a.Qc != a.Q || a.na < 1 || a.nb < 1 || a.na > kRequantU8MaxShift || a.nb > kRequantU8MaxShift || !a.acc_ok || a.out32 ||
+        if (!head2_supported(a.rH, a.rW) || a.P != a.rH / 2 || a.Q != a.rW / 2 || a.Pc != a.P || a.Qc != a.Q || a.na < 1 || a.nb < 1 || a.na > kRequantU8MaxShift || a.nb > kRequantU8MaxShift || (!a.acc_ok && !a.rq_int) || a.out32 ||
             (a.raw_kind < 0 && !(a.org == 4 && a.Wp % 4 == 0))) return hipErrorInvalidValue;
         const int lds_bytes = 2 * RB_ROWS * (a.rW + 8) * 4 + 512 + 1536;
         static int ncu3 = 0;

@@ -72,9 +72,25 @@ CHAINS = [
 @pytest.mark.parametrize('variant', ['acc_shifts_left', 'res_shifts_left'])
 @pytest.mark.parametrize('tail', ['int32_out', 'int8_out'])
 def test_stage_chain_matches_oracle(dev, cfg, variant, tail):
-    C, MID, HW, nblk, cin0, N = cfg
-    if tail == 'int8_out' and N > 8:
+    if tail == 'int8_out' and cfg[5] > 8:
         pytest.skip('the int8 tail is covered at the small batch')
+    _run_stage_chain(dev, cfg, variant, tail)
+
+
+@pytest.mark.parametrize('cfg', [CHAINS[0], CHAINS[2], CHAINS[4], CHAINS[5]], ids=lambda g: 'x'.join(map(str, g)))
+@pytest.mark.parametrize('mode', ['requant_float=0', 'bias_near_2^31'])
+def test_stage_chain_integer_requant_instances(dev, cfg, mode):
+    """The float-converter requantisation is planned only where it is provably exact.  `requant_float = 0` plans the INTEGER form
+    (shift / round-half-even / clamp, fix_quant_ops.py:99-112; no float instruction) in every instance; a bias next to 2^31 makes
+    body.0 / body.2 accumulators unboundable (f8_net.cpp conv_acc_bounded): the reference's `v + 2^(n-1)` wraps there (the value turns
+    negative, the clamp makes it 0) and the launch must take the integer instance by itself — and equal the oracle either way."""
+    for tail in ('int32_out', 'int8_out'):
+        _run_stage_chain(dev, cfg, 'acc_shifts_left', tail, options={'requant_float': 0} if mode == 'requant_float=0' else None,
+                         big_bias=(mode != 'requant_float=0'))
+
+
+def _run_stage_chain(dev, cfg, variant, tail, options=None, big_bias=False):
+    C, MID, HW, nblk, cin0, N = cfg
     blocks, fls = _stage(C, MID, nblk, cin0, variant)
     convs = [c for b in blocks for c in (b.body + ([b.shortcut] if b.shortcut is not None else []))]
     tailc = topology.ConvSpec('tail.0', C, 64, 1, 1, 0)
@@ -82,6 +98,9 @@ def test_stage_chain_matches_oracle(dev, cfg, variant, tail):
     fls['tail.0'], fls['tail.1'] = (3, 6), (5, 7)
     tail2.signed_in = True
     params = _params(convs + [tailc, tail2], fls, 11, variant)
+    if big_bias:      # accumulators within 2^(n-1) of 2^31 in body.0 and body.2 of the second block: the rounding add wraps
+        params['s.1.body.0.bias'][[3, MID - 1]] = [2 ** 31 - 50, 2 ** 31 - 2 ** 12]
+        params['s.1.body.2.bias'][[0, 17]] = [2 ** 31 - 2 ** 10, 2 ** 31 - 7]
     x_fl = 9
     scale = 3.0e3 if cin0 == C else 60.0
     x = synth.rand_normal_int(7, 'chainx' + variant, (N, cin0, HW, HW), scale).astype(np.int32)
@@ -91,6 +110,8 @@ def test_stage_chain_matches_oracle(dev, cfg, variant, tail):
         x = np.abs(x)
 
     net = F8Net()
+    for k, v in (options or {}).items():
+        net.set_option(k, v)
     t = net.input(cin0, HW, HW, x_fl)
     r = t
     for b in blocks:
@@ -121,6 +142,10 @@ def test_stage_chain_matches_oracle(dev, cfg, variant, tail):
     w, fl = x, x_fl
     for b in blocks:
         w, fl = oracle.block_forward(b, params, w, fl)
+    if big_bias:      # the wrap really happens in the oracle: those mid channels requantise to 0 although their accumulators are huge
+        w0, fl0 = oracle.block_forward(blocks[0], params, x, x_fl)
+        m1, _ = oracle._conv_layer(blocks[1].body[0], params, w0, fl0)
+        assert (np.abs(m1[:, 3].astype(np.int64)) > 2 ** 30).all() and (m1[:, 3] < 0).any()      # some sums passed 2^31 and wrapped
     if tail == 'int8_out':
         w, fl = oracle._conv_layer(tailc, params, w, fl)
         got = got.reshape(N, 64, HW, HW)
@@ -157,9 +182,23 @@ BCHAINS = [(64, 56, 2, 3), (64, 56, 3, 40), (128, 28, 1, 5), (128, 28, 2, 70), (
 @pytest.mark.parametrize('variant', ['acc_shifts_left', 'res_shifts_left'])
 @pytest.mark.parametrize('tail', ['int32_out', 'int8_out'])
 def test_basic_block_chain_matches_oracle(dev, cfg, variant, tail):
-    C, HW, nblk, N = cfg
-    if tail == 'int8_out' and N > 8:
+    if tail == 'int8_out' and cfg[3] > 8:
         pytest.skip('the int8 tails are covered at the small batch')
+    _run_basic_chain(dev, cfg, variant, tail)
+
+
+@pytest.mark.parametrize('cfg', [BCHAINS[0], (128, 28, 2, 5), (256, 14, 2, 4)], ids=lambda g: 'x'.join(map(str, g)))
+@pytest.mark.parametrize('mode', ['requant_float=0', 'bias_near_2^31'])
+def test_basic_block_chain_integer_requant_instances(dev, cfg, mode):
+    """As test_stage_chain_integer_requant_instances, for bchain_kernel: the integer instance by option, and by itself where the first
+    conv's accumulators cannot be bounded (bias next to 2^31: the reference's rounding add wraps)."""
+    for tail in ('int32_out', 'int8_out'):
+        _run_basic_chain(dev, cfg, 'acc_shifts_left', tail, options={'requant_float': 0} if mode == 'requant_float=0' else None,
+                         big_bias=(mode != 'requant_float=0'))
+
+
+def _run_basic_chain(dev, cfg, variant, tail, options=None, big_bias=False):
+    C, HW, nblk, N = cfg
     blocks, fls = _basic_stage(C, nblk, variant)
     convs = [c for b in blocks for c in b.body]
     t0 = topology.ConvSpec('tail.0', C, 64, 1, 1, 0)
@@ -172,8 +211,12 @@ def test_basic_block_chain_matches_oracle(dev, cfg, variant, tail):
     pre = topology.ConvSpec('pre.0', C, C, 1, 1, 0)              # a conv in front: the chain's input is not the network input
     fls['pre.0'] = (4, 7)
     params.update(_params([pre], fls, 33, variant))
+    if big_bias:
+        params[f'b.{nblk - 1}.body.0.bias'][[2, C - 1]] = [2 ** 31 - 50, 2 ** 31 - 2 ** 12]
 
     net = F8Net()
+    for k, v in (options or {}).items():
+        net.set_option(k, v)
     t = net.input(C, HW, HW, x_fl)
     r = net.conv(t, params['pre.0.weight'], params['pre.0.bias'], stride=1, pad=0, groups=1, weight_fl=7, input_fl=4, input_signed=False,
                  quant_input=True, relu=True)
