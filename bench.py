@@ -158,7 +158,7 @@ def main():
     # consecutive steps overlap inside the library as well (f8_net_set_pipelined: static input, double-buffered outputs)
     # F8_BENCH_PIPELINED: 0 = runs back to back, 1 = lagged sub-batches, 2 = whole batches alternating between two streams
 
-    def timed(mode, steps, warmup):
+    def timed(mode, steps, warmup, net=net):
         net.set_pipelined(mode)
         sharded = f8dist.PipelinedShardedForward(lambda t, out: net.run(t, out=out), spec.num_classes, BS, dev, lagged=mode != 0, depth=depth)
 
@@ -182,6 +182,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         assert out.shape == (BS * world, spec.num_classes)
+        net.check()                         # sticky device error words (a chain launch's halo wait timed out; int32 input outside the head's format): raises
         return dt, sharded.local[0]
 
     lean = os.environ.get('F8_BENCH_LEAN', '0') == '1'      # profiling runs (tools/profile.sh): the headline loop only, fewer kernel records
@@ -216,6 +217,21 @@ def main():
             print(f'bench.py: the timed region of {args.steps} steps lasted {dt * 1e3:.1f} ms (< {MIN_TIMED_S} s); also timed {k2} steps '
                   f'({dte * 1e3:.1f} ms) -> value_extended', file=sys.stderr)
     net.set_pipelined(pipe_mode)
+    # (4b) the same K steps with INTEGER-ONLY requantisation (option requant_float = 0: shift / round-half-even / clamp in every epilogue, no
+    #      float instruction); the headline plan routes ReLU -> unsigned 8-bit right shifts of bounded accumulators through the float converter
+    #      (exact, compared over all 2^32 values on the device: tests/test_gpu_requant_probe.py).  Same logits, two arithmetic paths.
+    rq_float = bool(net.get_option('requant_float'))
+    extra_rq = {}
+    if world == 1 and not lean and rq_float:
+        opts_i = {'requant_float': 0}
+        if pipe_mode == 2:
+            opts_i.update({'whole_batch_launches': 1, 'arena_copies': depth, 'pipeline_depth': depth})
+        net_i = build_net(spec, params, max_batch=BS, hw=224, options=opts_i)
+        net_i.upload()
+        dti, logits_i = timed(pipe_mode, args.steps, args.warmup, net=net_i)
+        extra_rq = {'value_int_requant': round(BS * args.steps / dti, 1), 'int_requant_matches': bool(torch.equal(logits_i[:BS], logits[:BS]))}
+        del net_i
+        net.set_pipelined(pipe_mode)
 
     # (5) the drop-in module path and the host-fed path (single GPU, full runs only): the same K steps
     #     (a) through IntModel.forward — the nn.Module the reference's fix_resnet.py / fix_mobilenet_v*.py callers hold;
@@ -317,6 +333,8 @@ def main():
                                    f'int32 NCHW input resident in HBM' + ('' if headline else ' [not the headline configuration]'),
                        'global_batch': BS * world, 'parallelism': f'dp{world} (batch shards + RCCL all-gather of logits)',
                        'launches_per_step': sum(net.step_launches(i, BS) for i in range(n_l)), 'sub_batches': parts, 'autotuned_launches': retiled,
+                       'requant': 'float-converter (exact, probed): v_cvt_f32_i32, v_mul_f32 by 2^-n, v_cvt_pk_u8_f32 where the planner bounds the accumulators, '
+                                  'integer shift/round/clamp elsewhere; value_int_requant = the same steps with option requant_float = 0' if rq_float else 'int',
                        'schedule': {0: 'runs back to back (two concurrent sub-batches per run)',
                                     1: 'pipelined: sub-batches of consecutive runs overlap (f8_net_set_pipelined(1))',
                                     2: f'pipelined: {depth} consecutive batches in flight (one arena copy each), each launch covers a whole batch '
@@ -343,6 +361,7 @@ def main():
             'build': {'csrc_sha256': stamp[:16]},
         }
         result.update(extra)
+        result.update(extra_rq)
         if ext is not None:
             result['value_extended'] = round(BS * world * ext[0] / ext[1], 1)
             result['steps_extended'] = ext[0]

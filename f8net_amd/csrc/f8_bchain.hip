@@ -458,6 +458,19 @@ bchain_kernel(const BChainArgs a) {
         __syncthreads();
         F8_BT(3);
     }
+    // ---- re-arm the ticket and the flags for the NEXT launch on this scratch (f8_chain.hip).  A workgroup counts itself out once ITS flag stores have been performed (lane 0 issued
+    //      them: its vmcnt(0)) and its last poll has returned; the last one out sees every other workgroup past its last access of the words
+    //      and zeroes them; the kernel boundary orders the zeroes before the next launch.  Every workgroup gets here — a timed-out wait sets the
+    //      error word and runs on — and the words are zeroed once at allocation (f8_net.cpp), so the first launch starts clean.
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        misc[2] = (__hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) ? 1 : 0;
+    }
+    __syncthreads();
+    if (misc[2]) {
+        if (tid < (int)gridDim.x) __hip_atomic_store(flags + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) { __hip_atomic_store(a.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(a.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    }
 #ifdef F8_TRACE
     if (a.trace && tid == 0) {
         unsigned long long* tp = (unsigned long long*)a.trace + (size_t)blockIdx.x * 8;
@@ -507,8 +520,6 @@ static hipError_t launch_bchain_t(const BChainArgs& a, hipStream_t s) {
     }
     const int grid = a.NG * Cfg::T;
     if (grid < 1 || grid > 256) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(a.sync, 0, (size_t)kChainSyncWords * 4, s);
-    if (e != hipSuccess) return e;
 #ifdef F8_TRACE
     static unsigned long long* tbuf = nullptr; static int count = 0;
     static const int want = [] { const char* e = getenv("F8_TRACE_BCHAIN"); return e ? atoi(e) : -1; }();

@@ -101,6 +101,15 @@ chain_kernel(const ChainArgs a) {
     constexpr int NPW = (NPT + PG - 1) / PG;                    // pixel tiles per wave there
     constexpr int NK1 = C / 32, NK2 = 9 * CM, KK = CM, KS = CIN0 / 32;   // K32 steps of body.0 / body.2 / body.4 / the opening block's shortcut
     constexpr bool WSTAT = NPT > 2;                             // P3: this wave's weights stay in registers for all pixel tiles (else streamed, two tiles at a time)
+    // EARLY (round 4): the halo rows are published STRAIGHT FROM THE REGISTERS of P1's epilogue (no patch read-back, no extra barrier: the
+    // "patch complete" barrier is also the publish barrier), body.2 starts with its CENTRE-ROW taps, which read no halo row, and the
+    // neighbours' rows are waited for and fetched only in front of the first tap that needs one: the flag's and the rows' round trips
+    // through the fabric (~2 x 1 us) run under a third of the 3x3.  (Round 3 could not afford the consume point inside the unrolled K
+    // loop: the kernel was at 256 registers; the weight streams as buffer loads and the peeled opening block freed 25-55.)
+#ifndef F8_CH_EARLY
+#define F8_CH_EARLY 1
+#endif
+    constexpr bool EARLY = F8_CH_EARLY != 0 && T > 1 && !ROT;
     static_assert(NB <= CM && CM % NB == 0 && NK1 % NB == 0, "a batch of K steps stays inside one 3x3 tap / one weight tile");
     static_assert(!DS0 || KS % NB == 0, "stage-opening block: whole batches");
     static_assert(!ROT || (NK1 % 8 == 0 && CM == 8), "rotation: groups of 8 K steps (256 bytes of a row), whole taps");
@@ -171,7 +180,11 @@ chain_kernel(const ChainArgs a) {
 
     // ---- weight streams (fragment order: [tile][K32 step][lane][16 B]).  step -> K index: identity, or rotated in coarse groups.
     auto k1_of = [&](int g, int nk) { return ROT ? (((g >> 3) + opaque(rot)) & (nk / 8 - 1)) * 8 + (g & 7) : g; };       // body.0: groups of 8 steps
-    auto tap_of = [&](int t) { if (!ROT) return t; int q = t + (int)((unsigned)opaque(rot) % 9u); return q >= 9 ? q - 9 : q; };   // body.2: whole taps
+    auto tap_of = [&](int t) {                                  // body.2: whole taps
+        if constexpr (EARLY) return t < 3 ? t + 3 : (t < 6 ? t - 3 : t);         // centre row first (taps 3, 4, 5), then the rows that read a halo row
+        else if constexpr (!ROT) return t;
+        else { int q = t + (int)((unsigned)opaque(rot) % 9u); return q >= 9 ? q - 9 : q; }
+    };
     // A-operand loads: uniform base (+ a SCALAR step offset, kept scalar by `opaque`: as a constant it gets folded into a per-step
     // per-lane offset register that is hoisted out of the block loop and spilled) + ONE per-lane offset register per stream
     // Round 4: BUFFER loads (resource = the weight pointer, scalar step offset in soffset, the per-lane offset in voffset).  As a flat
@@ -326,6 +339,8 @@ chain_kernel(const ChainArgs a) {
                     __syncthreads();                            // the zero fill is complete
                     F8_CT(8);
                     const int floor0 = relu_a ? 0 : INT32_MIN;
+                    const __amdgpu_buffer_rsrc_t rxp = __builtin_amdgcn_make_buffer_rsrc((void*)a.xchg, 0, (unsigned)kChainXchgBytes, 0x00020000);
+                    const unsigned pub0 = (unsigned)((L * 2 + (int)(seq & 1u)) * 2 * ROWB + mt * 32 + lh * 16);   // this block's parity, side 0 (my top row)
 #pragma unroll
                     for (int j = 0; j < NPW; ++j) {
                         const int pix = p12_pix[j];
@@ -337,14 +352,20 @@ chain_kernel(const ChainArgs a) {
                         }
                         const v4i o = quant_tile16<FAST, true>(acc[j], n1, lo1, hi1, xor1);   // FAST: lo1 == 0 is the ReLU
                         if (pix < npx) *(v4i*)(patch + ent * MS + mt * 32 + lh * 16) = o;
+                        if constexpr (EARLY) {                  // my first / last row -> the neighbours, write-through (sc0 sc1), 16 bytes per lane
+                            if (pix < npx && pr == 0 && has_up) __builtin_amdgcn_raw_buffer_store_b128(o, rxp, pub0 + (unsigned)(pc * MID), 0, 17);
+                            if (pix < npx && pr == rows - 1 && has_dn) __builtin_amdgcn_raw_buffer_store_b128(o, rxp, pub0 + (unsigned)(ROWB + pc * MID), 0, 17);
+                        }
                     }
+                    if constexpr (EARLY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains (the first body.2 weight batches land too)
                 }
                 F8_CT(1);
-                __syncthreads();                                // the patch interior is complete
+                __syncthreads();                                // the patch interior is complete (EARLY: and every halo store has been performed)
+                if constexpr (EARLY) { if (tid == 0) __hip_atomic_store(flags + L, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                 F8_CT(9);
 
-                // ============================ halo rows: publish mine, fetch the neighbours'
-                if constexpr (T > 1) {
+                // ============================ halo rows: publish mine (EARLY: done above), fetch the neighbours' (EARLY: inside body.2's K loop)
+                if constexpr (T > 1 && !EARLY) {
                     constexpr int RCH = ROWB / 16, CPE = MID / 16;              // 16-byte pieces per row / per patch entry
                     const __amdgpu_buffer_rsrc_t rxc = __builtin_amdgcn_make_buffer_rsrc((void*)a.xchg, 0, (unsigned)kChainXchgBytes, 0x00020000);
                     int th = tid; asm volatile("" : "+v"(th));                   // re-derived per block, not hoisted and spilled
@@ -362,6 +383,16 @@ chain_kernel(const ChainArgs a) {
                     __syncthreads();
                     if (tid == 0) __hip_atomic_store(flags + L, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     F8_CT(11);
+                }
+                auto consume = [&]() {
+                  if constexpr (T > 1) {
+                    constexpr int RCH = ROWB / 16, CPE = MID / 16;
+                    const __amdgpu_buffer_rsrc_t rxc = __builtin_amdgcn_make_buffer_rsrc((void*)a.xchg, 0, (unsigned)kChainXchgBytes, 0x00020000);
+                    int th = tid; asm volatile("" : "+v"(th));
+                    const int side = th >> 8, idx = th & 255;
+                    const bool mine = idx < RCH && (side == 0 ? has_up : has_dn);
+                    const int col = idx / CPE, c16 = idx % CPE;
+                    const unsigned par = seq & 1u;
                     // one lane per neighbour polls its flag
                     if ((tid == 0 && has_up) || (tid == 256 && has_dn)) {
                         unsigned* const f = flags + (tid == 0 ? L - 1 : L + 1);
@@ -387,7 +418,9 @@ chain_kernel(const ChainArgs a) {
                         *(v4i*)(patch + ent * MS + c16 * 16) = v;
                     }
                     __syncthreads();
-                }
+                  }
+                };
+                if constexpr (!EARLY) consume();
                 F8_CT(2);
 
                 // ============================ P2: mid2 = requant(relu(conv3x3(mid1) + b2)) -> mid2
@@ -431,7 +464,8 @@ chain_kernel(const ChainArgs a) {
                         bpb[j] = (unsigned)((orow * PW + ocol) * MS + lh * 16);
                     }
                     auto rd = [&](v4i (&xf)[NPW], auto gc) {
-                        constexpr int G = decltype(gc)::value, TAP = G / CM, CI = G % CM;
+                        constexpr int G = decltype(gc)::value, TAP0 = G / CM, CI = G % CM;
+                        constexpr int TAP = EARLY ? (TAP0 < 3 ? TAP0 + 3 : (TAP0 < 6 ? TAP0 - 3 : TAP0)) : TAP0;
                         if constexpr (ROT) {
                             const int tp = tap_of(TAP);
                             const int tr = tp / 3, ts = tp - tr * 3;
@@ -445,12 +479,14 @@ chain_kernel(const ChainArgs a) {
                     };
                     v4i xfa[NPW], xfb[NPW];
                     rd(xfa, std::integral_constant<int, 0>{});
+                    constexpr int GH = EARLY ? 3 * CM : NK2 + 1;        // first K step of a tap that reads a halo row
                     static_for<NK2>([&](auto gc) {
                         constexpr int G = decltype(gc)::value, Bi = G / NB, S = G % NB;
                         if constexpr (S == 0 && Bi + NBUF - 1 < NBAT2) w2_load(pw2, wbuf[(Bi + NBUF - 1) % NBUF], Bi + NBUF - 1, wl16);
                         v4i (&cur)[NPW] = (G & 1) ? xfb : xfa;
                         v4i (&nxt)[NPW] = (G & 1) ? xfa : xfb;
-                        if constexpr (G + 1 < NK2) rd(nxt, std::integral_constant<int, G + 1>{});
+                        if constexpr (G == GH) { F8_CT(3); consume(); F8_CT(2); rd(cur, gc); }
+                        if constexpr (G + 1 < NK2 && G + 1 != GH) rd(nxt, std::integral_constant<int, G + 1>{});
                         pin(cur);
 #pragma unroll
                         for (int j = 0; j < NPW; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Bi % NBUF][S], cur[j], acc[j], 0, 0, 0);
@@ -605,6 +641,20 @@ chain_kernel(const ChainArgs a) {
         __syncthreads();                                        // before the next image's tile overwrites x8 / xin
         F8_CT(5);
     }
+    // ---- re-arm the ticket and the flags for the NEXT launch on this scratch (round 4: the hipMemsetAsync node in front of every chain launch
+    //      was 3 x 5 us per step on the critical path).  A workgroup counts itself out once ITS flag stores have been performed (lane 0 issued
+    //      them: its vmcnt(0)) and its last poll has returned; the last one out sees every other workgroup past its last access of the words
+    //      and zeroes them; the kernel boundary orders the zeroes before the next launch.  Every workgroup gets here — a timed-out wait sets the
+    //      error word and runs on — and the words are zeroed once at allocation (f8_net.cpp), so the first launch starts clean.
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        misc[2] = (__hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) ? 1 : 0;
+    }
+    __syncthreads();
+    if (misc[2]) {
+        if (tid < (int)gridDim.x) __hip_atomic_store(flags + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) { __hip_atomic_store(a.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(a.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    }
 #ifdef F8_TRACE
     if (a.trace && (tid & 63) == 0) {
         unsigned long long* tp = (unsigned long long*)a.trace + ((size_t)blockIdx.x * 8 + wave) * 16;
@@ -633,8 +683,6 @@ static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t s) {
     }
     const int grid = a.NG * Cfg::T;
     if (grid < 1 || grid > 256) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(a.sync, 0, (size_t)kChainSyncWords * 4, s);     // ticket and flags: every launch (also under graph replay)
-    if (e != hipSuccess) return e;
 #ifdef F8_TRACE
     static unsigned long long* tbuf = nullptr; static int count = 0;
     static const int want = [] { const char* e = getenv("F8_TRACE_CHAIN"); return e ? atoi(e) : -1; }();

@@ -26,7 +26,7 @@ struct Options {
     int wreg = 1;                // late 1x1 convs on conv1x1_wreg_kernel (weights straight to registers, f8_wreg.hip)
     int fuse_bchain = 2;         // consecutive BasicBlock identity blocks of a stage in ONE launch (f8_bchain.hip); 2: with the stage-opening block in front of them
     int fuse_chain = 1;          // all consecutive bottleneck blocks of a stage in ONE launch, int32 residual stream in registers (f8_chain.hip)
-    int chain_timeout_ms = 2000; // bound of its halo-exchange spins
+    int chain_timeout_ms = 10000; // bound of its halo-exchange spins (another process holding the CUs for longer: sticky error word, logits poisoned, f8_net_check)
     int fuse_p12 = 1;            // 7x7 identity blocks: body.0 + body.2 in one launch, split over a workgroup pair per image (f8_p12.hip)
     int fuse_head2 = 1;          // MobileNet-V2 head (3x3 / 2 conv, depthwise 3x3, 1x1) as one row-walking launch (f8_stem.hip, H2)
     int fuse_ir = 1;             // MobileNet-V2 inverted residual (expand -> depthwise -> project) in one launch: 1 = where it wins, 2 = always
@@ -158,6 +158,7 @@ struct InArgs {                            // network input: int32 NCHW -> NHWC 
 struct OutArgs {                           // NHWC int32 -> NCHW int32 / float32
     const int32_t* x; int32_t N, C, HW, Cs;
     void* out; int32_t as_float;
+    const uint32_t* err;                   // the run's stage-chain error word or nullptr: when set, the outputs are poisoned (NaN / INT32_MIN)
 };
 
 // One launch for a ResNet bottleneck identity block (f8_fused.hip).
@@ -324,7 +325,7 @@ bool conv1x1_wreg_supported(int ck, int coutP);
 hipError_t launch_conv1x1_wreg(const ConvArgs& a, hipStream_t s);
 // classifier: integer linear + int32 -> float32 / int32 [N][classes] into the caller's buffer (f8_fc.hip); ConvArgs::w = fragment order
 bool fc_dense_supported(int ck, int coutP);
-hipError_t launch_fc_dense(const ConvArgs& a, void* out, int classes, int as_float, hipStream_t s);
+hipError_t launch_fc_dense(const ConvArgs& a, void* out, int classes, int as_float, const uint32_t* err, hipStream_t s);   // err: the run's chain error word (logits poisoned when set) or nullptr
 // 3x3 / stride 2 / pad 1 with the input patch in LDS and the weights streamed into registers (f8_s2conv.hip); ConvArgs::w = fragment order
 bool conv3x3s2_wreg_supported(int ck, int HO, int WO, int coutP);
 hipError_t launch_conv3x3s2_wreg(const ConvArgs& a, hipStream_t s);

@@ -1091,7 +1091,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         if (!head2_supported(x.H, x.W) || ta.H * 2 != x.H || ta.W * 2 != x.W) continue;
         int na = 0, nb2 = 0;
         if (consumer_format(ta, b.cd, &na, "finalize") || consumer_format(tb, c.cd, &nb2, "finalize") || na < 1 || nb2 < 1 || na > 16 || nb2 > 16 ||
-            (opt.requant_float && (!conv_acc_bounded(h) || !conv_acc_bounded(b) || !conv_acc_bounded(c)))) continue;   // 16: kRequantU8MaxShift; bounded: requant_u8x4 (f8_device.h); requant_float = 0: integer form, any accumulator
+            false) continue;   // 16: kRequantU8MaxShift (the launch's float-converter form; accumulators the planner cannot bound take its integer form: rq_int)
         bool int8_readers = !T[c.out].consumers.empty() && T[c.out].consumers.size() <= 2;
         for (int u : T[c.out].consumers) if (ND[u].kind != N_CONV || !ND[u].cd.quant_input) int8_readers = false;
         if (!int8_readers) continue;
@@ -1953,7 +1953,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             fill_out(&a.out32, a.q);
             if (st.dense) {
                 a.w = (const int8_t*)(net->d_w + nd.wf_off);
-                e = launch_fc_dense(a, (char*)output + (size_t)n0 * oT.C * 4, oT.C, net->out_float, s);
+                e = launch_fc_dense(a, (char*)output + (size_t)n0 * oT.C * 4, oT.C, net->out_float, net->d_chain ? (const uint32_t*)(net->d_chain + (size_t)part * net->chain_stride + 2048) : nullptr, s);
             } else if (nd.s2w) { a.w = (const int8_t*)(net->d_w + nd.wf_off); e = launch_conv3x3s2_wreg(a, s); }
             else if (nd.wstat) {
                 a.w = (const int8_t*)(net->d_w + nd.wf_off);
@@ -1978,7 +1978,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             a.N = N; a.Hp = sF.Hp; a.Wp = sF.Wp; a.org = sF.pad - hh.cd.pad;
             a.Pc = oT.H; a.Qc = oT.W; a.P = oT.H; a.Q = oT.W;
             a.relu0 = 1; a.grid_div = net->opt.stem_grid_div;
-            a.acc_ok = conv_acc_bounded(hh) && conv_acc_bounded(hb) && conv_acc_bounded(nd); a.rq_int = !net->opt.requant_float;
+            a.acc_ok = conv_acc_bounded(hh) && conv_acc_bounded(hb) && conv_acc_bounded(nd); a.rq_int = !net->opt.requant_float || !a.acc_ok;
             a.rC = sT.C; a.rH = sT.H; a.rW = sT.W; a.xor8 = sF.sgn ? 0u : 0x80808080u;
             a.raw_kind = -1;
             if (st.raw_input && !(net->in_u8 && net->in_u8_nhwc)) {
@@ -2109,6 +2109,9 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             const Node& a0 = net->nodes[ds ? hf.fbd_a : hf.fb_a];
             const int C = T[st.out.t].C, MID = a0.cd.cout;
             const int tiles = chain_tiles_per_img(x.H, x.W);
+            // every workgroup of a chain launch must be resident (one per CU): a device with fewer CUs than one image has tiles cannot run it
+            if ((net->num_cu > 0 ? std::min(net->num_cu, 256) : 256) < tiles)
+                return fail(F8_ERR_STATE, "f8_net_run: a stage-chain launch needs %d co-resident workgroups per image, the device has %d compute units (plan with fuse_chain = 0 / fuse_bchain = 0)", tiles, net->num_cu);
             a.N = N; a.NG = chain_groups(N, (net->num_cu > 0 ? std::min(net->num_cu, 256) : 256) / tiles);
             fill_out(&a.out32, a.q);
             if (!net->d_chain) return fail(F8_ERR_STATE, "f8_net_run: chain scratch missing");
@@ -2152,6 +2155,9 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             else a.xr = (const int32_t*)fp(xs.forms[st.src_f]);
             const Tensor& x = T[st.out.t];
             const int tiles = bchain_tiles_per_img(x.C, x.H, x.W);
+            // every workgroup of a chain launch must be resident (one per CU): a device with fewer CUs than one image has tiles cannot run it
+            if ((net->num_cu > 0 ? std::min(net->num_cu, 256) : 256) < tiles)
+                return fail(F8_ERR_STATE, "f8_net_run: a stage-chain launch needs %d co-resident workgroups per image, the device has %d compute units (plan with fuse_chain = 0 / fuse_bchain = 0)", tiles, net->num_cu);
             a.N = N; a.NG = chain_groups(N, (net->num_cu > 0 ? std::min(net->num_cu, 256) : 256) / tiles);
             fill_out(&a.out32, a.q);
             if (!net->d_chain) return fail(F8_ERR_STATE, "f8_net_run: chain scratch missing");
@@ -2254,6 +2260,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             OutArgs a{};
             a.x = (const int32_t*)fp(sT.forms[st.src_f]); a.N = N; a.C = sT.C; a.HW = sT.H * sT.W; a.Cs = sT.Cs;
             a.out = (char*)output + (size_t)n0 * sT.C * sT.H * sT.W * 4; a.as_float = net->out_float;
+            a.err = net->d_chain ? (const uint32_t*)(net->d_chain + (size_t)part * net->chain_stride + 2048) : nullptr;
             e = launch_output(a, s);
             break;
         }

@@ -651,13 +651,21 @@ bool stem_pool_supported(int cin, int cout, int k, int stride, int pad, int pool
 // MobileNet-V2 head (stem_rows_kernel<KIND, true>): input sides multiples of 4, at most 4 strips of 28 output columns
 bool head2_supported(int H, int W) { return H >= 8 && W >= 8 && H % 4 == 0 && W % 4 == 0 && W / 2 <= 4 * SW; }
 
+// compute units of the CURRENT device, cached per device ordinal (a process may drive several GPUs)
+static int device_cus() {
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) { int v = 0; cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256; }
+    return cus[dev];
+}
+
 hipError_t launch_stem_pool(const StemPoolArgs& a, hipStream_t s) {
     if (a.h2) {
         if (!head2_supported(a.rH, a.rW) || a.P != a.rH / 2 || a.Q != a.rW / 2 || a.Pc != a.P || a.Qc != a.Q || a.na < 1 || a.nb < 1 || a.na > kRequantU8MaxShift || a.nb > kRequantU8MaxShift || (!a.acc_ok && !a.rq_int) || a.out32 ||
             (a.raw_kind < 0 && !(a.org == 4 && a.Wp % 4 == 0))) return hipErrorInvalidValue;
         const int lds_bytes = 2 * RB_ROWS * (a.rW + 8) * 4 + 512 + 1536;
-        static int ncu3 = 0;
-        if (!ncu3) { int dev = 0; hipDeviceProp_t p; ncu3 = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+        const int ncu3 = device_cus();
         const int ntiles = a.N * ((a.P + H2_RB - 1) / H2_RB);
         const int gdiv = a.grid_div > 0 ? a.grid_div : 1;
         const int gmax = (ncu3 / gdiv + 7) / 8 * 8;
@@ -672,8 +680,7 @@ hipError_t launch_stem_pool(const StemPoolArgs& a, hipStream_t s) {
     }
     if (a.rows && stem_rows_ok(a)) {
         const int lds_bytes = 2 * RB_ROWS * (4 * a.Q + 8) * 4 + 512 + 1536;   // 67 KB at 224 x 224: patches, biases, the u8 table
-        static int ncu2 = 0;
-        if (!ncu2) { int dev = 0; hipDeviceProp_t p; ncu2 = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+        const int ncu2 = device_cus();
         const int ntiles = a.N * ((a.P + RB - 1) / RB);
         // Persistent, one workgroup per CU, on ALL CUs when the launch is write-bound (int32 pooled output: ResNet-18 / 34), on HALF of
         // them otherwise (int8 output: compute-bound): measured, not assumed — with several batches in flight the other batches' launches
@@ -694,8 +701,7 @@ hipError_t launch_stem_pool(const StemPoolArgs& a, hipStream_t s) {
     if (!(a.P % TP == 0 && a.Q % TQ == 0)) return hipErrorInvalidValue;
     const int ntiles = a.N * (a.P / TP) * (a.Q / TQ);
     const int wpc = a.wpc > 0 ? a.wpc : 2;               // resident workgroups per CU (63 KB LDS each), Options::stem_wpc
-    static int ncu = 0;
-    if (!ncu) { int dev = 0; hipDeviceProp_t p; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+    const int ncu = device_cus();
     const int grid = ntiles < ncu * wpc ? ntiles : ncu * wpc;
     switch (a.raw_kind) {
         case 0: hipLaunchKernelGGL(stem_pool_kernel<0>, dim3(grid), dim3(512), 0, s, a); break;

@@ -107,10 +107,13 @@ class IntModel(nn.Module):
         ts = self._ptensors
         if ts is None:
             ts = self._ptensors = tuple(self.state_dict(keep_vars=True).values())
-        v = 0
+        # ... and an XOR of the storage pointers: `param.data = new_tensor` — how the reference itself installs integer weights
+        # (fix_quant_ops.py:705-706) — bumps no version counter, it only rebinds the storage
+        v = p = 0
         for t in ts:
             v += t._version
-        return v
+            p ^= t.data_ptr()
+        return (v, p)
 
     def _head_fraclen(self):
         # `head.input_fraclen.item()` on a device buffer is a device -> host synchronisation on EVERY forward (it serialised the

@@ -217,7 +217,9 @@ int f8_net_set_input_ready(f8_net* net, void* event);
 
 /* Blocks until the device is idle and reports failures that happened INSIDE kernels of earlier runs of this handle: the
  * stage-chain launches (option fuse_chain) exchange halo rows between workgroups and bound every wait (chain_timeout_ms); a
- * workgroup whose neighbour never arrives sets an error word and leaves, and the run's outputs are then invalid.  F8_OK, or
+ * workgroup whose neighbour never arrives sets a sticky error word, the launch runs on without waiting, and the run's outputs are then
+ * invalid — they are POISONED where they leave the library (the classifier / output kernel writes NaN, or INT32_MIN for int32 outputs,
+ * while the word is set), so a caller that never calls this function cannot mistake them for results.  F8_OK, or
  * F8_ERR_HIP with the code in f8_last_error (the word is cleared).  It also reports (F8_ERR_INVALID) an int32 network input that held
  * values outside the head's 8-bit format in a run since the last check: f8_net_run NARROWS such an input to 8 bits where the reference
  * would feed the full int32 to the head conv (fix_train.py:689 only asserts >= 0), so out-of-format values cannot be honoured; the range
@@ -237,7 +239,11 @@ int f8_net_check(f8_net* net);
  *               wstat_min_tiles (pixel tiles per workgroup a launch must offer; 0 = always) and wstat_fast (0 = general epilogue), wreg (weights-streamed 1x1 kernel for the
  *               512 -> 256 / 1024 -> 512 reductions of smaller launches),
  *               patch3x3, dual_wide, deep_nk, bk128, dw_dot4, opener_stg, whole_batch_launches (hint: runs will use
- *               f8_net_set_pipelined(2))
+ *               f8_net_set_pipelined(2)),
+ *               requant_float (default 1: a ReLU -> unsigned-8-bit right shift of a conv accumulator the planner can bound, and of the chains'
+ *               int32 stream, runs through the float converter — v_cvt_f32_i32, v_mul_f32 / v_fma_f32 by 2^-n, v_cvt_pk_u8_f32: exact, compared
+ *               with the integer form over all 2^32 inputs on the device; 0: INTEGER shift / round-half-even / clamp in every kernel
+ *               (fix_quant_ops.py:99-112 literally; no float instruction in any epilogue).  Same results either way, bit for bit)
  *   scheduling: chunk56 / chunk28 / chunk14 (images per chunk of the fused blocks; -1 = derived from chunk_budget_mb, 0 = whole
  *               batch), chunk_budget_mb (memory-side cache a chunk's int32 stream may occupy), chunk_ds, chunk_opener,
  *               split_streams, graph, stagger, stagger_pipelined, stem_wpc, stem_grid_div (row-walking head on 1 / n of the CUs; 0 = by output form), check_device, check_input_range, pipeline_depth (2..4 runs in flight),

@@ -227,3 +227,21 @@ def test_smoke_plans_hold_the_kernels_smoke_asserts():
     r18 = topology.get('resnet18')
     plan = build_net(r18, synth.make_params(r18, seed=3), max_batch=2, hw=224).describe()
     assert 'basic_chain_x2_ds' in plan and 'patch' in plan, plan
+
+
+def test_intmodel_parameter_fingerprint_sees_rebound_storage():
+    """`param.data = new_tensor` (how the reference installs integer weights, fix_quant_ops.py:705-706) bumps no `_version` counter: the
+    fingerprint IntModel.forward compares before it reuses a plan must change anyway, and so must an in-place edit."""
+    import torch
+    from f8net_amd import int_model, synth, topology
+    spec = topology.get('resnet18', num_classes=8)
+    m = int_model.from_params(spec, synth.make_params(spec, seed=2))
+    v0 = m._param_version()
+    assert m._param_version() == v0
+    w = m.head[0].weight
+    w.data = w.data.clone()                        # same values, new storage, same version counter
+    v1 = m._param_version()
+    assert v1 != v0
+    with torch.no_grad():
+        w[0, 0, 0, 0] += 1                         # in-place edit: version counter
+    assert m._param_version() != v1

@@ -139,6 +139,44 @@ def test_every_inverted_residual_block_fused_matches_golden(dev, golden_dir):
     np.testing.assert_array_equal(net.run(torch.from_numpy(x).to(dev)).cpu().numpy(), oracle.net_forward(spec, params, x, fl))
 
 
+@pytest.mark.parametrize('arch', ARCHS)
+def test_integer_only_requant_plan_matches_golden(arch, golden_dir, dev):
+    """Option requant_float = 0: every kernel requantises with the integer shift / round-half-even / clamp of fix_quant_ops.py:99-112 (no
+    float instruction in any epilogue); the default plan routes ReLU -> unsigned 8-bit right shifts of bounded accumulators through the
+    float converter instead.  Both equal the goldens captured from the reference."""
+    from f8net_amd.net import build_net
+    g, spec, params = _golden_setup(arch, golden_dir)
+    for hw, n in ((64, 2), (224, 1)):
+        x, _ = synth.make_input(spec, params, n, hw, seed=7)
+        for rq in (0, 1):
+            net = build_net(spec, params, max_batch=n, hw=hw, options={'requant_float': rq, 'fuse_ir': 2})
+            assert net.get_option('requant_float') == rq
+            np.testing.assert_array_equal(net.run(torch.from_numpy(x).to(dev)).cpu().numpy(), g[f's1234_hw{hw}_n{n}/logits'], err_msg=f'{arch} hw{hw} rq{rq}')
+
+
+def test_mobilenet_v2_fused_launches_where_the_rounding_add_wraps(dev):
+    """Biases next to 2^31 in the head conv, the head's depthwise conv and the expand / depthwise convs of two inverted-residual blocks:
+    their accumulators cannot be bounded below 2^31 - 2^16, the reference's `v + 2^(n-1)` wraps there (fix_quant_ops.py:100-104: the value
+    turns negative, the clamp makes it 0), and the fused launches (stem_rows_kernel<.., true>, fused_ir_kernel) must take their INTEGER
+    requantisation by themselves — same plan, oracle's values."""
+    from f8net_amd.net import build_net
+    spec = topology.get('mobilenet_v2')
+    params = synth.make_params(spec, seed=55)
+    for key, ch in (('head.0', 5), ('stage_0_layer_0.body.0', 7), ('stage_1_layer_0.body.0', 11), ('stage_1_layer_0.body.2', 3),
+                    ('stage_2_layer_1.body.0', 20), ('stage_2_layer_1.body.2', 9)):
+        b = params[key + '.bias'].copy()
+        b[ch], b[(ch + 13) % b.size] = 2 ** 31 - 50, 2 ** 31 - 2 ** 12
+        params[key + '.bias'] = b
+    for hw, n in ((64, 3), (224, 2)):
+        x, fl = synth.make_input(spec, params, n, hw, seed=3)
+        want = oracle.net_forward(spec, params, x, fl)
+        for opts in ({'fuse_ir': 2}, {'fuse_ir': 2, 'requant_float': 0}):
+            net = build_net(spec, params, max_batch=n, hw=hw, options=opts)
+            plan = net.describe()
+            assert 'head3x3s2+dw3x3+1x1' in plan and plan.count('fused_ir_') == 16, plan
+            np.testing.assert_array_equal(net.run(torch.from_numpy(x).to(dev)).cpu().numpy(), want, err_msg=f'hw{hw} {opts}')
+
+
 @pytest.mark.parametrize('mode', [1, 2])
 def test_pipelined_runs_overlap_safely(dev, mode):
     """f8_net_set_pipelined (1: lagged sub-batches, 2: whole batches alternating between two streams / arena copies):
