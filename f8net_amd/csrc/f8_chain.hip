@@ -32,8 +32,9 @@
 
 namespace f8 {
 
-template <int C, int MID, int W, int H, int R, int CIN0>
+template <int C, int MID, int W, int H, int R, int CIN0, int MAXB_ = kChainMaxBlocks>
 struct ChainCfg {
+    static constexpr int MAXB = MAXB_;                         // blocks whose biases fit the instance's LDS
     static constexpr int T = (H + R - 1) / R;                  // tiles (workgroups) per image
     static constexpr int PX = R * W, NPT = (PX + 31) / 32, ROWS = NPT * 32;
     static constexpr int PW = W + 2, PR = R + 2;
@@ -46,7 +47,7 @@ struct ChainCfg {
     static constexpr int MID2_BYTES = ROWS * MS;
     static constexpr int XIN_BYTES = CIN0 != C ? ROWS * IS : 0;
     static constexpr int BIAS_INTS = 2 * MID + C;              // per block: b0 | b2 | b4
-    static constexpr int BIAS_BYTES = (kChainMaxBlocks * BIAS_INTS + (CIN0 != C ? C : 0)) * 4;   // + bsc of the stage-opening block
+    static constexpr int BIAS_BYTES = (MAXB * BIAS_INTS + (CIN0 != C ? C : 0)) * 4;   // + bsc of the stage-opening block
     static constexpr int MISC_BYTES = 256;
     static constexpr int LDS_BYTES = X8_BYTES + PATCH_BYTES + MID2_BYTES + XIN_BYTES + BIAS_BYTES + MISC_BYTES;
     static constexpr int ROWB = W * MID;                       // one exchanged row of mid1
@@ -88,11 +89,17 @@ __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+s"(v)); retur
 // FAST: every block has ReLU after body.0 / body.2 / the join, every int8 format of the chain is unsigned with a right shift, and the
 // stream itself is never shifted (res_shl == 0) — true for the real fraclen tables; the generic instance takes everything else.
 // ROT: rotate the K order per (workgroup, wave) in coarse groups (L2-bound instance: all workgroups stream the same weights).
-template <int C, int MID, int W, int H, int R, int CIN0, int NB, int NBUF, int FAST, bool ROT>
+// TAIL (round 4): the first block is only the JOIN of a stage-opening block whose 3x3 and shortcut have stride 2 (fix_resnet.py:55-77): body.0 and
+// body.2 ran in f8_opener.hip (P12) and left mid2 in HBM; here the tile loads mid2 and the shortcut's operand (pixels (2p, 2q) of the block input,
+// CIN0 channels) into LDS and computes  stream = clamp(((Wsc . x + bsc) << sa) + ((W4 . mid2 + b4) << sr)) [ReLU]  straight into the stream
+// registers, weights streamed — the block's int32 output (205 MB per 128 images in ResNet-50's stage 1) is neither written nor read back.
+template <int C, int MID, int W, int H, int R, int CIN0, int NB, int NBUF, int FAST, bool ROT, bool TAIL = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 chain_kernel(const ChainArgs a) {
-    using Cfg = ChainCfg<C, MID, W, H, R, CIN0>;
+    using Cfg = ChainCfg<C, MID, W, H, R, CIN0, TAIL ? 4 : kChainMaxBlocks>;
+    constexpr int MAXB = Cfg::MAXB;
     constexpr bool DS0 = CIN0 != C;
+    static_assert(!TAIL || (DS0 && ((H + R - 1) / R * R == H) && ((R * W + 31) / 32) % 2 == 0), "TAIL: an opening block; whole tiles, an even number of pixel tiles");
     constexpr int T = Cfg::T, NPT = Cfg::NPT, PW = Cfg::PW, ROWB = Cfg::ROWB, BIAS_INTS = Cfg::BIAS_INTS;
     constexpr int XS = Cfg::XS, MS = Cfg::MS, IS = Cfg::IS;
     constexpr int CT = C / 32, CM = MID / 32, CTW = CT / 8;
@@ -106,6 +113,10 @@ chain_kernel(const ChainArgs a) {
     // neighbours' rows are waited for and fetched only in front of the first tap that needs one: the flag's and the rows' round trips
     // through the fabric (~2 x 1 us) run under a third of the 3x3.  (Round 3 could not afford the consume point inside the unrolled K
     // loop: the kernel was at 256 registers; the weight streams as buffer loads and the peeled opening block freed 25-55.)
+    // Tried on top and NOT kept (round 4): cutting the 3x3 by pixel tile as well — a wave's first tile never holds the tile's last row, its
+    // second never the first, so two thirds of the MFMAs can run before the rows are needed, with the rows requested after the first third
+    // and written to the patch after the second.  Bit-exact, no spills, and slower on every instance (same box, us per 128 images: 245 -> 257,
+    // 192 -> 205, 222 -> 248): the top / bottom taps' weight fragments are then loaded twice and feed ONE MFMA each.
 #ifndef F8_CH_EARLY
 #define F8_CH_EARLY 1
 #endif
@@ -151,9 +162,9 @@ chain_kernel(const ChainArgs a) {
     for (int b = 0; b < a.nblk; ++b) {
         const ChainBlk& B = a.blk[b];
         for (int i = tid; i < BIAS_INTS; i += 512)
-            bias_lds[b * BIAS_INTS + i] = i < MID ? B.b0[i] : (i < 2 * MID ? B.b2[i - MID] : B.b4[i - 2 * MID]);
+            bias_lds[b * BIAS_INTS + i] = i < 2 * MID ? ((TAIL && b == 0) ? 0 : (i < MID ? B.b0[i] : B.b2[i - MID])) : B.b4[i - 2 * MID];
     }
-    if constexpr (DS0) for (int i = tid; i < C; i += 512) bias_lds[kChainMaxBlocks * BIAS_INTS + i] = a.blk[0].bsc[i];
+    if constexpr (DS0) for (int i = tid; i < C; i += 512) bias_lds[MAXB * BIAS_INTS + i] = a.blk[0].bsc[i];
     __syncthreads();
     const int L = __builtin_amdgcn_readfirstlane(misc[0]);
     const int grp = L / T, ti = L - grp * T;
@@ -214,6 +225,17 @@ chain_kernel(const ChainArgs a) {
     auto w2_prime = [&](const int8_t* w2, unsigned wl) {
         static_for<NBUF - 1>([&](auto bc) { constexpr int Bi = decltype(bc)::value; w2_load(w2, wbuf[Bi], Bi, wl); });
     };
+    // TAIL: fragments of the join in use order: per channel tile I of this wave, per PAIR of pixel tiles, KS shortcut steps then KK body.4 steps
+    constexpr int KT2 = KS + KK, NPAIR = NPT / 2, NFRT = CTW * NPAIR * KT2, NBT = NFRT / NB;
+    auto wt_load = [&](const int8_t* wsc, const int8_t* w4, v4i (&dst)[NB], auto bic, unsigned wl) {
+        constexpr int BI = decltype(bic)::value;
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+            constexpr int dummy = 0; (void)dummy;
+            const int f = BI * NB + s, I = f / (NPAIR * KT2), k = f % KT2;
+            dst[s] = k < KS ? ldw(wsc, (I * KS + k) * 1024, (unsigned)(wave * CTW * KS * 1024) + wl) : ldw(w4, (I * KK + (k - KS)) * 1024, (unsigned)(wave * CTW * KK * 1024) + wl);
+        }
+    };
     // the MFMAs of a step must not be scheduled above the LDS reads of the NEXT step that are issued just before them
     auto pin = [](auto& xf) {
 #pragma unroll
@@ -226,7 +248,31 @@ chain_kernel(const ChainArgs a) {
         // =====================================================================================
         // stage input -> registers (identity first block) / LDS (stage-opening first block)
         // =====================================================================================
-        if constexpr (!DS0) {
+        if constexpr (TAIL) {
+            static_assert(KT2 % NB == 0 && KS % NB == 0 && NPT % 2 == 0, "TAIL: whole batches per K loop, pixel-tile pairs");
+            // xin <- the shortcut's operand: pixels (2 (p0 + r), 2 c) of the block input (2H x 2W, CIN0 channels); mid2 <- body.2's output
+            constexpr int CHX = CIN0 / 16, CHM = MID / 16, NX = NPT * 32 * CHX / 512, NM = NPT * 32 * CHM / 512;
+            static_assert((NPT * 32 * CHX) % 512 == 0 && (NPT * 32 * CHM) % 512 == 0, "whole passes");
+            int tq0 = tid; asm volatile("" : "+v"(tq0));
+            v4i vx[NX], vm[NM];
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {
+                const int idx = tq0 + k * 512, row = idx / CHX, c16 = idx % CHX, pr = row / W, pc = row - pr * W;
+                vx[k] = v4i{0, 0, 0, 0};
+                if (row < npx) vx[k] = *(const v4i*)(a.x8in + ((size_t)(n * 2 * H + 2 * (p0 + pr)) * (2 * W) + 2 * pc) * CIN0 + c16 * 16);
+            }
+#pragma unroll
+            for (int k = 0; k < NM; ++k) {
+                const int idx = tq0 + k * 512, row = idx / CHM, c16 = idx % CHM;
+                vm[k] = v4i{0, 0, 0, 0};
+                if (row < npx) vm[k] = *(const v4i*)(a.m2in + (size_t)(m_tile + row) * MID + c16 * 16);
+            }
+            { F8_LANES; static_for<(NBUF - 1 < NBT ? NBUF - 1 : NBT)>([&](auto bc) { constexpr int Bi = decltype(bc)::value; wt_load(a.blk[0].wsc, a.blk[0].w4, wbuf[Bi], bc, wl16); }); }
+#pragma unroll
+            for (int k = 0; k < NX; ++k) { const int idx = tq0 + k * 512; *(v4i*)(xin + (idx / CHX) * IS + (idx % CHX) * 16) = vx[k]; }
+#pragma unroll
+            for (int k = 0; k < NM; ++k) { const int idx = tq0 + k * 512; *(v4i*)(mid2 + (idx / CHM) * MS + (idx % CHM) * 16) = vm[k]; }
+        } else if constexpr (!DS0) {
             F8_LANES;
             const ChainBlk& B0 = a.blk[0];
             const __amdgpu_buffer_rsrc_t rxr = __builtin_amdgcn_make_buffer_rsrc((void*)a.xr, 0, (unsigned)(((a.N * H * W + 31) & ~31) * C * 4), 0x00020000);
@@ -272,10 +318,11 @@ chain_kernel(const ChainArgs a) {
         // opening-block instance spilled 144 bytes per lane that way (179 MB of scratch write-back per launch at the counters).
         auto block = [&](const int b, auto dsc) {
             {
-                ++seq;
+                constexpr bool TAILB = decltype(dsc)::value == 2;   // 0: identity block, 1: stage-opening block (same resolution), 2: only the join of one (TAIL)
+                if constexpr (!TAILB) ++seq;
                 const ChainBlk& B = a.blk[b];
                 const int* const bl = bias_lds + b * BIAS_INTS;
-                constexpr bool DSB = decltype(dsc)::value;      // this block is the stage-opening block (first block of a DS0 chain)
+                constexpr bool DSB = decltype(dsc)::value != 0; // this block is the stage-opening block (first block of a DS0 chain)
                 constexpr int NK1B = DSB ? KS : NK1;
                 constexpr bool ROT1 = ROT && !DSB;
                 // the block's scalars, read once (FAST: formats are unsigned with a right shift, ReLUs present, the stream unshifted)
@@ -292,6 +339,27 @@ chain_kernel(const ChainArgs a) {
                 const int loq = FAST ? 0 : (last ? a.q[0].lo : BN.loq), hiq = FAST ? 255 : (last ? a.q[0].hi : BN.hiq);
                 const unsigned xorq = FAST ? 0x80808080u : (last ? a.q[0].bias_xor : BN.xorq);
 
+                // this wave's P3 weights (WSTAT): requested when P2's K loop is over, so they travel during its epilogue
+                constexpr int K0 = DSB ? KS : 0, KT = KK + K0;  // opening block: the shortcut's K steps come first
+                v4i wst[(WSTAT && !TAILB) ? CTW * KT : 1];
+                auto wst_load = [&](unsigned wl) {
+                    if constexpr (WSTAT && !TAILB) {
+#pragma unroll
+                        for (int i = 0; i < CTW; ++i) {
+                            if constexpr (DSB) {
+#pragma unroll
+                                for (int k = 0; k < KS; ++k) wst[i * KT + k] = ldw(pwsc, (i * KS + k) * 1024, (unsigned)(wave * CTW * KS * 1024) + wl);
+                            }
+#pragma unroll
+                            for (int k = 0; k < KK; ++k) wst[i * KT + K0 + k] = ldw(pw4, (i * KK + k) * 1024, (unsigned)(wave * CTW * KK * 1024) + wl);
+                        }
+                    }
+                };
+                auto w3_load = [&](v4i (&dst)[NB], int qi, unsigned wl) {      // streamed P3: batch qi of this wave's CTW consecutive channel tiles
+#pragma unroll
+                    for (int s = 0; s < NB; ++s) dst[s] = ldw(pw4, (qi * NB + s) * 1024, (unsigned)(wave * CTW * KK * 1024) + wl);
+                };
+                if constexpr (!TAILB) {
                 // ============================ P1: mid1 = requant(relu(W0 . x8 + b0)) -> patch interior   (its first weight batches are in flight)
                 {
                     F8_LANES_P12;
@@ -402,6 +470,9 @@ chain_kernel(const ChainArgs a) {
                         // launch RUNS ON without waiting any more — here and in every other workgroup, which see the word in their own polls.
                         // (An early return from the middle of the block loop gave the loop a second exit and the opening-block instance a
                         // second copy of the 112 stream registers at the loop header: 56 v_mov_b64 per block and its spills.)
+#ifdef F8_CH_ABL_NOPOLL         // tuning build (results invalid): the neighbours' rows are taken as they are
+                        if (false)
+#endif
                         while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
                             __builtin_amdgcn_s_sleep(2);
                             if (wall_clock64() - t0 > t_limit) { ok = false; break; }
@@ -424,27 +495,6 @@ chain_kernel(const ChainArgs a) {
                 F8_CT(2);
 
                 // ============================ P2: mid2 = requant(relu(conv3x3(mid1) + b2)) -> mid2
-                // this wave's P3 weights (WSTAT): requested when P2's K loop is over, so they travel during its epilogue
-                constexpr int K0 = DSB ? KS : 0, KT = KK + K0;  // opening block: the shortcut's K steps come first
-                v4i wst[WSTAT ? CTW * KT : 1];
-                auto wst_load = [&](unsigned wl) {
-                    if constexpr (WSTAT) {
-#pragma unroll
-                        for (int i = 0; i < CTW; ++i) {
-                            const int ct = wave * CTW + i;
-                            if constexpr (DSB) {
-#pragma unroll
-                                for (int k = 0; k < KS; ++k) wst[i * KT + k] = ldw(pwsc, (i * KS + k) * 1024, (unsigned)(wave * CTW * KS * 1024) + wl);
-                            }
-#pragma unroll
-                            for (int k = 0; k < KK; ++k) wst[i * KT + K0 + k] = ldw(pw4, (i * KK + k) * 1024, (unsigned)(wave * CTW * KK * 1024) + wl);
-                        }
-                    }
-                };
-                auto w3_load = [&](v4i (&dst)[NB], int qi, unsigned wl) {      // streamed P3: batch qi of this wave's CTW consecutive channel tiles
-#pragma unroll
-                    for (int s = 0; s < NB; ++s) dst[s] = ldw(pw4, (qi * NB + s) * 1024, (unsigned)(wave * CTW * KK * 1024) + wl);
-                };
                 {
                     F8_LANES_P12;
                     v16i acc[NPW];
@@ -505,6 +555,7 @@ chain_kernel(const ChainArgs a) {
                 }
                 F8_CT(3);
                 __syncthreads();                                // mid2 is complete; nobody reads the patch any more
+                }   // !TAILB
 
                 // ============================ P3: stream' = clamp((W4 . mid2 + b4) << sa + (stream << sr)) [ReLU]; x8' = requant(stream')
                 {
@@ -516,6 +567,9 @@ chain_kernel(const ChainArgs a) {
                         const int ct = wave * CTW + I;
                         const int pix = PT * 32 + l31;
                         v16i& rr = res[PT][I];
+#ifdef F8_CH_ABL_NOFIN          // tuning build (results invalid): no join, no requantisation — what P3 costs without its vector work
+                        { const v4i o = {acc[0] ^ rr[0], acc[5], acc[10], acc[15]}; *(v4i*)(x8 + xlane + PT * 32 * XS + ct * 32) = o; (void)pix; (void)floor1; return; }
+#endif
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             // identity: (body.4 << acc_shl) + (stream << res_shl); opening block: (shortcut << acc_shl) + (body.4 << res_shl)
@@ -552,7 +606,48 @@ chain_kernel(const ChainArgs a) {
                             for (int e = 0; e < 4; ++e) acc[4 * g + e] = bv[e];
                         }
                     };
-                    if constexpr (WSTAT) {
+                    if constexpr (TAILB) {
+                        // the join of the stride-2 opening block: per channel tile I and pair of pixel tiles, KS shortcut steps (B: xin) into the
+                        // stream registers (they are born here), KK body.4 steps (B: mid2) into acc; weights streamed (each fragment twice)
+                        auto rdt = [&](v4i (&xf)[2], auto gc) {
+                            constexpr int G = decltype(gc)::value, H2 = (G / KT2) % NPAIR, K = G % KT2;
+                            if constexpr (K < KS) { xf[0] = *(const v4i*)(xin + ilane + (2 * H2) * 32 * IS + K * 32); xf[1] = *(const v4i*)(xin + ilane + (2 * H2 + 1) * 32 * IS + K * 32); }
+                            else { xf[0] = *(const v4i*)(mid2 + mlane + (2 * H2) * 32 * MS + (K - KS) * 32); xf[1] = *(const v4i*)(mid2 + mlane + (2 * H2 + 1) * 32 * MS + (K - KS) * 32); }
+                        };
+                        v4i xfa[2], xfb[2];
+                        v16i acc[2];
+                        rdt(xfa, std::integral_constant<int, 0>{});
+                        static_for<NFRT>([&](auto gc) {
+                            constexpr int G = decltype(gc)::value, I = G / (NPAIR * KT2), H2 = (G / KT2) % NPAIR, K = G % KT2, Bi = G / NB, S = G % NB;
+                            const int ct = wave * CTW + I;
+                            if constexpr (S == 0 && Bi + NBUF - 1 < NBT) wt_load(pwsc, pw4, wbuf[(Bi + NBUF - 1) % NBUF], std::integral_constant<int, Bi + NBUF - 1>{}, wl16);
+                            if constexpr (K == 0) {
+                                bias_init(acc[0], ct); acc[1] = acc[0];
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) {
+                                    const v4i bs = *(const v4i*)(bias_lds + MAXB * BIAS_INTS + ct * 32 + 8 * g + 4 * lh);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) { res[2 * H2][I][4 * g + e] = bs[e]; res[2 * H2 + 1][I][4 * g + e] = bs[e]; }
+                                }
+                            }
+                            v4i (&cur)[2] = (G & 1) ? xfb : xfa;
+                            v4i (&nxt)[2] = (G & 1) ? xfa : xfb;
+                            if constexpr (G + 1 < NFRT) rdt(nxt, std::integral_constant<int, G + 1>{});
+                            pin(cur);
+                            if constexpr (K < KS) {
+                                res[2 * H2][I] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Bi % NBUF][S], cur[0], res[2 * H2][I], 0, 0, 0);
+                                res[2 * H2 + 1][I] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Bi % NBUF][S], cur[1], res[2 * H2 + 1][I], 0, 0, 0);
+                            } else {
+                                acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Bi % NBUF][S], cur[0], acc[0], 0, 0, 0);
+                                acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Bi % NBUF][S], cur[1], acc[1], 0, 0, 0);
+                            }
+                            if constexpr (K == KT2 - 1) {
+                                if constexpr (G == NFRT - 1) { if (!last) w1_prime(pw0n, std::integral_constant<int, NK1>{}, wl16); }
+                                finish(std::integral_constant<int, 2 * H2>{}, std::integral_constant<int, I>{}, acc[0]);
+                                finish(std::integral_constant<int, 2 * H2 + 1>{}, std::integral_constant<int, I>{}, acc[1]);
+                            }
+                        });
+                    } else if constexpr (WSTAT) {
                         // one pixel tile at a time; the wave's weights (CTW x KT fragments) stay in registers; B fragments one step ahead
                         constexpr int NST = NPT * CTW * KT;
                         auto rd = [&](v4i& xf, auto gc) {
@@ -571,7 +666,7 @@ chain_kernel(const ChainArgs a) {
                                 if constexpr (DSB) {    // the shortcut product accumulates straight into the stream registers (they are born here)
 #pragma unroll
                                     for (int g = 0; g < 4; ++g) {
-                                        const v4i bs = *(const v4i*)(bias_lds + kChainMaxBlocks * BIAS_INTS + ct * 32 + 8 * g + 4 * lh);
+                                        const v4i bs = *(const v4i*)(bias_lds + MAXB * BIAS_INTS + ct * 32 + 8 * g + 4 * lh);
 #pragma unroll
                                         for (int e = 0; e < 4; ++e) res[PT][I][4 * g + e] = bs[e];
                                     }
@@ -625,8 +720,9 @@ chain_kernel(const ChainArgs a) {
                 __syncthreads();                                // x8 is complete (the next block's P1 reads it); mid2 may be rewritten
             }
         };
-        if constexpr (DS0) block(0, std::true_type{});
-        for (int b = DS0 ? 1 : 0; b < a.nblk; ++b) block(b, std::false_type{});
+        if constexpr (TAIL) block(0, std::integral_constant<int, 2>{});
+        else if constexpr (DS0) block(0, std::integral_constant<int, 1>{});
+        for (int b = DS0 ? 1 : 0; b < a.nblk; ++b) block(b, std::integral_constant<int, 0>{});
 
         // ---- the int8 copy of the stage output: LDS rows -> whole NHWC rows in HBM
         if (a.q[0].ptr) {
@@ -670,14 +766,18 @@ bool chain_supported(int C, int MID, int H, int W, int cin0) {
     if (C == 1024 && MID == 256 && H == 14 && W == 14 && cin0 == 1024) return true;
     return false;
 }
+// ... starting with the JOIN of a stride-2 opening block (TAIL): H, W = the stage's resolution, cin0 = the block input's channels
+bool chain_tail_supported(int C, int MID, int H, int W, int cin0) { return C == 512 && MID == 128 && H == 28 && W == 28 && cin0 == 256; }
+int chain_max_blocks(int C, int MID, int H, int W, int cin0, bool tail) { (void)C; (void)MID; (void)H; (void)W; (void)cin0; return tail ? 4 : kChainMaxBlocks; }
 int chain_tiles_per_img(int H, int W) { (void)W; return (H + 3) / 4; }
 
-template <int C, int MID, int W, int H, int R, int CIN0, int NB, int NBUF, int FAST, bool ROT>
+template <int C, int MID, int W, int H, int R, int CIN0, int NB, int NBUF, int FAST, bool ROT, bool TAIL = false>
 static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t s) {
-    using Cfg = ChainCfg<C, MID, W, H, R, CIN0>;
+    using Cfg = ChainCfg<C, MID, W, H, R, CIN0, TAIL ? 4 : kChainMaxBlocks>;
+    if (a.nblk > Cfg::MAXB) return hipErrorInvalidValue;
     static unsigned long long attr_done = 0; int attr_dev = -1;
     if (!dyn_lds_opted_in(&attr_done, &attr_dev)) {
-        hipError_t e = hipFuncSetAttribute((const void*)chain_kernel<C, MID, W, H, R, CIN0, NB, NBUF, FAST, ROT>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)chain_kernel<C, MID, W, H, R, CIN0, NB, NBUF, FAST, ROT, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
         if (attr_dev >= 0) attr_done |= 1ull << attr_dev;
     }
@@ -689,7 +789,7 @@ static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t s) {
     ChainArgs b = a;
     const bool tracing = (count++ == want);
     if (tracing) { if (!tbuf) (void)hipMalloc((void**)&tbuf, (size_t)1 << 19); (void)hipMemsetAsync(tbuf, 0, (size_t)grid * 1024, s); b.trace = tbuf; }
-    hipLaunchKernelGGL((chain_kernel<C, MID, W, H, R, CIN0, NB, NBUF, FAST, ROT>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, b);
+    hipLaunchKernelGGL((chain_kernel<C, MID, W, H, R, CIN0, NB, NBUF, FAST, ROT, TAIL>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, b);
     if (tracing) {
         (void)hipStreamSynchronize(s);
         static unsigned long long hb[256 * 8 * 16];
@@ -710,7 +810,7 @@ static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t s) {
     }
     return hipGetLastError();
 #else
-    hipLaunchKernelGGL((chain_kernel<C, MID, W, H, R, CIN0, NB, NBUF, FAST, ROT>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((chain_kernel<C, MID, W, H, R, CIN0, NB, NBUF, FAST, ROT, TAIL>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, a);
     return hipGetLastError();
 #endif
 }
@@ -751,6 +851,11 @@ hipError_t launch_chain(const ChainArgs& a, int C, int MID, int H, int W, int ci
     if (C == 256 && MID == 64 && H == 56 && W == 56 && cin0 == 64) return F8_CHAIN_INST(256, 64, 56, 56, 4, 64, F8_CH_S0);
     if (C == 256 && MID == 64 && H == 56 && W == 56 && cin0 == 256) return F8_CHAIN_INST(256, 64, 56, 56, 4, 256, F8_CH_S0);
     if (C == 512 && MID == 128 && H == 28 && W == 28 && cin0 == 512) return F8_CHAIN_INST(512, 128, 28, 28, 4, 512, F8_CH_S1);
+    if (C == 512 && MID == 128 && H == 28 && W == 28 && cin0 == 256 && a.tail) {
+        if (!a.m2in || !a.x8in) return hipErrorInvalidValue;
+        return fast == 1 ? launch_chain_t<512, 128, 28, 28, 4, 256, F8_CH_S1, 1, false, true>(a, s) : fast == 2 ? launch_chain_t<512, 128, 28, 28, 4, 256, F8_CH_S1, 2, false, true>(a, s)
+                                                                                                             : launch_chain_t<512, 128, 28, 28, 4, 256, F8_CH_S1, 0, false, true>(a, s);
+    }
 #undef F8_CHAIN_ROT
 #ifdef F8_CH_ROT
 #define F8_CHAIN_ROT true

@@ -26,6 +26,7 @@ struct Options {
     int wreg = 1;                // late 1x1 convs on conv1x1_wreg_kernel (weights straight to registers, f8_wreg.hip)
     int fuse_bchain = 2;         // consecutive BasicBlock identity blocks of a stage in ONE launch (f8_bchain.hip); 2: with the stage-opening block in front of them
     int fuse_chain = 1;          // all consecutive bottleneck blocks of a stage in ONE launch, int32 residual stream in registers (f8_chain.hip)
+    int fuse_tail = 1;           // ... and the JOIN of a stride-2 stage-opening block as the first block of its stage's chain (its body.0 + body.2 on f8_opener.hip, P12)
     int chain_timeout_ms = 10000; // bound of its halo-exchange spins (another process holding the CUs for longer: sticky error word, logits poisoned, f8_net_check)
     int fuse_p12 = 1;            // 7x7 identity blocks: body.0 + body.2 in one launch, split over a workgroup pair per image (f8_p12.hip)
     int fuse_head2 = 1;          // MobileNet-V2 head (3x3 / 2 conv, depthwise 3x3, 1x1) as one row-walking launch (f8_stem.hip, H2)
@@ -178,6 +179,8 @@ struct FusedArgs {
     void* trace;                           // tuning builds (F8_TRACE) only
     int32_t stride2;                       // stage-opening block with a stride-2 3x3 (f8_opener.hip): H, W are the INPUT map
     int32_t stg;                           // Options::opener_stg
+    int32_t p12only;                       // f8_opener.hip: body.0 + body.2 only, q[0] = body.2's output (NHWC int8, MID channels); the join runs as the
+                                           // first block of the stage's chain launch (ChainArgs::tail)
 };
 
 // One launch for ALL consecutive bottleneck blocks of a ResNet stage (f8_chain.hip): the int32 residual stream of a tile stays in
@@ -199,6 +202,10 @@ struct ChainArgs {
 
     const int32_t* xr;                     // first block an identity block: the stage's int32 stream (I32T) — its int8 form is computed in the launch
     const int8_t* x8in;                    // first block a stage-opening block: its int8 NHWC input [N*H*W][CIN0] in body.0's / the shortcut's format
+    // tail != 0: the first block is only the JOIN of a stage-opening block with a stride-2 3x3 (body.0 + body.2 ran in f8_opener.hip, P12):
+    // x8in = the block input at TWICE the resolution [N][2H][2W][CIN0] in the SHORTCUT's int8 format (its pixels (2p, 2q) are the 1x1 / 2
+    // shortcut's operand), m2in = body.2's output [N*H*W][MID] in body.4's int8 input format; blk[0] carries wsc / bsc / w4 / b4 / the join
+    const int8_t* m2in; int32_t tail;
     int32_t N, NG;                         // images; image groups resident at once (grid = NG * tiles per image)
     int32_t* out32; QuantOut q[2];         // forms of the last block's output
     uint32_t* sync;                        // [0] ticket, [16 + workgroup] halo flag; zeroed before every launch
@@ -310,6 +317,8 @@ hipError_t launch_fused_opener(const FusedArgs& a, hipStream_t s);
 // all consecutive bottleneck blocks of a stage in one launch, residual stream in registers (f8_chain.hip).  cin0 != C: the first
 // block is the stage-opening block at unchanged resolution (1x1 shortcut conv from cin0 channels).
 bool chain_supported(int C, int MID, int H, int W, int cin0);
+bool chain_tail_supported(int C, int MID, int H, int W, int cin0);   // ... a stride-2 opening block's join as the first block (H, W = the stage's resolution)
+int chain_max_blocks(int C, int MID, int H, int W, int cin0, bool tail);
 int chain_tiles_per_img(int H, int W);
 hipError_t launch_chain(const ChainArgs& a, int C, int MID, int H, int W, int cin0, hipStream_t s);
 // consecutive BasicBlock identity blocks of a stage in one launch (f8_bchain.hip)

@@ -92,6 +92,8 @@ struct Node {
     int bchain_into = -1;                // ... the host (second conv) of the chain's LAST block
     std::vector<int> bchain;             // host of the last block of a BasicBlock chain: the hosts of all its blocks (f8_bchain.hip)
     int p12_a = -1;                      // 3x3 conv hosting "1x1 -> 3x3 in one launch" (f8_p12.hip): its 1x1 producer
+    bool p12_s2 = false;                 // ... the 3x3 has stride 2: body.0 + body.2 of a stage-opening block on f8_opener.hip (P12); the block's join opens the stage's chain
+    bool tail = false;                   // shortcut conv (dual GEMM host) of such a block: its join runs as the FIRST block of a chain launch (ChainArgs::tail)
     int h2_head = -1, h2_dw = -1;        // 1x1 conv that ends the MobileNet-V2 head launch (f8_stem.hip, H2): its 3x3 / 2 head conv and its depthwise conv
     int ir_a = -1, ir_b = -1, ir_R = 0, ir_G = 0;   // project conv of a fused inverted-residual block: its expand / depthwise convs, tile
     int dual = -1;                     // 1x1 conv hosting a join whose other operand is ANOTHER 1x1 conv (node id): one dual-GEMM launch
@@ -249,6 +251,7 @@ static const OptKey kOptKeys[] = {
     {"fuse_head2", "F8_FUSE_HEAD2", &Options::fuse_head2, 0, 1, true},
     {"fuse_p12", "F8_FUSE_P12", &Options::fuse_p12, 0, 1, true},
     {"fuse_chain", "F8_FUSE_CHAIN", &Options::fuse_chain, 0, 1, true},
+    {"fuse_tail", "F8_FUSE_TAIL", &Options::fuse_tail, 0, 1, true},
     {"fuse_bchain", "F8_FUSE_BCHAIN", &Options::fuse_bchain, 0, 2, true},
     {"chain_timeout_ms", "F8_CHAIN_TIMEOUT_MS", &Options::chain_timeout_ms, 1, 1 << 20, false},
     {"wreg", "F8_WREG", &Options::wreg, 0, 1, true},
@@ -879,7 +882,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
     //          -> ONE launch for all of them, the int32 residual stream stays in registers (f8_chain.hip).  A chain may start with
     //          the stage-opening block at unchanged resolution (1d) and continues through identity blocks (1b).
     if (opt.fuse_chain && fuse_blocks) {
-        struct Blk { int host, in_t, out_t, C, MID, H, W, cin0; bool ds; };
+        struct Blk { int host, in_t, out_t, C, MID, H, W, cin0; bool ds; bool tail = false; };
         auto block_of = [&](int i, Blk* bk) -> bool {
             const Node& h = ND[i];
             if (h.kind != N_CONV || h.fused_add < 0 || h.chain_into >= 0) return false;
@@ -893,14 +896,23 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 *bk = Blk{i, h.a, ND[h.fused_add].out, h.cd.cout, a0.cd.cout, x.H, x.W, a0.cd.cin, true};
                 return true;
             }
+            if (h.fbd_a >= 0 && h.fbd_s2 && opt.fuse_tail) {
+                // stage-opening block with a stride-2 3x3 (1d fused it on f8_opener.hip): candidate for body.0 + body.2 there and the JOIN as the
+                // first block of the stage's chain (geometry of the chain = the block's OUTPUT map)
+                const Node& a0 = ND[h.fbd_a]; const Tensor& y = T[ND[h.fused_add].out];
+                *bk = Blk{i, h.a, ND[h.fused_add].out, h.cd.cout, a0.cd.cout, y.H, y.W, a0.cd.cin, true, true};
+                return true;
+            }
             return false;
         };
         for (int i = 0; i < nn; ++i) {
             Blk first;
-            if (!block_of(i, &first) || !chain_supported(first.C, first.MID, first.H, first.W, first.cin0)) continue;
+            if (!block_of(i, &first)) continue;
+            if (first.tail ? !chain_tail_supported(first.C, first.MID, first.H, first.W, first.cin0) : !chain_supported(first.C, first.MID, first.H, first.W, first.cin0)) continue;
             std::vector<int> hosts{first.host};
             Blk cur = first;
-            while ((int)hosts.size() < kChainMaxBlocks && cur.out_t != net->out_t) {
+            const int max_blocks = chain_max_blocks(first.C, first.MID, first.H, first.W, first.cin0, first.tail);
+            while ((int)hosts.size() < max_blocks && cur.out_t != net->out_t) {
                 const Tensor& y = T[cur.out_t];
                 if (y.consumers.size() != 2) break;
                 int next = -1;
@@ -919,6 +931,13 @@ int f8_net_finalize(f8_net* net, int max_batch) {
             const int last = hosts.back();
             for (int h : hosts) ND[h].chain_into = last;
             ND[last].chain = hosts;
+            if (first.tail) {
+                // the opener becomes: [body.0 + body.2 on f8_opener.hip (P12), host = the 3x3, output = mid2 in body.4's int8 format] + [the chain's first block]
+                Node& h = ND[first.host];
+                const int ia = h.fbd_a, ib = h.fbd_b;
+                ND[ia].absorbed_by = ib; ND[ib].absorbed_by = -1; ND[ib].p12_a = ia; ND[ib].p12_s2 = true; ND[ib].fb_R = h.fb_R;
+                h.fbd_a = h.fbd_b = -1; h.fbd_s2 = false; h.tail = true;
+            }
         }
         // identity blocks that only the chain kernel could run and that did not end up in a chain: back to separate launches
         for (int i = 0; i < nn; ++i) {
@@ -1327,17 +1346,24 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     // ---- stage chain: nd is the host conv of its LAST block
                     const std::vector<int> ch = nd.chain;
                     Node& hf = ND[ch[0]];
-                    const bool ds = hf.fbd_a >= 0;
+                    const bool tail = hf.tail;                  // first block = the join of a stride-2 opening block (its body.0 + body.2: the S_P12 step in front)
+                    const bool ds = hf.fbd_a >= 0 || tail;
                     Tensor& x = T[ds ? hf.a : ND[hf.fb_a].a];
                     st.kind = S_CHAIN;
                     st.src_t = ds ? hf.a : ND[hf.fb_a].a;
-                    if (ds) { int n0 = 0; consumer_format(x, ND[hf.fbd_a].cd, &n0, "finalize"); st.src_f = find_form(x, FORM_I8, n0, ND[hf.fbd_a].cd.input_signed ? 1 : 0); }
+                    if (tail) {
+                        int n0 = 0; consumer_format(x, hf.cd, &n0, "finalize"); st.src_f = find_form(x, FORM_I8, n0, hf.cd.input_signed ? 1 : 0);      // the shortcut's int8 form
+                        const Node& g0 = ND[hf.dual];
+                        int n2 = 0; consumer_format(T[g0.a], g0.cd, &n2, "finalize");
+                        st.src2_t = g0.a; st.src2_f = find_form(T[g0.a], FORM_I8, n2, g0.cd.input_signed ? 1 : 0);                                      // mid2 in body.4's format
+                    }
+                    else if (ds) { int n0 = 0; consumer_format(x, ND[hf.fbd_a].cd, &n0, "finalize"); st.src_f = find_form(x, FORM_I8, n0, ND[hf.fbd_a].cd.input_signed ? 1 : 0); }
                     else st.src_f = find_form(x, FORM_I32, 0, 0);
                     double ops = 0, wbytes = 0;
                     for (int hi : ch) {
                         Node& hh = ND[hi];
-                        const bool hds = hh.fbd_a >= 0;
-                        Node* cv[4] = {&ND[hds ? hh.fbd_a : hh.fb_a], &ND[hds ? hh.fbd_b : hh.fb_b], hds ? &ND[hh.dual] : &hh, hds ? &hh : nullptr};
+                        const bool hds = hh.fbd_a >= 0, htl = hh.tail;
+                        Node* cv[4] = {htl ? nullptr : &ND[hds ? hh.fbd_a : hh.fb_a], htl ? nullptr : &ND[hds ? hh.fbd_b : hh.fb_b], (hds || htl) ? &ND[hh.dual] : &hh, (hds || htl) ? &hh : nullptr};
                         for (Node* c : cv) {
                             if (!c) continue;
                             pack_conv_weights(net, *c, T[c->a], T[c->out]);
@@ -1350,16 +1376,16 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     out_t = ND[nd.fused_add].out;
                     select_outputs(net, out_t, &st.out, &extra);
                     Tensor& o = T[out_t];
-                    const double px = (double)x.H * x.W;
-                    double b = px * x.Cs * (ds ? 1 : 4);                            // the stage input, once
+                    const double px = (double)o.H * o.W;
+                    double b = tail ? px * (x.Cs + T[st.src2_t].Cs) : px * x.Cs * (ds ? 1 : 4);   // the stage input, once (tail: the shortcut's pixels + mid2)
                     if (st.out.f32 >= 0) b += px * o.Cs * 4;
                     for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += px * o.Cs;
                     st.ops_per_img = ops; st.bytes_per_img = b; st.bytes_const = wbytes;
-                    const Node& a0 = ND[ds ? hf.fbd_a : hf.fb_a];
-                    st.name = "stage_chain_x" + std::to_string(ch.size()) + (ds ? "_ds:" : ":") + tname(net, a0.out) + ".." + tname(net, nd.out);
+                    const Node& a0 = tail ? ND[hf.dual] : ND[ds ? hf.fbd_a : hf.fb_a];
+                    st.name = "stage_chain_x" + std::to_string(ch.size()) + (tail ? "_tail:" : (ds ? "_ds:" : ":")) + tname(net, a0.out) + ".." + tname(net, nd.out);
                     char kb[160];
-                    const int C = o.C, MID = a0.cd.cout;
-                    snprintf(kb, sizeof kb, "f8::chain_kernel<%d, %d, %d, %d, 4, %d, %s, %d, false>", C, MID, x.W, x.H, a0.cd.cin, MID == 256 ? "2, 4" : (MID == 64 ? "2, 2" : "2, 3"), opt.requant_float ? 1 : 2);   // keep in sync with launch_chain (the FAST instance: real fraclen tables)
+                    const int C = o.C, MID = tail ? a0.cd.cin : a0.cd.cout;
+                    snprintf(kb, sizeof kb, "f8::chain_kernel<%d, %d, %d, %d, 4, %d, %s, %d, false, %s>", C, MID, o.W, o.H, tail ? hf.cd.cin : a0.cd.cin, MID == 256 ? "2, 4" : (MID == 64 ? "2, 2" : "2, 3"), opt.requant_float ? 1 : 2, tail ? "true" : "false");   // keep in sync with launch_chain (the FAST instance: real fraclen tables)
                     st.kernel = kb;
                     break;
                 }
@@ -1410,21 +1436,22 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     st.src_f = find_form(x, FORM_I8, n0, na.cd.input_signed ? 1 : 0);
                     pack_conv_weights(net, na, x, T[na.out]);
                     pack_conv_weights(net, nd, T[nd.a], T[nd.out]);
-                    pack_frag_weights(net, na);
-                    pack_frag_weights(net, nd);
+                    if (!nd.p12_s2) { pack_frag_weights(net, na); pack_frag_weights(net, nd); }      // f8_opener.hip streams the plain [cout][K] images
                     st.relu0 = nd.cd.relu;
                     select_outputs(net, out_t, &st.out, &extra);
                     if (st.out.f32 >= 0) return fail(F8_ERR_UNSUPPORTED, "finalize: the fused 1x1 -> 3x3 launch writes int8 forms only");
+                    if (nd.p12_s2 && (st.out.f8[0] < 0 || st.out.f8[1] >= 0)) return fail(F8_ERR_UNSUPPORTED, "finalize: the stride-2 1x1 -> 3x3 launch writes exactly one int8 form");
                     Tensor& o = T[out_t];
-                    const double px = (double)x.H * x.W;
-                    st.ops_per_img = 2.0 * px * ((double)na.cd.cin * na.cd.cout + 9.0 * nd.cd.cin * nd.cd.cout);
+                    const double px = (double)x.H * x.W, pxo = (double)o.H * o.W;
+                    st.ops_per_img = 2.0 * (px * (double)na.cd.cin * na.cd.cout + pxo * 9.0 * nd.cd.cin * nd.cd.cout);
                     double b = px * x.Cs;
-                    for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += px * o.Cs;
+                    for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += pxo * o.Cs;
                     st.bytes_per_img = b;
                     st.bytes_const = (double)na.coutP * (na.ktot + 4) + (double)nd.coutP * (nd.ktot + 4);
-                    st.name = "fused_p12:" + tname(net, na.out) + "+" + tname(net, nd.out);
+                    st.name = std::string(nd.p12_s2 ? "fused_opener_s2_p12_R" + std::to_string(nd.fb_R) + ":" : "fused_p12:") + tname(net, na.out) + "+" + tname(net, nd.out);
                     char kb[96];
-                    snprintf(kb, sizeof kb, "f8::fused_p12_kernel<%d, %d>", na.cd.cin, na.cd.cout);
+                    if (nd.p12_s2) snprintf(kb, sizeof kb, "f8::fused_opener_kernel<%d, %d, %d, %d, %d, false, true>", na.cd.cin, na.cd.cout, x.W, nd.fb_R, 4 * na.cd.cout);
+                    else snprintf(kb, sizeof kb, "f8::fused_p12_kernel<%d, %d>", na.cd.cin, na.cd.cout);
                     st.kernel = kb;
                     break;
                 }
@@ -2084,10 +2111,21 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             };
             for (int k = 0; k < a.nblk; ++k) {
                 const Node& hh = net->nodes[ch[k]];
+                ChainBlk& B = a.blk[k];
+                if (hh.tail) {                                  // only the join of a stride-2 opening block: shortcut (hh) + body.4 (its dual)
+                    const Node& g4 = net->nodes[hh.dual];
+                    B.w4 = (const int8_t*)(net->d_w + g4.wf_off); B.b4 = (const int32_t*)(net->d_w + g4.b_off);
+                    B.wsc = (const int8_t*)(net->d_w + hh.wf_off); B.bsc = (const int32_t*)(net->d_w + hh.b_off);
+                    B.nq = B.n1 = B.n2 = 1; B.hiq = B.hi1 = B.hi2 = 255; B.xorq = B.xor1 = B.xor2 = 0x80808080u;     // (unused: no body.0 / body.2 here)
+                    B.relu_a = B.relu_b = 1; B.relu1 = net->nodes[hh.fused_add].relu;
+                    a.acc_ok = 1; a.rq_int = !net->opt.requant_float;
+                    const int dfl = T[hh.out].fl - T[g4.out].fl;             // (shortcut << acc_shl) + (body.4 << res_shl)
+                    B.acc_shl = dfl < 0 ? -dfl : 0; B.res_shl = dfl > 0 ? dfl : 0;
+                    continue;
+                }
                 const bool hds = hh.fbd_a >= 0;
                 const Node& na = net->nodes[hds ? hh.fbd_a : hh.fb_a]; const Node& nb = net->nodes[hds ? hh.fbd_b : hh.fb_b];
                 const Node& ng = hds ? net->nodes[hh.dual] : hh;
-                ChainBlk& B = a.blk[k];
                 B.w0 = (const int8_t*)(net->d_w + na.wf_off); B.w2 = (const int8_t*)(net->d_w + nb.wf_off); B.w4 = (const int8_t*)(net->d_w + ng.wf_off);
                 B.b0 = (const int32_t*)(net->d_w + na.b_off); B.b2 = (const int32_t*)(net->d_w + nb.b_off); B.b4 = (const int32_t*)(net->d_w + ng.b_off);
                 if (hds) { B.wsc = (const int8_t*)(net->d_w + hh.wf_off); B.bsc = (const int32_t*)(net->d_w + hh.b_off); }
@@ -2103,12 +2141,14 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
                 B.acc_shl = dfl < 0 ? -dfl : 0; B.res_shl = dfl > 0 ? dfl : 0;
             }
             const Node& hf = net->nodes[ch[0]];
-            const bool ds = hf.fbd_a >= 0;
+            const bool tail = hf.tail, ds = hf.fbd_a >= 0 || tail;
             const Tensor& x = T[st.src_t]; const Form& xF = x.forms[st.src_f];
             if (ds) a.x8in = (const int8_t*)fp(xF); else a.xr = (const int32_t*)fp(xF);
-            const Node& a0 = net->nodes[ds ? hf.fbd_a : hf.fb_a];
-            const int C = T[st.out.t].C, MID = a0.cd.cout;
-            const int tiles = chain_tiles_per_img(x.H, x.W);
+            if (tail) { a.tail = 1; a.m2in = (const int8_t*)fp(T[st.src2_t].forms[st.src2_f]); }
+            const Node& a0 = tail ? net->nodes[hf.dual] : net->nodes[ds ? hf.fbd_a : hf.fb_a];
+            const Tensor& oT = T[st.out.t];
+            const int C = oT.C, MID = tail ? a0.cd.cin : a0.cd.cout;
+            const int tiles = chain_tiles_per_img(oT.H, oT.W);
             // every workgroup of a chain launch must be resident (one per CU): a device with fewer CUs than one image has tiles cannot run it
             if ((net->num_cu > 0 ? std::min(net->num_cu, 256) : 256) < tiles)
                 return fail(F8_ERR_STATE, "f8_net_run: a stage-chain launch needs %d co-resident workgroups per image, the device has %d compute units (plan with fuse_chain = 0 / fuse_bchain = 0)", tiles, net->num_cu);
@@ -2119,7 +2159,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             a.err = a.sync + 512;
             a.xchg = (int8_t*)(net->d_chain + (size_t)part * net->chain_stride + 4096);
             a.timeout_ticks = (uint32_t)std::min<long long>((long long)net->opt.chain_timeout_ms * 100000ll, 0x7fffffffll);
-            e = launch_chain(a, C, MID, x.H, x.W, a0.cd.cin, s);
+            e = launch_chain(a, C, MID, oT.H, oT.W, tail ? hf.cd.cin : a0.cd.cin, s);
             break;
         }
         case S_BCHAIN: {
@@ -2171,6 +2211,23 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
         case S_P12: {
             const Node& na = net->nodes[nd.p12_a];
             const Tensor& x = T[st.src_t]; const Form& xF = x.forms[st.src_f];
+            if (nd.p12_s2) {                                    // body.0 + body.2 of a stride-2 opening block on f8_opener.hip (P12); q[0] = mid2
+                FusedArgs a{};
+                a.x8 = (const int8_t*)fp(xF); a.x_bytes = (uint32_t)(xF.bytes_per_img * N);
+                a.w0 = (const int8_t*)(net->d_w + na.w_off); a.w0_bytes = (uint32_t)((size_t)na.coutP * na.ktot);
+                a.w2 = (const int8_t*)(net->d_w + nd.w_off); a.w2_bytes = (uint32_t)((size_t)nd.coutP * nd.ktot);
+                a.b0 = (const int32_t*)(net->d_w + na.b_off); a.b2 = (const int32_t*)(net->d_w + nd.b_off);
+                a.N = N; a.H = x.H; a.W = x.W; a.C = na.cd.cin; a.MID = na.cd.cout; a.COUT = 4 * na.cd.cout; a.R = nd.fb_R;
+                a.tiles_per_img = (x.H / 2 + nd.fb_R - 1) / nd.fb_R;
+                { int nn = 0; consumer_format(T[nd.a], nd.cd, &nn, "run"); a.n1 = nn; a.lo1 = nd.cd.input_signed ? -127 : 0; a.hi1 = nd.cd.input_signed ? 127 : 255;
+                  a.xor1 = nd.cd.input_signed ? 0u : 0x80808080u; }
+                a.relu_a = na.cd.relu; a.relu_b = nd.cd.relu;
+                fill_out(&a.out32, a.q);
+                a.n2 = a.q[0].n; a.lo2 = a.q[0].lo; a.hi2 = a.q[0].hi; a.xor2 = a.q[0].bias_xor;      // mid2's one form = body.4's input format
+                a.stride2 = 1; a.p12only = 1;
+                e = launch_fused_opener(a, s);
+                break;
+            }
             FusedArgs a{};
             a.x8 = (const int8_t*)fp(xF); a.x_bytes = (uint32_t)(xF.bytes_per_img * N);
             a.w0 = (const int8_t*)(net->d_w + na.wf_off); a.w0_bytes = (uint32_t)((size_t)na.coutP * na.ktot);     // fragment order

@@ -50,7 +50,10 @@ struct OpenerCfg {
     static constexpr int STG_BYTES = NPO * 32 * 128;                              // int8 staging buffer: [px][128 B]
 };
 
-template <int C, int MID, int W, int R, int COUT, bool STG>
+// P12 (round 4): only body.0 and body.2 — mid2 (body.2's output in body.4's int8 input format) goes to HBM (a.q[0], NHWC, MID channels) and
+// the launch ends; the join of the block (body.4 + strided shortcut) is then the FIRST BLOCK of the stage's chain launch (f8_chain.hip, TAIL),
+// which keeps its result in registers: the block's 205 MB int32 output (per 128 images) is neither written here nor read back there.
+template <int C, int MID, int W, int R, int COUT, bool STG, bool P12 = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 fused_opener_kernel(const FusedArgs a) {
     using Cfg = OpenerCfg<C, MID, W, R, COUT>;
@@ -115,7 +118,7 @@ fused_opener_kernel(const FusedArgs a) {
 #endif
 
     // ---- biases -> LDS (plain loads; complete before P1's first barrier, which waits for vmcnt(0))
-    for (int i = tid; i < Cfg::BIAS_INTS; i += 512) {
+    for (int i = tid; i < (P12 ? 2 * MID : Cfg::BIAS_INTS); i += 512) {
         int v;
         if (i < MID) v = a.b0[i];
         else if (i < 2 * MID) v = a.b2[i - MID];
@@ -253,7 +256,7 @@ fused_opener_kernel(const FusedArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                    // every wave is done with the P1 ring: mid2 / xs / W2 ring take its place
         F8_OT(1);
-        issue_xs();                                      // oldest in the queue: any later counted wait covers it
+        if constexpr (!P12) issue_xs();                  // oldest in the queue: any later counted wait covers it
 #pragma unroll
         for (int k = 0; k < NS2 - 1; ++k) issue_w2(k, k);
 
@@ -332,10 +335,12 @@ fused_opener_kernel(const FusedArgs a) {
         F8_OT(3);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                    // patch and W2 ring are dead everywhere: the P3 ring takes them over
-        issue_p3(0, 0);
-        asm volatile("" ::: "memory");
-        issue_p3(1, 1);
-        asm volatile("" ::: "memory");
+        if constexpr (!P12) {
+            issue_p3(0, 0);
+            asm volatile("" ::: "memory");
+            issue_p3(1, 1);
+            asm volatile("" ::: "memory");
+        }
 
         const int floor0 = a.relu_b ? 0 : INT32_MIN;
 #pragma unroll
@@ -352,7 +357,8 @@ fused_opener_kernel(const FusedArgs a) {
             auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
             auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
             v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
-            *(v4i*)(mid2 + SM::off(opix, ct * 2 + lh)) = o;
+            if constexpr (P12) { if (opix_ok) *(v4i*)(a.q[0].ptr + (size_t)m * MID + ct * 32 + lh * 16) = o; }
+            else *(v4i*)(mid2 + SM::off(opix, ct * 2 + lh)) = o;
         }
     }
     F8_OT(4);
@@ -361,7 +367,7 @@ fused_opener_kernel(const FusedArgs a) {
     // P3: y = clamp(((Wsc . x + bsc) << sa) + ((W4 . mid2 + b4) << sr)) [ReLU] -> y32 (I32T) / int8 copies
     //     wave (wa, wb): px tile wa, co tile wb of each 64-channel chunk
     // =========================================================================================
-    {
+    if constexpr (!P12) {
         const int floor1 = a.relu1 ? 0 : -2147483647 /* the join's clamp_(min=-(2^31-1)) and the ReLU floor are one max */;
         const bool stage0 = STG && a.q[0].ptr != nullptr;
         const int n_direct = (a.out32 ? 4 : 0) + ((!STG && a.q[0].ptr) ? 1 : 0) + (a.q[1].ptr ? 1 : 0);
@@ -467,12 +473,12 @@ fused_opener_kernel(const FusedArgs a) {
 #endif
 }
 
-template <int C, int MID, int W, int R, int COUT, bool STG>
+template <int C, int MID, int W, int R, int COUT, bool STG, bool P12 = false>
 static hipError_t launch_opener_t(const FusedArgs& a, hipStream_t s) {
     using Cfg = OpenerCfg<C, MID, W, R, COUT>;
     static unsigned long long attr_done = 0; int attr_dev = -1;
     if (!dyn_lds_opted_in(&attr_done, &attr_dev)) {
-        hipError_t e = hipFuncSetAttribute((const void*)fused_opener_kernel<C, MID, W, R, COUT, STG>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)fused_opener_kernel<C, MID, W, R, COUT, STG, P12>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
         if (attr_dev >= 0) attr_done |= 1ull << attr_dev;
     }
@@ -483,7 +489,7 @@ static hipError_t launch_opener_t(const FusedArgs& a, hipStream_t s) {
     FusedArgs b = a;
     const bool tracing = (count++ == want);
     if (tracing) { if (!tbuf) (void)hipMalloc((void**)&tbuf, (size_t)1 << 22); (void)hipMemsetAsync(tbuf, 0, (size_t)grid * 64, s); b.trace = tbuf; }
-    hipLaunchKernelGGL((fused_opener_kernel<C, MID, W, R, COUT, STG>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, b);
+    hipLaunchKernelGGL((fused_opener_kernel<C, MID, W, R, COUT, STG, P12>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, b);
     if (tracing) {
         (void)hipStreamSynchronize(s);
         unsigned long long* h = new unsigned long long[(size_t)grid * 8];
@@ -496,15 +502,17 @@ static hipError_t launch_opener_t(const FusedArgs& a, hipStream_t s) {
     }
     return hipGetLastError();
 #else
-    hipLaunchKernelGGL((fused_opener_kernel<C, MID, W, R, COUT, STG>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((fused_opener_kernel<C, MID, W, R, COUT, STG, P12>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, a);
     return hipGetLastError();
 #endif
 }
 
 hipError_t launch_fused_opener(const FusedArgs& a, hipStream_t s) {
     const int stg = a.stg;
-    if (a.C == 256 && a.MID == 128 && a.COUT == 512 && a.W == 56 && a.R == 4)
+    if (a.C == 256 && a.MID == 128 && a.COUT == 512 && a.W == 56 && a.R == 4) {
+        if (a.p12only) return a.q[0].ptr && !a.q[1].ptr && !a.out32 ? launch_opener_t<256, 128, 56, 4, 512, false, true>(a, s) : hipErrorInvalidValue;
         return stg ? launch_opener_t<256, 128, 56, 4, 512, true>(a, s) : launch_opener_t<256, 128, 56, 4, 512, false>(a, s);
+    }
     return hipErrorInvalidValue;
 }
 

@@ -160,6 +160,83 @@ def _run_stage_chain(dev, cfg, variant, tail, options=None, big_bias=False):
         np.testing.assert_array_equal(got2, w[:N - 1])
 
 
+# ... starting with the JOIN of the stage-opening block whose 3x3 and shortcut have stride 2 (fix_resnet.py:55-77; ResNet-50 stage 1): its body.0 +
+# body.2 run on f8_opener.hip (P12: mid2 -> HBM, int8), its join (body.4 + 1x1 / 2 shortcut) is the first block of the chain launch (TAIL)
+TAIL_CHAINS = [(512, 128, 28, 3, 256, 3), (512, 128, 28, 1, 256, 5), (512, 128, 28, 3, 256, 37)]   # C, MID, H = W of the stage, identity blocks, CIN0, N
+
+
+@pytest.mark.parametrize('cfg', TAIL_CHAINS, ids=lambda g: 'x'.join(map(str, g)))
+@pytest.mark.parametrize('variant', ['body_shifts_left', 'shortcut_shifts_left', 'two_input_forms', 'requant_float=0', 'fuse_tail=0'])
+def test_stage_chain_opened_by_a_stride2_block_matches_oracle(dev, cfg, variant):
+    """`two_input_forms`: body.0 and the shortcut read the block input in DIFFERENT int8 formats — the planner does not fuse that opener at all
+    (pass 1d) and the stage must still equal the oracle; `fuse_tail=0`: the round-3 plan (whole opener in one launch, identity chain behind it)."""
+    C, MID, HW, nid, CIN0, N = cfg
+    if N > 8 and variant not in ('body_shifts_left', 'requant_float=0'):
+        pytest.skip('format variants are covered at the small batch')
+    HWI = 2 * HW
+    name = 'o.0'
+    body = [topology.ConvSpec(name + '.body.0', CIN0, MID, 1, 1, 0, relu=True), topology.ConvSpec(name + '.body.2', MID, MID, 3, 2, 1, relu=True),
+            topology.ConvSpec(name + '.body.4', MID, C, 1, 1, 0)]
+    sc = topology.ConvSpec(name + '.shortcut.0', CIN0, C, 1, 2, 0)
+    opener = topology.BlockSpec(name, body, sc, residual=True, post_relu=True)
+    idb, fls = _stage(C, MID, nid, C, 'acc_shifts_left')
+    if variant == 'shortcut_shifts_left':
+        fls[name + '.body.0'], fls[name + '.body.2'], fls[name + '.body.4'], fls[name + '.shortcut.0'] = (4, 7), (3, 6), (4, 7), (4, 6)     # body.4 11 > shortcut 10
+    elif variant == 'two_input_forms':
+        fls[name + '.body.0'], fls[name + '.body.2'], fls[name + '.body.4'], fls[name + '.shortcut.0'] = (4, 7), (3, 6), (3, 6), (3, 7)     # body.0 reads fl 4, the shortcut fl 3
+    else:
+        fls[name + '.body.0'], fls[name + '.body.2'], fls[name + '.body.4'], fls[name + '.shortcut.0'] = (4, 7), (3, 6), (3, 6), (4, 7)     # body.4 9 < shortcut 11
+    blocks = [opener] + idb
+    convs = [c for b in blocks for c in b.body] + [sc]
+    pre = topology.ConvSpec('pre.0', CIN0, CIN0, 1, 1, 0)          # a conv in front: the opener's input is not the network input
+    fls['pre.0'] = (4, 7)
+    params = _params(convs + [pre], fls, 51, variant)
+    x_fl = 9
+    x = synth.rand_normal_int(23, 'tailx' + variant, (N, CIN0, HWI, HWI), 3.0e3).astype(np.int32)
+
+    net = F8Net()
+    if variant == 'requant_float=0':
+        net.set_option('requant_float', 0)
+    if variant == 'fuse_tail=0':
+        net.set_option('fuse_tail', 0)
+    t = net.input(CIN0, HWI, HWI, x_fl)
+    r = net.conv(t, params['pre.0.weight'], params['pre.0.bias'], stride=1, pad=0, groups=1, weight_fl=7, input_fl=4, input_signed=False,
+                 quant_input=True, relu=True)
+    for b in blocks:
+        xin = r
+        for c in b.body:
+            r = net.conv(r, params[c.key + '.weight'], params[c.key + '.bias'], stride=c.stride, pad=c.pad, groups=1,
+                         weight_fl=fls[c.key][1], input_fl=fls[c.key][0], input_signed=False, quant_input=True, relu=c.relu)
+        if b.shortcut is not None:
+            c = b.shortcut
+            xin = net.conv(xin, params[c.key + '.weight'], params[c.key + '.bias'], stride=2, pad=0, groups=1,
+                           weight_fl=fls[c.key][1], input_fl=fls[c.key][0], input_signed=False, quant_input=True, relu=False)
+            r = net.add(r, xin, relu=True)
+        else:
+            r = net.add(r, xin, relu=True)
+    net.output(r, as_float=False)
+    net.finalize(N)
+    plan = net.describe()
+    if variant in ('two_input_forms', 'fuse_tail=0'):
+        assert '_tail' not in plan and '_p12' not in plan, plan
+        if nid >= 2:
+            assert f'stage_chain_x{nid}:' in plan, plan
+    else:
+        assert f'stage_chain_x{nid + 1}_tail' in plan and 'fused_opener_s2_p12' in plan, plan
+    got = net.run(_t(x, dev)).cpu().numpy().reshape(N, C, HW, HW)
+    net.check()
+
+    w, fl = oracle._conv_layer(pre, params, x, x_fl)
+    w = np.maximum(w, 0)
+    for b in blocks:
+        w, fl = oracle.block_forward(b, params, w, fl)
+    assert net.output_fraclen == fl
+    np.testing.assert_array_equal(got, w)
+    got2 = net.run(_t(x[:N - 1], dev)).cpu().numpy().reshape((N - 1,) + w.shape[1:])     # second run, ragged batch
+    net.check()
+    np.testing.assert_array_equal(got2, w[:N - 1])
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # BasicBlock chains (f8_bchain.hip): ResNet-18 / 34 identity blocks of one stage in one launch
 def _basic_stage(C, nblk, variant):

@@ -14,7 +14,7 @@ bash tools/profile.sh ${TAG}_mbv2 --arch mobilenet_v2 --bs 128 > $OUT/profile_mb
 bash tools/profile.sh ${TAG}_r50bs256 --arch resnet50 --bs 256 > $OUT/profile_r50bs256.log 2>&1
 for t in $TAG ${TAG}_r18 ${TAG}_mbv2 ${TAG}_r50bs256; do cp gpurun_out/prof_$t/summary/* $OUT/ 2>/dev/null; done
 # the stamped counter files must be in place before the bench lines are taken (bench.py reads them)
-cp $OUT/pmc_traffic_*.json $OUT/pmc_mfma_*.json profiles/ 2>/dev/null
+cp $OUT/pmc_traffic_*.json $OUT/pmc_mfma_*.json $OUT/pmc_limiter_*.json profiles/ 2>/dev/null
 timeout 900 python bench.py --steps 200 --warmup 20 --per-layer > $OUT/bench_$TAG.json 2> $OUT/perlayer_$TAG.txt
 timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench_${TAG}_driverflags.json 2> /dev/null
 timeout 900 python bench.py --arch resnet18 --bs 128 --steps 200 --warmup 20 --per-layer > $OUT/bench_${TAG}_resnet18_bs128.json 2> $OUT/perlayer_${TAG}_resnet18_bs128.txt

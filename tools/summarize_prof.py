@@ -108,6 +108,65 @@ def main():
                       open(os.path.join(out, f'pmc_mfma_{arch}_bs{bs}.json'), 'w'), indent=1, sort_keys=True)
     json.dump({'csrc_sha256': stamp, 'workload': workload, 'tag': tag, 'kernels': {k: v for k, v in traffic.items() if k.startswith('f8::')}},
               open(os.path.join(out, f'pmc_traffic_{arch}_bs{bs}.json'), 'w'), indent=1, sort_keys=True)
+    # ---- what the waves do (round 4): SQ_WAVE_CYCLES = WAIT_ANY (parked at s_waitcnt / s_barrier) + WAIT_INST_ANY (issue stall: dependency,
+    #      pipe busy) + ACTIVE_INST_ANY (issuing), all in quad-cycles summed over waves (MI355X_MICROARCH.md, rocprofv3 PMC slots)
+    sq = {}
+    for sub in ('pmc_sq', 'pmc_sq2'):
+        db = os.path.join(src, sub, 'pmc_results.db')
+        if not os.path.exists(db):
+            continue
+        c = sqlite3.connect(db)
+        try:
+            rows_ = list(c.execute('select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name'))
+        except sqlite3.Error:
+            continue
+        for name, cn, n, avg in rows_:
+            k = short(name)
+            if k.startswith('f8::'):
+                e = sq.setdefault(k, {})
+                e[cn if (sub == 'pmc_sq' or cn != 'GRBM_GUI_ACTIVE') else 'GRBM_GUI_ACTIVE_2'] = avg
+                e['launches'] = n
+    if sq:
+        durs = {short(name): (avg, pct) for name, calls, tot, avg, pct in rows}
+        lim = {}
+        for k, e in sq.items():
+            wc = e.get('SQ_WAVE_CYCLES', 0.0)
+            if not wc:
+                continue
+            parked, stall, active = e.get('SQ_WAIT_ANY', 0.0) / wc, e.get('SQ_WAIT_INST_ANY', 0.0) / wc, e.get('SQ_ACTIVE_INST_ANY', 0.0) / wc
+            valu = e.get('SQ_ACTIVE_INST_VALU', 0.0) / wc
+            act_simd = e.get('GRBM_GUI_ACTIVE', 0.0) / 8.0 * 1024.0           # SIMD-cycles the launch lasted
+            mfma_busy = mf.get(k, {}).get('mfma_busy_frac')
+            hbm = traffic.get(k, {}).get('hbm_bytes_per_launch')
+            dur = durs.get(k, (None, None))[0]
+            hbm_frac = (hbm / (dur * 1e-6) / 8.0e12) if (hbm and dur) else None
+            # VALU pipe busy: wave64 VALU instructions x 2 cycles (32 lanes per SIMD and cycle) over the SIMD-cycles of the launch
+            valu_busy = (e.get('SQ_INSTS_VALU', 0.0) * 2.0 / act_simd) if act_simd else None
+            lds_busy = (e.get('SQ_LDS_IDX_ACTIVE', 0.0) / (e.get('GRBM_GUI_ACTIVE_2', 0.0) / 8.0 * 256.0)) if e.get('GRBM_GUI_ACTIVE_2') else None
+            cand = {'hbm': hbm_frac or 0.0, 'mfma': mfma_busy or 0.0, 'valu': valu_busy or 0.0, 'lds': lds_busy or 0.0}
+            top = max(cand, key=cand.get)
+            # a pipe that is busy more than half of the launch names the limiter; otherwise the waves are waiting: parked at s_waitcnt / s_barrier
+            # (memory / exchange latency, barrier skew) or stalled at issue (dependent instructions, a busy pipe)
+            limiter = top if cand[top] >= 0.5 else ('latency' if parked >= stall else 'issue-stall')
+            lim[k] = {'limiter': limiter, 'wave_parked_frac': round(parked, 4), 'wave_issue_stall_frac': round(stall, 4), 'wave_issuing_frac': round(active, 4),
+                      'wave_issuing_valu_frac': round(valu, 4), 'valu_pipe_busy_frac': None if valu_busy is None else round(valu_busy, 4),
+                      'lds_busy_frac': None if lds_busy is None else round(lds_busy, 4), 'mfma_busy_frac': mfma_busy, 'hbm_frac_measured_bytes': None if hbm_frac is None else round(hbm_frac, 4),
+                      'valu_insts_per_launch': e.get('SQ_INSTS_VALU'), 'lds_insts_per_launch': e.get('SQ_INSTS_LDS'), 'lds_bank_conflict_cycles': e.get('SQ_LDS_BANK_CONFLICT'),
+                      'lds_bank_conflict_per_lds_active': (round(e.get('SQ_LDS_BANK_CONFLICT', 0.0) / e['SQ_LDS_IDX_ACTIVE'], 4) if e.get('SQ_LDS_IDX_ACTIVE') else None),
+                      'waves_per_launch': e.get('SQ_WAVES'), 'avg_us': dur, 'share_pct': durs.get(k, (None, None))[1]}
+        with open(os.path.join(out, f'rocprof_{tag}_valu.md'), 'w') as f:
+            f.write(f'# rocprofv3 --pmc, two SQ passes of their own (tools/profile.sh), same command ({tag}, {workload}, kernel sources {stamp[:16]})\n\n')
+            f.write('What the waves of each kernel do.  `parked` = SQ_WAIT_ANY / SQ_WAVE_CYCLES (waiting at s_waitcnt / s_barrier: memory and halo-exchange latency, barrier skew), '
+                    '`issue stall` = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (a dependent instruction or a busy pipe), `issuing` = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES (of which VALU: '
+                    'SQ_ACTIVE_INST_VALU).  `VALU pipe` = SQ_INSTS_VALU x 2 cycles / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); `MFMA` from the MFMA pass; `HBM` = measured bytes / duration / 8 TB/s; '
+                    '`LDS` = SQ_LDS_IDX_ACTIVE / (GUI_ACTIVE / 8 x 256 CUs).  **limiter** = the pipe that is busy at least half of the launch, else `latency` (parked > stalled) or `issue-stall`.\n\n')
+            f.write('| kernel | share % | avg us | limiter | parked | issue stall | issuing (VALU) | VALU pipe | MFMA | LDS | HBM | bank-conflict / LDS-active | VALU insts | LDS insts |\n|---|---:|---:|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|\n')
+            pc = lambda v: '-' if v is None else f'{100 * v:.1f} %'
+            for k, e in sorted(lim.items(), key=lambda kv: -(kv[1]['share_pct'] or 0)):
+                f.write(f"| `{k}` | {e['share_pct'] or 0:.2f} | {e['avg_us'] or 0:.1f} | **{e['limiter']}** | {pc(e['wave_parked_frac'])} | {pc(e['wave_issue_stall_frac'])} | "
+                        f"{pc(e['wave_issuing_frac'])} ({pc(e['wave_issuing_valu_frac'])}) | {pc(e['valu_pipe_busy_frac'])} | {pc(e['mfma_busy_frac'])} | {pc(e['lds_busy_frac'])} | {pc(e['hbm_frac_measured_bytes'])} | "
+                        f"{'-' if e['lds_bank_conflict_per_lds_active'] is None else e['lds_bank_conflict_per_lds_active']} | {e['valu_insts_per_launch'] or 0:.4g} | {e['lds_insts_per_launch'] or 0:.4g} |\n")
+        json.dump({'csrc_sha256': stamp, 'workload': workload, 'tag': tag, 'kernels': lim}, open(os.path.join(out, f'pmc_limiter_{arch}_bs{bs}.json'), 'w'), indent=1, sort_keys=True)
     line = os.path.join(src, 'bench_line.json')
     if os.path.exists(line):
         txt = open(line).read().strip()
