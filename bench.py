@@ -119,6 +119,9 @@ def main():
     ap.add_argument('--arch', default='resnet50', help='resnet50 (headline) | resnet18 | mobilenet_v2 | mobilenet_v1')
     ap.add_argument('--bs', type=int, default=128, help='images per GPU (the headline metric is quoted at 128)')
     ap.add_argument('--per-layer', action='store_true', help='also print the per-launch table to stderr')
+    ap.add_argument('--dry-run-dist', action='store_true', help='no GPU: the rendezvous / sharding / fence / max-over-ranks / JSON path of an N-GPU launch over gloo '
+                    'with a STUB forward (a deterministic function of the images, not a measurement): what a first 8-GPU launch must not fail on')
+    ap.add_argument('--hw', type=int, default=224, help=argparse.SUPPRESS)
     ap.add_argument('--autotune', action='store_true', help='measured tile selection (f8_net_autotune) instead of the planner heuristics; '
                     'measured: re-tiles ~12 launches, gain within run-to-run noise, so off by default')
     args = ap.parse_args()
@@ -131,27 +134,48 @@ def main():
     from f8net_amd.net import build_net
 
     BS = args.bs
-    rank, world, local_rank = f8dist.init_from_env()
+    dry = args.dry_run_dist
+    rank, world, local_rank = f8dist.init_from_env(backend='gloo' if dry else None)
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
-    assert torch.cuda.is_available(), 'bench.py needs a GPU (there is no CPU product path)'
-    dev = torch.device('cuda', local_rank)
-    torch.cuda.set_device(dev)
+    if world > 1 and not dry:
+        assert dist.get_backend() == 'nccl', f'N > 1 runs over RCCL (backend nccl), not {dist.get_backend()}'
+    if dry:
+        dev = torch.device('cpu')
+    else:
+        assert torch.cuda.is_available(), 'bench.py needs a GPU (there is no CPU product path)'
+        dev = torch.device('cuda', local_rank)
+        torch.cuda.set_device(dev)
+
+    def dev_sync():
+        if dev.type == 'cuda':
+            torch.cuda.synchronize(dev)
 
     normalize = args.arch == 'resnet50'
     spec = topology.get(args.arch, normalize=normalize)
     params = synth.reference_params(spec, seed=1234)
     fr_name = {'resnet50': 'NVIDIA-pretrained fraclens (normalize: True)', 'mobilenet_v2': "the reference log's learned fraclens (mbv2_fix_quant.out)"}.get(
         args.arch, 'seeded fraclens (weight_format [8,7]-style)')
-    x_np, x_fl = synth.make_input(spec, params, BS, 224, seed=1 + rank)
+    x_np, x_fl = synth.make_input(spec, params, BS, args.hw, seed=1 + rank)
     pipe_mode = int(os.environ.get('F8_BENCH_PIPELINED', '2'))
     # planning hint: under pipelining mode 2 every launch covers the whole batch (matters for the 14x14 fusion rule at bs 64..127)
     # ... and `depth` whole batches are in flight, one arena copy each (a run with ONE batch in flight still cuts it `split` = 2 ways)
     depth = max(2, min(4, int(os.environ.get('F8_PIPELINE_DEPTH', '3')))) if pipe_mode == 2 else 2
-    net = build_net(spec, params, max_batch=BS, hw=224,
-                    options={'whole_batch_launches': 1, 'arena_copies': depth, 'pipeline_depth': depth} if pipe_mode == 2 else None)
-    net.upload()
-    retiled = net.autotune(BS, dev) if args.autotune else 0      # one-time, outside the timed region
+    if dry:
+        class _Stub:            # stands in for F8Net on a box without a GPU: logits[i, c] = (sum of image i + c) mod 1000 — plumbing only, never a result
+            def run(self, t, out=None):
+                out.copy_(((t.reshape(t.shape[0], -1).sum(1, keepdim=True) + torch.arange(spec.num_classes)) % 1000).to(torch.float32))
+                return out
+            def set_pipelined(self, mode): pass
+            def check(self): return self
+            def get_option(self, key): return 1
+        net = _Stub()
+        retiled = 0
+    else:
+        net = build_net(spec, params, max_batch=BS, hw=args.hw,
+                        options={'whole_batch_launches': 1, 'arena_copies': depth, 'pipeline_depth': depth} if pipe_mode == 2 else None)
+        net.upload()
+        retiled = net.autotune(BS, dev) if args.autotune else 0      # one-time, outside the timed region
     x = torch.from_numpy(x_np).to(dev)
     # the all-gather of step i overlaps the compute of step i+1 (double-buffered logits); fence() completes every
     # outstanding collective before the clock stops
@@ -166,7 +190,7 @@ def main():
             sharded.finish()
             if world > 1:
                 dist.barrier()
-            torch.cuda.synchronize(dev)
+            dev_sync()
 
         out = None
         for _ in range(warmup):
@@ -185,6 +209,23 @@ def main():
         net.check()                         # sticky device error words (a chain launch's halo wait timed out; int32 input outside the head's format): raises
         return dt, sharded.local[0]
 
+    if dry:
+        dt, logits = timed(pipe_mode, args.steps, args.warmup)
+        # every rank's gathered logits must hold every rank's shard, in rank order (the stub forward is a function of the images alone)
+        full = f8dist.ShardedForward(lambda t: net.run(t, out=torch.empty((BS, spec.num_classes))), spec.num_classes)(x)
+        for r in range(world):
+            xr = torch.from_numpy(synth.make_input(spec, params, BS, args.hw, seed=1 + r)[0])
+            assert torch.equal(full[r * BS:(r + 1) * BS], net.run(xr, out=torch.empty((BS, spec.num_classes)))), f'rank {rank}: shard {r} of the gathered logits'
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({'metric': f'images/sec at bs={BS} ({PRETTY.get(args.arch, args.arch)} INT8)', 'value': round(BS * world * args.steps / dt, 1), 'unit': 'img/s',
+                              'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 4), 'higher_is_better': True,
+                              'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int8 x int8 -> int32 (exact integer)', 'data': 'synthetic',
+                              'dry_run': 'gloo on CPU with a stub forward: NOT a measurement (rendezvous, sharding, fence, max over ranks and this line only)',
+                              'config': {'workload': f'{spec.arch} dry run', 'global_batch': BS * world, 'parallelism': f'dp{world} (batch shards + all-gather of logits)'}}))
+        return
     lean = os.environ.get('F8_BENCH_LEAN', '0') == '1'      # profiling runs (tools/profile.sh): the headline loop only, fewer kernel records
     # Order: the secondary measurements first (one batch in flight; the per-launch roofline pass), the headline region last.
     # Each region has its own warm-up and is bracketed by barrier + synchronize; running the secondary ones first also means the
@@ -248,11 +289,11 @@ def main():
         outs = [torch.empty((BS, spec.num_classes), dtype=torch.float32, device=dev) for _ in range(NO)]
         for i in range(min(args.warmup, 10) + 2):
             m.forward(xi, out=outs[i % NO])
-        torch.cuda.synchronize(dev)
+        dev_sync()
         t0 = time.perf_counter()
         for i in range(args.steps):
             m.forward(xi, out=outs[i % NO])
-        torch.cuda.synchronize(dev)
+        dev_sync()
         dtm = time.perf_counter() - t0
         extra['value_intmodel'] = round(BS * args.steps / dtm, 1)
         extra['intmodel_matches'] = bool(torch.equal(outs[(args.steps - 1) % NO], logits[:BS]))
@@ -312,6 +353,18 @@ def main():
                     'whole_net_mfma_i8_insts_per_img': mj.get('whole_net_mfma_insts_per_img')}
         elif why:
             notes.append(why)
+        limiter = None
+        lj, why = stamped_json(f'pmc_limiter_{args.arch}_bs{BS}.json', stamp)    # what the waves do: two SQ counter passes of their own (tools/profile.sh)
+        if lj is not None and lj.get('workload') == f'{args.arch}/bs{BS}':
+            lk = lj.get('kernels', {}).get(dom)
+            if lk:
+                limiter = {'limiter': lk.get('limiter'),
+                           'evidence': 'rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT '
+                                       '(own pass; profiles/rocprof_*_valu.md): a pipe busy >= half of the launch names the limiter, else latency (waves parked at s_waitcnt / s_barrier) or issue-stall',
+                           **{k: lk.get(k) for k in ('wave_parked_frac', 'wave_issue_stall_frac', 'wave_issuing_frac', 'wave_issuing_valu_frac', 'valu_pipe_busy_frac', 'lds_busy_frac',
+                                                     'mfma_busy_frac', 'hbm_frac_measured_bytes', 'lds_bank_conflict_per_lds_active')}}
+        elif why:
+            notes.append(why)
         total_ms = sum(ms)
         if args.per_layer:
             for i, name, m, b, o in rows:
@@ -352,7 +405,7 @@ def main():
                          'avg_launch_us': round(1e3 * d['ms'] / d_launches, 2),
                          'alg_bytes_per_launch': round(d['bytes'] / d_launches, 0),
                          'kernel_share_of_step': round(d['ms'] / total_ms, 3),
-                         'mfma': mfma},
+                         'mfma': mfma, 'limiter': (limiter or {}).get('limiter'), 'limiter_detail': limiter},
             'whole_net': {'sum_kernel_ms': round(total_ms, 4),
                           'mfma_int8_frac_of_peak': round(value / world * OPS_PER_IMG.get(args.arch, 0.0) / 1e12 / MFMA_I8_PEAK_TOPS, 4),
                           'hbm_frac_structural_bytes': round(value / world * STRUCT_BYTES_PER_IMG.get(args.arch, 0.0) / 1e9 / HBM_PEAK_GBS, 4),

@@ -32,9 +32,12 @@
 
 namespace f8 {
 
-template <int C, int MID, int W, int H, int R, int CIN0, int MAXB_ = kChainMaxBlocks>
+// BROT: only TWO blocks' biases are resident (the current block's and the next one's, which is fetched during the current block) instead of
+// every block's: the TAIL instances need the 18-30 KB for the shortcut's operand
+template <int C, int MID, int W, int H, int R, int CIN0, bool BROT_ = false>
 struct ChainCfg {
-    static constexpr int MAXB = MAXB_;                         // blocks whose biases fit the instance's LDS
+    static constexpr bool BROT = BROT_;
+    static constexpr int BSLOTS = BROT ? 2 : kChainMaxBlocks;
     static constexpr int T = (H + R - 1) / R;                  // tiles (workgroups) per image
     static constexpr int PX = R * W, NPT = (PX + 31) / 32, ROWS = NPT * 32;
     static constexpr int PW = W + 2, PR = R + 2;
@@ -47,7 +50,7 @@ struct ChainCfg {
     static constexpr int MID2_BYTES = ROWS * MS;
     static constexpr int XIN_BYTES = CIN0 != C ? ROWS * IS : 0;
     static constexpr int BIAS_INTS = 2 * MID + C;              // per block: b0 | b2 | b4
-    static constexpr int BIAS_BYTES = (MAXB * BIAS_INTS + (CIN0 != C ? C : 0)) * 4;   // + bsc of the stage-opening block
+    static constexpr int BIAS_BYTES = (BSLOTS * BIAS_INTS + (CIN0 != C ? C : 0)) * 4;   // + bsc of the stage-opening block
     static constexpr int MISC_BYTES = 256;
     static constexpr int LDS_BYTES = X8_BYTES + PATCH_BYTES + MID2_BYTES + XIN_BYTES + BIAS_BYTES + MISC_BYTES;
     static constexpr int ROWB = W * MID;                       // one exchanged row of mid1
@@ -96,10 +99,11 @@ __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+s"(v)); retur
 template <int C, int MID, int W, int H, int R, int CIN0, int NB, int NBUF, int FAST, bool ROT, bool TAIL = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 chain_kernel(const ChainArgs a) {
-    using Cfg = ChainCfg<C, MID, W, H, R, CIN0, TAIL ? 4 : kChainMaxBlocks>;
-    constexpr int MAXB = Cfg::MAXB;
+    using Cfg = ChainCfg<C, MID, W, H, R, CIN0, TAIL>;
+    constexpr bool BROT = Cfg::BROT;
+    constexpr int BSLOTS = Cfg::BSLOTS;
     constexpr bool DS0 = CIN0 != C;
-    static_assert(!TAIL || (DS0 && ((H + R - 1) / R * R == H) && ((R * W + 31) / 32) % 2 == 0), "TAIL: an opening block; whole tiles, an even number of pixel tiles");
+    static_assert(!TAIL || (DS0 && ((R * W + 31) / 32) % 2 == 0), "TAIL: an opening block; an even number of pixel tiles");
     constexpr int T = Cfg::T, NPT = Cfg::NPT, PW = Cfg::PW, ROWB = Cfg::ROWB, BIAS_INTS = Cfg::BIAS_INTS;
     constexpr int XS = Cfg::XS, MS = Cfg::MS, IS = Cfg::IS;
     constexpr int CT = C / 32, CM = MID / 32, CTW = CT / 8;
@@ -159,12 +163,30 @@ chain_kernel(const ChainArgs a) {
     // ---- place in the logical grid: a ticket
     if (tid == 0) { misc[0] = (int)__hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); misc[1] = 0; }
     // ---- biases of every block: once per workgroup, into LDS (a global bias load at the head of a phase costs its whole latency)
-    for (int b = 0; b < a.nblk; ++b) {
+    constexpr int NBI = (BIAS_INTS + 511) / 512;                 // bias words per thread and block
+    auto bias_fetch = [&](int b, int (&v)[NBI]) {               // BROT: block b's b0 | b2 | b4 -> registers (the tail block has no b0 / b2)
         const ChainBlk& B = a.blk[b];
-        for (int i = tid; i < BIAS_INTS; i += 512)
-            bias_lds[b * BIAS_INTS + i] = i < 2 * MID ? ((TAIL && b == 0) ? 0 : (i < MID ? B.b0[i] : B.b2[i - MID])) : B.b4[i - 2 * MID];
+        int tb = tid; asm volatile("" : "+v"(tb));
+#pragma unroll
+        for (int k = 0; k < NBI; ++k) {
+            const int i = tb + k * 512;
+            v[k] = 0;
+            if (i < BIAS_INTS) v[k] = i < 2 * MID ? ((TAIL && b == 0) ? 0 : (i < MID ? B.b0[i] : B.b2[i - MID])) : B.b4[i - 2 * MID];
+        }
+    };
+    auto bias_store = [&](int b, const int (&v)[NBI]) {         // ... -> slot b & 1
+        int tb = tid; asm volatile("" : "+v"(tb));
+#pragma unroll
+        for (int k = 0; k < NBI; ++k) if (tb + k * 512 < BIAS_INTS) bias_lds[(b & 1) * BIAS_INTS + tb + k * 512] = v[k];
+    };
+    if constexpr (!BROT) {
+        for (int b = 0; b < a.nblk; ++b) {
+            const ChainBlk& B = a.blk[b];
+            for (int i = tid; i < BIAS_INTS; i += 512)
+                bias_lds[b * BIAS_INTS + i] = i < 2 * MID ? ((TAIL && b == 0) ? 0 : (i < MID ? B.b0[i] : B.b2[i - MID])) : B.b4[i - 2 * MID];
+        }
     }
-    if constexpr (DS0) for (int i = tid; i < C; i += 512) bias_lds[MAXB * BIAS_INTS + i] = a.blk[0].bsc[i];
+    if constexpr (DS0) for (int i = tid; i < C; i += 512) bias_lds[BSLOTS * BIAS_INTS + i] = a.blk[0].bsc[i];
     __syncthreads();
     const int L = __builtin_amdgcn_readfirstlane(misc[0]);
     const int grp = L / T, ti = L - grp * T;
@@ -267,7 +289,10 @@ chain_kernel(const ChainArgs a) {
                 vm[k] = v4i{0, 0, 0, 0};
                 if (row < npx) vm[k] = *(const v4i*)(a.m2in + (size_t)(m_tile + row) * MID + c16 * 16);
             }
+            int bv0[NBI], bv1[NBI];
+            if constexpr (BROT) { bias_fetch(0, bv0); bias_fetch(a.nblk > 1 ? 1 : 0, bv1); }
             { F8_LANES; static_for<(NBUF - 1 < NBT ? NBUF - 1 : NBT)>([&](auto bc) { constexpr int Bi = decltype(bc)::value; wt_load(a.blk[0].wsc, a.blk[0].w4, wbuf[Bi], bc, wl16); }); }
+            if constexpr (BROT) { bias_store(0, bv0); bias_store(1, bv1); }
 #pragma unroll
             for (int k = 0; k < NX; ++k) { const int idx = tq0 + k * 512; *(v4i*)(xin + (idx / CHX) * IS + (idx % CHX) * 16) = vx[k]; }
 #pragma unroll
@@ -320,8 +345,11 @@ chain_kernel(const ChainArgs a) {
             {
                 constexpr bool TAILB = decltype(dsc)::value == 2;   // 0: identity block, 1: stage-opening block (same resolution), 2: only the join of one (TAIL)
                 if constexpr (!TAILB) ++seq;
+                int bnext[NBI];                                 // BROT: the next block's biases travel during P1 / P2 and land in the other slot before P3
+                const bool bfetch = BROT && !TAILB && b + 1 < a.nblk;
+                if constexpr (BROT && !TAILB) { if (bfetch) bias_fetch(b + 1, bnext); }
                 const ChainBlk& B = a.blk[b];
-                const int* const bl = bias_lds + b * BIAS_INTS;
+                const int* const bl = bias_lds + (BROT ? (b & 1) : b) * BIAS_INTS;
                 constexpr bool DSB = decltype(dsc)::value != 0; // this block is the stage-opening block (first block of a DS0 chain)
                 constexpr int NK1B = DSB ? KS : NK1;
                 constexpr bool ROT1 = ROT && !DSB;
@@ -554,6 +582,7 @@ chain_kernel(const ChainArgs a) {
                     }
                 }
                 F8_CT(3);
+                if constexpr (BROT) { if (bfetch) bias_store(b + 1, bnext); }      // slot (b + 1) & 1 held block b - 1's: dead since that block's last barrier
                 __syncthreads();                                // mid2 is complete; nobody reads the patch any more
                 }   // !TAILB
 
@@ -625,7 +654,7 @@ chain_kernel(const ChainArgs a) {
                                 bias_init(acc[0], ct); acc[1] = acc[0];
 #pragma unroll
                                 for (int g = 0; g < 4; ++g) {
-                                    const v4i bs = *(const v4i*)(bias_lds + MAXB * BIAS_INTS + ct * 32 + 8 * g + 4 * lh);
+                                    const v4i bs = *(const v4i*)(bias_lds + BSLOTS * BIAS_INTS + ct * 32 + 8 * g + 4 * lh);
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) { res[2 * H2][I][4 * g + e] = bs[e]; res[2 * H2 + 1][I][4 * g + e] = bs[e]; }
                                 }
@@ -666,7 +695,7 @@ chain_kernel(const ChainArgs a) {
                                 if constexpr (DSB) {    // the shortcut product accumulates straight into the stream registers (they are born here)
 #pragma unroll
                                     for (int g = 0; g < 4; ++g) {
-                                        const v4i bs = *(const v4i*)(bias_lds + MAXB * BIAS_INTS + ct * 32 + 8 * g + 4 * lh);
+                                        const v4i bs = *(const v4i*)(bias_lds + BSLOTS * BIAS_INTS + ct * 32 + 8 * g + 4 * lh);
 #pragma unroll
                                         for (int e = 0; e < 4; ++e) res[PT][I][4 * g + e] = bs[e];
                                     }
@@ -767,14 +796,15 @@ bool chain_supported(int C, int MID, int H, int W, int cin0) {
     return false;
 }
 // ... starting with the JOIN of a stride-2 opening block (TAIL): H, W = the stage's resolution, cin0 = the block input's channels
-bool chain_tail_supported(int C, int MID, int H, int W, int cin0) { return C == 512 && MID == 128 && H == 28 && W == 28 && cin0 == 256; }
-int chain_max_blocks(int C, int MID, int H, int W, int cin0, bool tail) { (void)C; (void)MID; (void)H; (void)W; (void)cin0; return tail ? 4 : kChainMaxBlocks; }
+bool chain_tail_supported(int C, int MID, int H, int W, int cin0) {
+    return (C == 512 && MID == 128 && H == 28 && W == 28 && cin0 == 256) || (C == 1024 && MID == 256 && H == 14 && W == 14 && cin0 == 512);
+}
+int chain_max_blocks(int C, int MID, int H, int W, int cin0, bool tail) { (void)C; (void)MID; (void)H; (void)W; (void)cin0; (void)tail; return kChainMaxBlocks; }
 int chain_tiles_per_img(int H, int W) { (void)W; return (H + 3) / 4; }
 
 template <int C, int MID, int W, int H, int R, int CIN0, int NB, int NBUF, int FAST, bool ROT, bool TAIL = false>
 static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t s) {
-    using Cfg = ChainCfg<C, MID, W, H, R, CIN0, TAIL ? 4 : kChainMaxBlocks>;
-    if (a.nblk > Cfg::MAXB) return hipErrorInvalidValue;
+    using Cfg = ChainCfg<C, MID, W, H, R, CIN0, TAIL>;
     static unsigned long long attr_done = 0; int attr_dev = -1;
     if (!dyn_lds_opted_in(&attr_done, &attr_dev)) {
         hipError_t e = hipFuncSetAttribute((const void*)chain_kernel<C, MID, W, H, R, CIN0, NB, NBUF, FAST, ROT, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
@@ -863,6 +893,11 @@ hipError_t launch_chain(const ChainArgs& a, int C, int MID, int H, int W, int ci
 #define F8_CHAIN_ROT false      // measured on the 14x14 instance: 466 k cycles per workgroup without the K rotation, 512 k with it
 #endif
     if (C == 1024 && MID == 256 && H == 14 && W == 14 && cin0 == 1024) return F8_CHAIN_INST(1024, 256, 14, 14, 4, 1024, F8_CH_S2);
+    if (C == 1024 && MID == 256 && H == 14 && W == 14 && cin0 == 512 && a.tail) {
+        if (!a.m2in || !a.x8in) return hipErrorInvalidValue;
+        return fast == 1 ? launch_chain_t<1024, 256, 14, 14, 4, 512, F8_CH_S2, 1, false, true>(a, s) : fast == 2 ? launch_chain_t<1024, 256, 14, 14, 4, 512, F8_CH_S2, 2, false, true>(a, s)
+                                                                                                             : launch_chain_t<1024, 256, 14, 14, 4, 512, F8_CH_S2, 0, false, true>(a, s);
+    }
 #undef F8_CHAIN_ROT
 #undef F8_CHAIN_INST
     return hipErrorInvalidValue;

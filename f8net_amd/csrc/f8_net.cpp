@@ -903,6 +903,15 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 *bk = Blk{i, h.a, ND[h.fused_add].out, h.cd.cout, a0.cd.cout, y.H, y.W, a0.cd.cin, true, true};
                 return true;
             }
+            if (h.dual >= 0 && h.fbd_a < 0 && h.cd.stride == 2 && h.cd.kernel == 1 && h.cd.quant_input && opt.fuse_tail) {
+                // the same for an opening block whose convs run as separate launches (stages 2 / 3 of ResNet-50; stage 1 when body.0 and the shortcut
+                // read different int8 forms): the dual-GEMM join (1c) becomes the chain's first block, body.2's int8 output is its mid2
+                const Node& g = ND[h.dual]; const Tensor& y = T[ND[h.fused_add].out];
+                if (g.cd.kernel == 1 && g.cd.stride == 1 && g.cd.quant_input && !g.cd.relu && !h.cd.relu) {
+                    *bk = Blk{i, h.a, ND[h.fused_add].out, h.cd.cout, g.cd.cin, y.H, y.W, h.cd.cin, true, true};
+                    return true;
+                }
+            }
             return false;
         };
         for (int i = 0; i < nn; ++i) {
@@ -934,9 +943,12 @@ int f8_net_finalize(f8_net* net, int max_batch) {
             if (first.tail) {
                 // the opener becomes: [body.0 + body.2 on f8_opener.hip (P12), host = the 3x3, output = mid2 in body.4's int8 format] + [the chain's first block]
                 Node& h = ND[first.host];
-                const int ia = h.fbd_a, ib = h.fbd_b;
-                ND[ia].absorbed_by = ib; ND[ib].absorbed_by = -1; ND[ib].p12_a = ia; ND[ib].p12_s2 = true; ND[ib].fb_R = h.fb_R;
-                h.fbd_a = h.fbd_b = -1; h.fbd_s2 = false; h.tail = true;
+                if (h.fbd_a >= 0) {
+                    const int ia = h.fbd_a, ib = h.fbd_b;
+                    ND[ia].absorbed_by = ib; ND[ib].absorbed_by = -1; ND[ib].p12_a = ia; ND[ib].p12_s2 = true; ND[ib].fb_R = h.fb_R;
+                    h.fbd_a = h.fbd_b = -1; h.fbd_s2 = false;
+                }
+                h.tail = true;
             }
         }
         // identity blocks that only the chain kernel could run and that did not end up in a chain: back to separate launches

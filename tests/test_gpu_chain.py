@@ -162,14 +162,16 @@ def _run_stage_chain(dev, cfg, variant, tail, options=None, big_bias=False):
 
 # ... starting with the JOIN of the stage-opening block whose 3x3 and shortcut have stride 2 (fix_resnet.py:55-77; ResNet-50 stage 1): its body.0 +
 # body.2 run on f8_opener.hip (P12: mid2 -> HBM, int8), its join (body.4 + 1x1 / 2 shortcut) is the first block of the chain launch (TAIL)
-TAIL_CHAINS = [(512, 128, 28, 3, 256, 3), (512, 128, 28, 1, 256, 5), (512, 128, 28, 3, 256, 37)]   # C, MID, H = W of the stage, identity blocks, CIN0, N
+TAIL_CHAINS = [(512, 128, 28, 3, 256, 3), (512, 128, 28, 1, 256, 5), (512, 128, 28, 3, 256, 37),   # C, MID, H = W of the stage, identity blocks, CIN0, N
+               (1024, 256, 14, 2, 512, 3), (1024, 256, 14, 5, 512, 70)]          # ResNet-50 stage 2: the opener's convs are launches of their own, its dual-GEMM join opens the chain
 
 
 @pytest.mark.parametrize('cfg', TAIL_CHAINS, ids=lambda g: 'x'.join(map(str, g)))
 @pytest.mark.parametrize('variant', ['body_shifts_left', 'shortcut_shifts_left', 'two_input_forms', 'requant_float=0', 'fuse_tail=0'])
 def test_stage_chain_opened_by_a_stride2_block_matches_oracle(dev, cfg, variant):
-    """`two_input_forms`: body.0 and the shortcut read the block input in DIFFERENT int8 formats — the planner does not fuse that opener at all
-    (pass 1d) and the stage must still equal the oracle; `fuse_tail=0`: the round-3 plan (whole opener in one launch, identity chain behind it)."""
+    """`two_input_forms`: body.0 and the shortcut read the block input in DIFFERENT int8 formats — the planner does not fuse body.0 + body.2 on the
+    opener kernel (pass 1d) but the dual-GEMM join still opens the chain; `fuse_tail=0`: the round-3 plan (whole opener in one launch / a dual-GEMM
+    launch, identity chain behind it)."""
     C, MID, HW, nid, CIN0, N = cfg
     if N > 8 and variant not in ('body_shifts_left', 'requant_float=0'):
         pytest.skip('format variants are covered at the small batch')
@@ -217,12 +219,13 @@ def test_stage_chain_opened_by_a_stride2_block_matches_oracle(dev, cfg, variant)
     net.output(r, as_float=False)
     net.finalize(N)
     plan = net.describe()
-    if variant in ('two_input_forms', 'fuse_tail=0'):
+    if variant == 'fuse_tail=0':
         assert '_tail' not in plan and '_p12' not in plan, plan
         if nid >= 2:
             assert f'stage_chain_x{nid}:' in plan, plan
     else:
-        assert f'stage_chain_x{nid + 1}_tail' in plan and 'fused_opener_s2_p12' in plan, plan
+        assert f'stage_chain_x{nid + 1}_tail' in plan, plan
+        assert ('fused_opener_s2_p12' in plan) == (HW == 28 and variant != 'two_input_forms'), plan
     got = net.run(_t(x, dev)).cpu().numpy().reshape(N, C, HW, HW)
     net.check()
 

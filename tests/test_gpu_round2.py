@@ -238,6 +238,7 @@ def _nccl_worker(rank, world, port, q):
     from f8net_amd import synth as sy, topology as tp
     from f8net_amd.net import build_net
     r, w, lr = f8dist.init_from_env(backend='nccl')
+    assert th.distributed.get_backend() == 'nccl'        # RCCL, not a silent gloo fallback
     dev = th.device('cuda', lr)
     th.cuda.set_device(dev)
     spec = tp.get('resnet50', normalize=True)
@@ -256,6 +257,7 @@ def _nccl_worker(rank, world, port, q):
     pf.finish()
     th.cuda.synchronize(dev)
     res = {rep: full.cpu().numpy() for rep, full in outs[-2:]}       # the buffers still holding their last results
+    res['device'] = th.cuda.current_device()
     q.put((rank, res))
     th.distributed.barrier()
     th.distributed.destroy_process_group()
@@ -277,6 +279,7 @@ def test_two_ranks_over_rccl_match_oracle(dev):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    assert got[0]['device'] != got[1]['device']          # one GPU per rank
     spec = topology.get('resnet50', normalize=True)
     params = synth.reference_params(spec, seed=1234)
     for rep in (4, 5):
