@@ -264,39 +264,64 @@ chain_kernel(const ChainArgs a) {
         for (int j = 0; j < (int)(sizeof(xf) / sizeof(xf[0])); ++j) asm volatile("" : "+v"(xf[j]));
     };
 
+    // ---- stage-opening first blocks: the tile's int8 input is REQUESTED one image ahead — after the last block of the previous image, BEFORE that
+    //      image's output stores (VMEM retires in order: loads issued behind 57 KB of stores would wait for their drain) — and lands in LDS at
+    //      the top of the next round (round 4; the registers are free there: the stream is dead between the last finish and the next join)
+    constexpr int CHX = CIN0 / 16, CHM = MID / 16;
+    constexpr int NXI = DS0 ? (NPT * 32 * CHX + 511) / 512 : 0, NMI = TAIL ? (NPT * 32 * CHM + 511) / 512 : 0;
+    v4i vin[NXI + NMI > 0 ? NXI + NMI : 1];
+    auto in_issue = [&](int n, bool live) {     // !live: zeros (every register is (re)defined here on every path: nothing stays live through the blocks)
+        if constexpr (DS0) {
+            int tq0 = tid; asm volatile("" : "+v"(tq0));
+            const int mt0 = (n * H + p0) * W;
+#pragma unroll
+            for (int k = 0; k < NXI; ++k) {
+                const int idx = tq0 + k * 512, row = idx / CHX, c16 = idx % CHX;
+                vin[k] = v4i{0, 0, 0, 0};
+                if constexpr (TAIL) {       // the shortcut's operand: pixels (2 (p0 + r), 2 c) of the block input (2H x 2W, CIN0 channels)
+                    const int pr = row / W, pc = row - pr * W;
+                    if (live && row < npx) vin[k] = *(const v4i*)(a.x8in + ((size_t)(n * 2 * H + 2 * (p0 + pr)) * (2 * W) + 2 * pc) * CIN0 + c16 * 16);
+                } else {
+                    if (live && row < npx) vin[k] = *(const v4i*)(a.x8in + (size_t)(mt0 + row) * CIN0 + c16 * 16);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NMI; ++k) {   // TAIL: body.2's output
+                const int idx = tq0 + k * 512, row = idx / CHM, c16 = idx % CHM;
+                vin[NXI + k] = v4i{0, 0, 0, 0};
+                if (live && row < npx) vin[NXI + k] = *(const v4i*)(a.m2in + (size_t)(mt0 + row) * MID + c16 * 16);
+            }
+        }
+    };
+    auto in_commit = [&]() {
+        if constexpr (DS0) {
+            int tq0 = tid; asm volatile("" : "+v"(tq0));
+#pragma unroll
+            for (int k = 0; k < NXI; ++k) { const int idx = tq0 + k * 512; if (idx < NPT * 32 * CHX) *(v4i*)(xin + (idx / CHX) * IS + (idx % CHX) * 16) = vin[k]; }
+#pragma unroll
+            for (int k = 0; k < NMI; ++k) { const int idx = tq0 + k * 512; if (idx < NPT * 32 * CHM) *(v4i*)(mid2 + (idx / CHM) * MS + (idx % CHM) * 16) = vin[NXI + k]; }
+        }
+    };
+#ifndef F8_CH_PREFETCH
+#define F8_CH_PREFETCH 1          // 0 (tuning builds): the input tile is requested at the top of its own round
+#endif
+    if (F8_CH_PREFETCH) in_issue(grp < a.N ? grp : 0, grp < a.N);
+
     for (int n = grp; n < a.N; n += a.NG) {
         const int m_tile = (n * H + p0) * W;                    // global pixel index of the tile's first pixel
+        if (!F8_CH_PREFETCH) in_issue(n, true);
 
         // =====================================================================================
         // stage input -> registers (identity first block) / LDS (stage-opening first block)
         // =====================================================================================
         if constexpr (TAIL) {
             static_assert(KT2 % NB == 0 && KS % NB == 0 && NPT % 2 == 0, "TAIL: whole batches per K loop, pixel-tile pairs");
-            // xin <- the shortcut's operand: pixels (2 (p0 + r), 2 c) of the block input (2H x 2W, CIN0 channels); mid2 <- body.2's output
-            constexpr int CHX = CIN0 / 16, CHM = MID / 16, NX = NPT * 32 * CHX / 512, NM = NPT * 32 * CHM / 512;
-            static_assert((NPT * 32 * CHX) % 512 == 0 && (NPT * 32 * CHM) % 512 == 0, "whole passes");
-            int tq0 = tid; asm volatile("" : "+v"(tq0));
-            v4i vx[NX], vm[NM];
-#pragma unroll
-            for (int k = 0; k < NX; ++k) {
-                const int idx = tq0 + k * 512, row = idx / CHX, c16 = idx % CHX, pr = row / W, pc = row - pr * W;
-                vx[k] = v4i{0, 0, 0, 0};
-                if (row < npx) vx[k] = *(const v4i*)(a.x8in + ((size_t)(n * 2 * H + 2 * (p0 + pr)) * (2 * W) + 2 * pc) * CIN0 + c16 * 16);
-            }
-#pragma unroll
-            for (int k = 0; k < NM; ++k) {
-                const int idx = tq0 + k * 512, row = idx / CHM, c16 = idx % CHM;
-                vm[k] = v4i{0, 0, 0, 0};
-                if (row < npx) vm[k] = *(const v4i*)(a.m2in + (size_t)(m_tile + row) * MID + c16 * 16);
-            }
+            // xin <- the shortcut's operand, mid2 <- body.2's output: requested one image ahead (in_issue)
             int bv0[NBI], bv1[NBI];
             if constexpr (BROT) { bias_fetch(0, bv0); bias_fetch(a.nblk > 1 ? 1 : 0, bv1); }
             { F8_LANES; static_for<(NBUF - 1 < NBT ? NBUF - 1 : NBT)>([&](auto bc) { constexpr int Bi = decltype(bc)::value; wt_load(a.blk[0].wsc, a.blk[0].w4, wbuf[Bi], bc, wl16); }); }
             if constexpr (BROT) { bias_store(0, bv0); bias_store(1, bv1); }
-#pragma unroll
-            for (int k = 0; k < NX; ++k) { const int idx = tq0 + k * 512; *(v4i*)(xin + (idx / CHX) * IS + (idx % CHX) * 16) = vx[k]; }
-#pragma unroll
-            for (int k = 0; k < NM; ++k) { const int idx = tq0 + k * 512; *(v4i*)(mid2 + (idx / CHM) * MS + (idx % CHM) * 16) = vm[k]; }
+            in_commit();
         } else if constexpr (!DS0) {
             F8_LANES;
             const ChainBlk& B0 = a.blk[0];
@@ -325,15 +350,8 @@ chain_kernel(const ChainArgs a) {
                 for (int i = 0; i < CTW; ++i)
                     *(v4i*)(x8 + xlane + pt * 32 * XS + (wave * CTW + i) * 32) = quant_tile16<FAST>(res[pt][i], B0.nq, FAST ? 0 : B0.loq, FAST ? 255 : B0.hiq, FAST ? 0x80808080u : B0.xorq);
         } else {
-            constexpr int CH = CIN0 / 16;                       // 16-byte chunks per pixel
-            int tq0 = tid; asm volatile("" : "+v"(tq0));         // (nothing derived from the thread id is hoisted out of the image loop: it would spill)
-            for (int idx = tq0; idx < NPT * 32 * CH; idx += 512) {
-                const int row = idx / CH, c16 = idx % CH;
-                v4i v = {0, 0, 0, 0};
-                if (row < npx) v = *(const v4i*)(a.x8in + (size_t)(m_tile + row) * CIN0 + c16 * 16);
-                *(v4i*)(xin + row * IS + c16 * 16) = v;
-            }
             { F8_LANES; w1_prime(a.blk[0].w0, std::integral_constant<int, KS>{}, wl16); }
+            in_commit();                                        // the stage input tile, requested one image ahead (in_issue)
         }
         __syncthreads();
         F8_CT(0);
@@ -753,6 +771,7 @@ chain_kernel(const ChainArgs a) {
         else if constexpr (DS0) block(0, std::integral_constant<int, 1>{});
         for (int b = DS0 ? 1 : 0; b < a.nblk; ++b) block(b, std::integral_constant<int, 0>{});
 
+        if (F8_CH_PREFETCH) in_issue(n + a.NG < a.N ? n + a.NG : n, n + a.NG < a.N);   // the next image's input tile: ahead of the output stores in the memory queue
         // ---- the int8 copy of the stage output: LDS rows -> whole NHWC rows in HBM
         if (a.q[0].ptr) {
             constexpr int CH = C / 16;
