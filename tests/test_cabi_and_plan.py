@@ -123,14 +123,18 @@ def test_plan_runs_each_stage_as_one_chain_launch():
         net = build_net(spec, synth.make_params(spec, 1234, topology.R50_NVIDIA_FRACLENS), max_batch=mb, hw=224)
         lines = net.describe().splitlines()
         chains = [l for l in lines if 'stage_chain_x' in l]
-        assert [l.split()[1].split(':')[0] for l in chains] == ['stage_chain_x3_ds', 'stage_chain_x3', 'stage_chain_x5'], net.describe()
+        # stage 0: opened by its (same-resolution) opening block; stages 1 and 2: by the JOIN of their stride-2 opening block (round 4: TAIL)
+        assert [l.split()[1].split(':')[0] for l in chains] == ['stage_chain_x3_ds', 'stage_chain_x4_tail', 'stage_chain_x6_tail'], net.describe()
         assert all('i32=0' in l and 'i8=1' in l for l in chains)          # the next stage's opening block reads int8 only
         assert not any('fused_bottleneck' in l for l in lines)
-        assert 'stage_0_layer_0.body.0..stage_0_layer_2.body.4' in chains[0] and 'stage_2_layer_1.body.0..stage_2_layer_5.body.4' in chains[2]
-        # the stage-1 opener (stride 2) stays its own launch and hands the chain the int32 stream only (no int8 copy)
+        assert 'stage_0_layer_0.body.0..stage_0_layer_2.body.4' in chains[0] and 'stage_2_layer_0.body.4..stage_2_layer_5.body.4' in chains[2]
+        # body.0 + body.2 of the stage-1 opener are one launch that writes mid2 as int8; no int32 tensor exists between a stage's blocks or in front of its chain
         opener = [l for l in lines if 'fused_opener_s2' in l]
-        assert len(opener) == 1 and 'i32=1 i8=0' in opener[0]
-    assert net.num_launches <= 21
+        assert len(opener) == 1 and 'fused_opener_s2_p12' in opener[0] and 'i32=0 i8=1' in opener[0]
+        assert sum('i32=1' in l for l in lines) == 3                      # stage 3: its opener's join and the two 7x7 identity joins
+    assert net.num_launches <= 17
+    off = build_net(spec, synth.make_params(spec, 1234, topology.R50_NVIDIA_FRACLENS), max_batch=128, hw=224, options={'fuse_tail': 0}).describe()
+    assert 'stage_chain_x3:' in off and 'stage_chain_x5:' in off and '_tail' not in off and '_p12_R' not in off      # the round-3 plan
     # ResNet-18 / MobileNets have no bottleneck blocks: nothing changes for them
     for arch in ('resnet18', 'mobilenet_v2'):
         sp = topology.get(arch)
@@ -223,7 +227,7 @@ def test_smoke_plans_hold_the_kernels_smoke_asserts():
     change that silently drops one of them would otherwise only fail on the GPU box)."""
     r50 = topology.get('resnet50', normalize=True)
     plan = build_net(r50, synth.make_params(r50, seed=3, fraclens=topology.R50_NVIDIA_FRACLENS), max_batch=2, hw=224).describe()
-    assert all(k in plan for k in ('stem7x7s2+maxpool3x3s2', 'stage_chain_x5', '_dual', 'fused_p12')), plan
+    assert all(k in plan for k in ('stem7x7s2+maxpool3x3s2', 'stage_chain_x3_ds', 'stage_chain_x6_tail', 'fused_opener_s2_p12', '_dual', 'fused_p12:')), plan
     r18 = topology.get('resnet18')
     plan = build_net(r18, synth.make_params(r18, seed=3), max_batch=2, hw=224).describe()
     assert 'basic_chain_x2_ds' in plan and 'patch' in plan, plan
