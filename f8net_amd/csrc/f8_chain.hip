@@ -409,9 +409,24 @@ chain_kernel(const ChainArgs a) {
                 // ============================ P1: mid1 = requant(relu(W0 . x8 + b0)) -> patch interior   (its first weight batches are in flight)
                 {
                     F8_LANES_P12;
-                    {   // the whole patch <- biased zero: border columns, rows outside the image; everything else is overwritten below
+#ifndef F8_CH_BFILL
+#define F8_CH_BFILL 1             // 0 (tuning builds): the whole patch is filled, with a barrier between the fill and the epilogue's interior stores
+#endif
+                    {   // patch BORDER <- biased zero: row 0, the rows below the tile's last row (halo row; rows of a ragged last tile), the two side columns of the
+                        // interior rows.  Round 4: only the border — disjoint from what the epilogue below writes, so no barrier stands between the two
+                        // (the whole-patch fill of round 3 needed one); the halo rows of tiles with a neighbour are overwritten in consume()
                         const v4i zv = {(int)xor1, (int)xor1, (int)xor1, (int)xor1};
-                        for (int o = tq_ * 16; o < Cfg::PATCH_BYTES; o += 512 * 16) *(v4i*)(patch + o) = zv;
+                        if constexpr (F8_CH_BFILL) {
+                            constexpr int RB = PW * MS, CPM = MS / 16;
+                            for (int o = tq_ * 16; o < RB; o += 512 * 16) *(v4i*)(patch + o) = zv;
+                            for (int o = (rows + 1) * RB + tq_ * 16; o < Cfg::PR * RB; o += 512 * 16) *(v4i*)(patch + o) = zv;
+                            if (tq_ < rows * 2 * CPM) {
+                                const int r = tq_ / (2 * CPM), q = tq_ - r * 2 * CPM, sidec = q / CPM, c16 = q - sidec * CPM;
+                                *(v4i*)(patch + ((r + 1) * PW + (sidec ? PW - 1 : 0)) * MS + c16 * 16) = zv;
+                            }
+                        } else {
+                            for (int o = tq_ * 16; o < Cfg::PATCH_BYTES; o += 512 * 16) *(v4i*)(patch + o) = zv;
+                        }
                     }
                     v16i acc[NPW];
 #pragma unroll
@@ -450,7 +465,7 @@ chain_kernel(const ChainArgs a) {
                     });
                     F8_CT(7);
                     w2_prime(pw2, wl16);                                // body.2's first weight batches travel during the epilogue and the halo exchange
-                    __syncthreads();                            // the zero fill is complete
+                    if constexpr (!F8_CH_BFILL) __syncthreads();     // the (whole-patch) zero fill is complete
                     F8_CT(8);
                     const int floor0 = relu_a ? 0 : INT32_MIN;
                     const __amdgpu_buffer_rsrc_t rxp = __builtin_amdgcn_make_buffer_rsrc((void*)a.xchg, 0, (unsigned)kChainXchgBytes, 0x00020000);
@@ -498,6 +513,8 @@ chain_kernel(const ChainArgs a) {
                     if (tid == 0) __hip_atomic_store(flags + L, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     F8_CT(11);
                 }
+                // (Tried in round 4 and not kept: ONE wave per neighbour doing the whole hand-over — lane 0 polls, its 64 lanes fetch four pieces each — which
+                // saves the barrier between poll and fetch: no faster on any instance, 231-234 vs 234-237 us per 128 images on the 56x56 launch.)
                 auto consume = [&]() {
                   if constexpr (T > 1) {
                     constexpr int RCH = ROWB / 16, CPE = MID / 16;

@@ -43,7 +43,7 @@ print('OK')
 
 SWITCHES = ['F8_FUSE_BLOCKS=0', 'F8_FUSE_STAGES=0', 'F8_FUSE_STAGES=7', 'F8_FUSE_DS=0', 'F8_FUSE_DUAL=0', 'F8_FUSE_STEM=0',
             'F8_PATCH3X3=0', 'F8_SPLIT=1', 'F8_SPLIT=3', 'F8_SPLIT_STREAMS=0', 'F8_GRAPH=1', 'F8_BK128=1', 'F8_DEEP_NK=1',
-            'F8_DUAL_WIDE=0', 'F8_CHUNK=0', 'F8_CHUNK=1', 'F8_CHUNK28=0', 'F8_CHUNK28=2', 'F8_BN=32', 'F8_BM=64', 'F8_RES_BN=128', 'F8_DW_DOT4=0', 'F8_STAGGER=0', 'F8_STEM_WPC=1', 'F8_FUSE_CHAIN=0', 'F8_FUSE_BCHAIN=0', 'F8_FUSE_BCHAIN=1', 'F8_STEM_ROWS=0', 'F8_DW_MMA=0', 'F8_FUSE_HEAD2=0', 'F8_REQUANT_FLOAT=0']
+            'F8_DUAL_WIDE=0', 'F8_CHUNK=0', 'F8_CHUNK=1', 'F8_CHUNK28=0', 'F8_CHUNK28=2', 'F8_BN=32', 'F8_BM=64', 'F8_RES_BN=128', 'F8_DW_DOT4=0', 'F8_STAGGER=0', 'F8_STEM_WPC=1', 'F8_FUSE_CHAIN=0', 'F8_FUSE_BCHAIN=0', 'F8_FUSE_BCHAIN=1', 'F8_STEM_ROWS=0', 'F8_DW_MMA=0', 'F8_FUSE_HEAD2=0', 'F8_REQUANT_FLOAT=0', 'F8_FUSE_TAIL=0']
 
 
 @pytest.mark.parametrize('switch', SWITCHES)
@@ -98,7 +98,7 @@ def test_chunked_execution_is_bit_exact_with_ragged_chunks():
 # Round-2 / round-3 planning and scheduling keys at a size where their kernels ARE planned (224x224, 8 images): per-handle options,
 # one process.  Each entry: options of one handle; results must equal the oracle bit for bit and the plan must change as stated.
 OPTION_SETS = [
-    ({}, 'stage_chain_x5'),
+    ({}, 'stage_chain_x6_tail'), ({'fuse_tail': 0}, 'stage_chain_x5'),      # the joins of the stride-2 opening blocks open their stages' chain launches / the round-3 plan
     ({'fuse_chain': 0}, 'fused_bottleneck_R'),
     ({'fuse_chain': 0, 'fuse_stages': 7}, 'fused_bottleneck_R7'),
     ({'fuse_chain': 0, 'fuse_ds': 0}, '_dual:'),
