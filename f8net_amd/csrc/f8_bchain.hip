@@ -78,6 +78,7 @@ bchain_kernel(const BChainArgs a) {
     using ic_ct = std::integral_constant<int, CT>;
     using ic_cti = std::integral_constant<int, CTI>;
 
+    if constexpr (FAST == 1) set_fp_round_nearest_even();
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const patchX = lds;                                   // [(R+2)][(W+2)][CS]: int8 copy of the stream in the first conv's input format, with halo
     char* const patchM = lds + Cfg::PATCH_BYTES;                // the same for `mid`

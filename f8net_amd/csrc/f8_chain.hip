@@ -131,6 +131,7 @@ chain_kernel(const ChainArgs a) {
     static_assert(WSTAT || NPT == 2, "streamed P3: exactly one pixel pair");
     static_assert(W <= 62, "tile");
 
+    if constexpr (FAST == 1) set_fp_round_nearest_even();
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const x8 = lds;                                       // [NPT*32 px][XS] int8, body.0's input format of the NEXT P1
     char* const patch = x8 + Cfg::X8_BYTES;                     // [(R+2)][(W+2)][MS] mid1, border = biased zero

@@ -55,6 +55,10 @@ __device__ __forceinline__ int requant1(int v, int n, int lo, int hi) {
 // (tools/ubench/cvt_u8_probe.hip, tests/test_gpu_requant_probe.py; n >= 17 differs from 2^24 on, as predicted) — the hosts select the
 // instances that use this only when every shift involved is in 1 .. 16 (kRequantU8MaxShift).
 constexpr int kRequantU8MaxShift = 16;
+// The float forms rely on ROUND-TO-NEAREST-EVEN in v_cvt_pk_u8_f32 (and v_cvt_f32_i32 above 2^24): that is the power-on state of the MODE register
+// and what HIP launches kernels with, but nothing else in the program states it — every kernel that instantiates a float form states it itself,
+// first thing (s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 4) = 0: FP_ROUND single / double = nearest even).
+__device__ __forceinline__ void set_fp_round_nearest_even() { __builtin_amdgcn_s_setreg(1 | (0 << 6) | (3 << 11), 0); }
 __device__ __forceinline__ float requant_u8_scale(int n) { return __builtin_ldexpf(1.0f, -n); }   // wave-uniform, hoisted
 __device__ __forceinline__ unsigned requant_u8x4(int a, int b, int c, int d, float scale) {
     unsigned r = __builtin_amdgcn_cvt_pk_u8_f32((float)a * scale, 0u, 0u);

@@ -33,6 +33,7 @@ __device__ __forceinline__ v4i dw_next_lane(const v4i& v) {   // lane i <- lane 
 template <int S, int FQ, int SUBS>
 __global__ void __launch_bounds__(256, S == 1 ? 4 : 3) dwconv3x3_mma_kernel(const DwArgs a) {
     constexpr int VW = SUBS == 2 ? 14 : DW_SW;                      // output columns per sub-row
+    if constexpr (FQ == 1) set_fp_round_nearest_even();
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 3;
     const int cts = a.Cs >> 5, strips = (a.Q + VW - 1) / VW, bands = (a.P + a.band - 1) / a.band;

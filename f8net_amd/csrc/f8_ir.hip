@@ -48,6 +48,7 @@ __global__ void __launch_bounds__(NW * 64, (COUT_S <= 64 ? 4 : COUT_S <= 96 ? 3 
     constexpr int W0_BYTES = 64 * CIN_S, W4_BYTES = COUT_S * 64;
     constexpr int W0_SLOTS = W0_BYTES / 16, W4_SLOTS = W4_BYTES / 16, SM_SLOTS = 36 + 16 + 16;   // dw weights (576 B), dw bias, expand bias
     constexpr int W0_L = (W0_SLOTS + NT - 1) / NT, W4_L = (W4_SLOTS + NT - 1) / NT;
+    if constexpr (FQ == 1) set_fp_round_nearest_even();
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const X = lds;                                   // [KK1][xp][32 B]
     char* const patch = lds + a.off_patch;                 // [2][G][PR][PW][32 B]: channel-tile planes, so that a wave's fragment read (one

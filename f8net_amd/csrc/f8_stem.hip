@@ -305,6 +305,7 @@ __device__ __forceinline__ v4i stem_quant16(const Y& y, int n, int lo, int hi, u
 template <int KIND, bool H2 = false>
 __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) stem_rows_kernel(const StemPoolArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];      // 2 x [RB_ROWS][PWB pixels][4 B] (patch column pc = input column pc - 5) | 64 biases
+    set_fp_round_nearest_even();                                    // stem_quant16 / quant_row may take the float-converter form (f8_device.h)
     const int tid = threadIdx.x;
     const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0 .. 7 compute, 8 .. 11 loaders

@@ -98,9 +98,14 @@ def invalidate_plans():
     _plans.d.clear()
 
 
-def _fingerprint(t):
-    """(sum, position-weighted sum) of an integer tensor; only computed when set_detect_data_edits(True)."""
-    if not _DETECT_DATA_EDITS:
+_AUDIT_PERIOD = max(1, int(os.environ.get('F8NET_PLAN_AUDIT_PERIOD', '64')))      # default guard: every N-th reuse of a plan re-reads its parameters
+_warned = [False]
+
+
+def _fingerprint(t, force=False):
+    """(sum, position-weighted sum) of an integer tensor; computed on every call only when set_detect_data_edits(True), and on every
+    F8NET_PLAN_AUDIT_PERIOD-th reuse of a plan otherwise (`force`)."""
+    if not (_DETECT_DATA_EDITS or force):
         return ()
     v = t.detach().reshape(-1).to(torch.int64)
     if v.numel() == 0:
@@ -119,13 +124,27 @@ class _PlanCache:
         ent = self.d.get(key)
         ver = tuple(None if t is None else (t._version, t.data_ptr()) + _fingerprint(t) for t in tensors)
         if ent is not None:
-            refs, ever, net = ent
+            refs, ever, net, audit = ent
             same = all((r is None and t is None) or (r is not None and r() is t) for r, t in zip(refs, tensors))
             if same and ever == ver and net.max_batch >= n:
-                self.d.move_to_end(key)
-                return net
+                # default guard against edits no version counter sees (`weight.data[...] = v`): every _AUDIT_PERIOD-th reuse the
+                # parameters are re-read (two reductions + one host sync per tensor) and compared with what the plan was built from
+                audit[0] += 1
+                stale = False
+                if not _DETECT_DATA_EDITS and audit[0] % _AUDIT_PERIOD == 0:
+                    stale = tuple(None if t is None else _fingerprint(t, True) for t in tensors) != audit[1]
+                    if stale and not _warned[0]:
+                        _warned[0] = True
+                        import warnings
+                        warnings.warn('f8net: a parameter of an op-level module was edited through `.data` (no version counter sees that); the plan was rebuilt '
+                                      f'at the periodic audit (every {_AUDIT_PERIOD} calls).  Call f8net_amd.torch_ops.invalidate_plans() after such edits, or '
+                                      'set_detect_data_edits(True) to check on every call.')
+                if not stale:
+                    self.d.move_to_end(key)
+                    return net
         net = build(max(n, 1))
-        self.d[key] = (tuple(None if t is None else weakref.ref(t) for t in tensors), ver, net)
+        self.d[key] = (tuple(None if t is None else weakref.ref(t) for t in tensors), ver, net,
+                       [0, tuple(None if t is None else _fingerprint(t, True) for t in tensors)])
         self.d.move_to_end(key)
         while len(self.d) > self.cap:
             self.d.popitem(last=False)

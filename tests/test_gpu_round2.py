@@ -81,6 +81,15 @@ def test_module_weight_edit_replans(dev):
         m.weight[7, 1, 0, 0] = 55                       # through the parameter: version bump
     w[7, 1, 0, 0] = 55
     np.testing.assert_array_equal(m(_t(x, dev)).cpu().numpy(), oracle.conv2d(x, w, np.zeros(32, np.int32), 1, 0))
+    # ... and, with nothing switched on, by the periodic audit of a reused plan (every F8NET_PLAN_AUDIT_PERIOD-th call, default 64)
+    m.weight.data[9, 2, 0, 0] = -13
+    w[9, 2, 0, 0] = -13
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for _ in range(tops._AUDIT_PERIOD):
+            y = m(_t(x, dev))
+    np.testing.assert_array_equal(y.cpu().numpy(), oracle.conv2d(x, w, np.zeros(32, np.int32), 1, 0))
 
 
 def test_net_forward_op_and_device_binding(dev):
