@@ -56,7 +56,7 @@ struct ChainCfg {
     static constexpr int ROWB = W * MID;                       // one exchanged row of mid1
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static_assert(X8_BYTES < 65536 + 4096 && PATCH_BYTES < 65536 && MID2_BYTES < 65536, "immediate offsets");
-    static_assert(ROWB / 16 <= 256 && (size_t)256 * 4 * ROWB <= kChainXchgBytes, "one 16-byte piece of a halo row per thread of a half workgroup");
+    static_assert(ROWB / 16 <= 256 && (size_t)512 * 4 * ROWB <= kChainXchgBytes, "one 16-byte piece of a halo row per thread of a half workgroup");
 };
 
 // 16 accumulator values of one 32x32 tile (this lane: one pixel, channels 8g + 4 lh + e) -> this lane's 16 bytes of the int8 row:
@@ -97,9 +97,9 @@ __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+s"(v)); retur
 // CIN0 channels) into LDS and computes  stream = clamp(((Wsc . x + bsc) << sa) + ((W4 . mid2 + b4) << sr)) [ReLU]  straight into the stream
 // registers, weights streamed — the block's int32 output (205 MB per 128 images in ResNet-50's stage 1) is neither written nor read back.
 template <int C, int MID, int W, int H, int R, int CIN0, int NB, int NBUF, int FAST, bool ROT, bool TAIL = false>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(R < 4 ? 4 : 2, R < 4 ? 4 : 2)))
 chain_kernel(const ChainArgs a) {
-    using Cfg = ChainCfg<C, MID, W, H, R, CIN0, TAIL>;
+    using Cfg = ChainCfg<C, MID, W, H, R, CIN0, TAIL || R < 4>;
     constexpr bool BROT = Cfg::BROT;
     constexpr int BSLOTS = Cfg::BSLOTS;
     constexpr bool DS0 = CIN0 != C;
@@ -351,7 +351,10 @@ chain_kernel(const ChainArgs a) {
                 for (int i = 0; i < CTW; ++i)
                     *(v4i*)(x8 + xlane + pt * 32 * XS + (wave * CTW + i) * 32) = quant_tile16<FAST>(res[pt][i], B0.nq, FAST ? 0 : B0.loq, FAST ? 255 : B0.hiq, FAST ? 0x80808080u : B0.xorq);
         } else {
+            int bv0[NBI];
+            if constexpr (BROT) bias_fetch(0, bv0);
             { F8_LANES; w1_prime(a.blk[0].w0, std::integral_constant<int, KS>{}, wl16); }
+            if constexpr (BROT) bias_store(0, bv0);
             in_commit();                                        // the stage input tile, requested one image ahead (in_issue)
         }
         __syncthreads();
@@ -837,11 +840,21 @@ bool chain_tail_supported(int C, int MID, int H, int W, int cin0) {
     return (C == 512 && MID == 128 && H == 28 && W == 28 && cin0 == 256) || (C == 1024 && MID == 256 && H == 14 && W == 14 && cin0 == 512);
 }
 int chain_max_blocks(int C, int MID, int H, int W, int cin0, bool tail) { (void)C; (void)MID; (void)H; (void)W; (void)cin0; (void)tail; return kChainMaxBlocks; }
-int chain_tiles_per_img(int H, int W) { (void)W; return (H + 3) / 4; }
+// Tried in round 4 and NOT kept in the default build: a 2-row instance of the 56x56 opening-block chain — half the tile, 64 stream registers, 128 VGPRs,
+// 78 KB of LDS, TWO workgroups per CU (four waves per SIMD) so that one workgroup's exchange / barrier waits hide behind the other's work.  Bit-exact
+// (tests/test_gpu_chain.py with -DF8_CH_R2_S0=1, option chain_r2 = 1) and SLOWER: 264-271 vs 231-234 us per 128 images, same box — twice the halo rows,
+// 12.5 % padding in the 32-pixel tiles, a weight fragment feeds one MFMA instead of two in P1 / P2, 40 bytes per lane of scratch.
+#ifndef F8_CH_R2_S0
+#define F8_CH_R2_S0 0             // 1 (tuning builds): compile that instance; option chain_r2 = 1 then selects it
+#endif
+void chain_shape(int C, int MID, int H, int W, int cin0, bool tail, int r2, int* R, int* wg_per_cu) {
+    *R = 4; *wg_per_cu = 1;
+    if (F8_CH_R2_S0 && r2 && !tail && C == 256 && MID == 64 && H == 56 && W == 56 && cin0 == 64) { *R = 2; *wg_per_cu = 2; }
+}
 
 template <int C, int MID, int W, int H, int R, int CIN0, int NB, int NBUF, int FAST, bool ROT, bool TAIL = false>
 static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t s) {
-    using Cfg = ChainCfg<C, MID, W, H, R, CIN0, TAIL>;
+    using Cfg = ChainCfg<C, MID, W, H, R, CIN0, TAIL || R < 4>;
     static unsigned long long attr_done = 0; int attr_dev = -1;
     if (!dyn_lds_opted_in(&attr_done, &attr_dev)) {
         hipError_t e = hipFuncSetAttribute((const void*)chain_kernel<C, MID, W, H, R, CIN0, NB, NBUF, FAST, ROT, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
@@ -849,7 +862,7 @@ static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t s) {
         if (attr_dev >= 0) attr_done |= 1ull << attr_dev;
     }
     const int grid = a.NG * Cfg::T;
-    if (grid < 1 || grid > 256) return hipErrorInvalidValue;
+    if (grid < 1 || grid > (R < 4 ? 512 : 256)) return hipErrorInvalidValue;
 #ifdef F8_TRACE
     static unsigned long long* tbuf = nullptr; static int count = 0;
     static const int want = [] { const char* e = getenv("F8_TRACE_CHAIN"); return e ? atoi(e) : -1; }();
@@ -915,6 +928,9 @@ hipError_t launch_chain(const ChainArgs& a, int C, int MID, int H, int W, int ci
     const int fast = chain_fast(a);
 #define F8_CHAIN_INST(...) (fast == 1 ? launch_chain_t<__VA_ARGS__, 1, F8_CHAIN_ROT>(a, s) : fast == 2 ? launch_chain_t<__VA_ARGS__, 2, F8_CHAIN_ROT>(a, s) : launch_chain_t<__VA_ARGS__, 0, F8_CHAIN_ROT>(a, s))
 #define F8_CHAIN_ROT false
+#if F8_CH_R2_S0
+    if (C == 256 && MID == 64 && H == 56 && W == 56 && cin0 == 64 && a.R == 2) return F8_CHAIN_INST(256, 64, 56, 56, 2, 64, F8_CH_S0);
+#endif
     if (C == 256 && MID == 64 && H == 56 && W == 56 && cin0 == 64) return F8_CHAIN_INST(256, 64, 56, 56, 4, 64, F8_CH_S0);
     if (C == 256 && MID == 64 && H == 56 && W == 56 && cin0 == 256) return F8_CHAIN_INST(256, 64, 56, 56, 4, 256, F8_CH_S0);
     if (C == 512 && MID == 128 && H == 28 && W == 28 && cin0 == 512) return F8_CHAIN_INST(512, 128, 28, 28, 4, 512, F8_CH_S1);

@@ -26,6 +26,7 @@ struct Options {
     int wreg = 1;                // late 1x1 convs on conv1x1_wreg_kernel (weights straight to registers, f8_wreg.hip)
     int fuse_bchain = 2;         // consecutive BasicBlock identity blocks of a stage in ONE launch (f8_bchain.hip); 2: with the stage-opening block in front of them
     int fuse_chain = 1;          // all consecutive bottleneck blocks of a stage in ONE launch, int32 residual stream in registers (f8_chain.hip)
+    int chain_r2 = 0;            // stage chains with a 2-row / two-workgroups-per-CU instance use it (tuning builds with -DF8_CH_R2_S0=1 only: measured slower, f8_chain.hip)
     int fuse_tail = 1;           // ... and the JOIN of a stride-2 stage-opening block as the first block of its stage's chain (its body.0 + body.2 on f8_opener.hip, P12)
     int chain_timeout_ms = 10000; // bound of its halo-exchange spins (another process holding the CUs for longer: sticky error word, logits poisoned, f8_net_check)
     int fuse_p12 = 1;            // 7x7 identity blocks: body.0 + body.2 in one launch, split over a workgroup pair per image (f8_p12.hip)
@@ -213,9 +214,11 @@ struct ChainArgs {
     int8_t* xchg;                          // halo rows between vertically adjacent tiles: [workgroup][parity][side][W * MID]
     uint32_t timeout_ticks;                // bound of every spin (100 MHz wall clock)
     void* trace;
+    int32_t R;                             // rows per tile of the instance to launch (chain_shape)
 };
-constexpr int kChainSyncWords = 16 + 256;
-constexpr size_t kChainXchgBytes = (size_t)256 * 2 * 2 * 3584;
+constexpr int kChainSyncWords = 16 + 512;   // [0] ticket, [1] workgroups out, [16 + workgroup] halo flags (up to two workgroups per CU)
+constexpr int kChainErrWord = 1000;          // the sticky error word, inside the first 4096 bytes of the scratch
+constexpr size_t kChainXchgBytes = (size_t)512 * 2 * 2 * 3584;
 
 // One launch for consecutive BasicBlock identity blocks of a ResNet-18 / 34 stage (f8_bchain.hip); weights in fragment order.
 struct BChainBlk {
@@ -319,7 +322,8 @@ hipError_t launch_fused_opener(const FusedArgs& a, hipStream_t s);
 bool chain_supported(int C, int MID, int H, int W, int cin0);
 bool chain_tail_supported(int C, int MID, int H, int W, int cin0);   // ... a stride-2 opening block's join as the first block (H, W = the stage's resolution)
 int chain_max_blocks(int C, int MID, int H, int W, int cin0, bool tail);
-int chain_tiles_per_img(int H, int W);
+// rows per tile (4, or 2: the two-workgroups-per-CU instance, option chain_r2) and resident workgroups per CU of the instance that runs the shape
+void chain_shape(int C, int MID, int H, int W, int cin0, bool tail, int r2, int* R, int* wg_per_cu);
 hipError_t launch_chain(const ChainArgs& a, int C, int MID, int H, int W, int cin0, hipStream_t s);
 // consecutive BasicBlock identity blocks of a stage in one launch (f8_bchain.hip)
 bool bchain_supported(int C, int H, int W);

@@ -252,6 +252,7 @@ static const OptKey kOptKeys[] = {
     {"fuse_p12", "F8_FUSE_P12", &Options::fuse_p12, 0, 1, true},
     {"fuse_chain", "F8_FUSE_CHAIN", &Options::fuse_chain, 0, 1, true},
     {"fuse_tail", "F8_FUSE_TAIL", &Options::fuse_tail, 0, 1, true},
+    {"chain_r2", "F8_CHAIN_R2", &Options::chain_r2, 0, 1, false},
     {"fuse_bchain", "F8_FUSE_BCHAIN", &Options::fuse_bchain, 0, 2, true},
     {"chain_timeout_ms", "F8_CHAIN_TIMEOUT_MS", &Options::chain_timeout_ms, 1, 1 << 20, false},
     {"wreg", "F8_WREG", &Options::wreg, 0, 1, true},
@@ -407,9 +408,9 @@ int f8_net_check(f8_net* net) {
     }
     for (int p = 0; net->d_chain && p < net->n_copies; ++p) {
         uint32_t w = 0;
-        if ((e = hipMemcpy(&w, net->d_chain + (size_t)p * net->chain_stride + 2048, 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "f8_net_check: hipMemcpy");
+        if ((e = hipMemcpy(&w, net->d_chain + (size_t)p * net->chain_stride + kChainErrWord * 4, 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "f8_net_check: hipMemcpy");
         if (w) {
-            (void)hipMemset(net->d_chain + (size_t)p * net->chain_stride + 2048, 0, 4);
+            (void)hipMemset(net->d_chain + (size_t)p * net->chain_stride + kChainErrWord * 4, 0, 4);
             return fail(F8_ERR_HIP, "f8_net_check: a stage-chain launch gave up waiting for a neighbouring tile (code 0x%x, arena copy %d): its outputs are invalid", w, p);
         }
     }
@@ -1397,7 +1398,9 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     st.name = "stage_chain_x" + std::to_string(ch.size()) + (tail ? "_tail:" : (ds ? "_ds:" : ":")) + tname(net, a0.out) + ".." + tname(net, nd.out);
                     char kb[160];
                     const int C = o.C, MID = tail ? a0.cd.cin : a0.cd.cout;
-                    snprintf(kb, sizeof kb, "f8::chain_kernel<%d, %d, %d, %d, 4, %d, %s, %d, false, %s>", C, MID, o.W, o.H, tail ? hf.cd.cin : a0.cd.cin, MID == 256 ? "2, 4" : (MID == 64 ? "2, 2" : "2, 3"), opt.requant_float ? 1 : 2, tail ? "true" : "false");   // keep in sync with launch_chain (the FAST instance: real fraclen tables)
+                    int cR = 4, cW = 1;
+                    chain_shape(C, MID, o.H, o.W, tail ? hf.cd.cin : a0.cd.cin, tail, opt.chain_r2, &cR, &cW);
+                    snprintf(kb, sizeof kb, "f8::chain_kernel<%d, %d, %d, %d, %d, %d, %s, %d, false, %s>", C, MID, o.W, o.H, cR, tail ? hf.cd.cin : a0.cd.cin, MID == 256 ? "2, 4" : (MID == 64 ? "2, 2" : "2, 3"), opt.requant_float ? 1 : 2, tail ? "true" : "false");   // keep in sync with launch_chain (the FAST instance: real fraclen tables)
                     st.kernel = kb;
                     break;
                 }
@@ -1992,7 +1995,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             fill_out(&a.out32, a.q);
             if (st.dense) {
                 a.w = (const int8_t*)(net->d_w + nd.wf_off);
-                e = launch_fc_dense(a, (char*)output + (size_t)n0 * oT.C * 4, oT.C, net->out_float, net->d_chain ? (const uint32_t*)(net->d_chain + (size_t)part * net->chain_stride + 2048) : nullptr, s);
+                e = launch_fc_dense(a, (char*)output + (size_t)n0 * oT.C * 4, oT.C, net->out_float, net->d_chain ? (const uint32_t*)(net->d_chain + (size_t)part * net->chain_stride + kChainErrWord * 4) : nullptr, s);
             } else if (nd.s2w) { a.w = (const int8_t*)(net->d_w + nd.wf_off); e = launch_conv3x3s2_wreg(a, s); }
             else if (nd.wstat) {
                 a.w = (const int8_t*)(net->d_w + nd.wf_off);
@@ -2160,15 +2163,18 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             const Node& a0 = tail ? net->nodes[hf.dual] : net->nodes[ds ? hf.fbd_a : hf.fb_a];
             const Tensor& oT = T[st.out.t];
             const int C = oT.C, MID = tail ? a0.cd.cin : a0.cd.cout;
-            const int tiles = chain_tiles_per_img(oT.H, oT.W);
-            // every workgroup of a chain launch must be resident (one per CU): a device with fewer CUs than one image has tiles cannot run it
-            if ((net->num_cu > 0 ? std::min(net->num_cu, 256) : 256) < tiles)
+            int wg_per_cu = 1;
+            chain_shape(C, MID, oT.H, oT.W, tail ? hf.cd.cin : a0.cd.cin, tail, net->opt.chain_r2, &a.R, &wg_per_cu);
+            const int tiles = (oT.H + a.R - 1) / a.R;
+            const int slots = (net->num_cu > 0 ? std::min(net->num_cu, 256) : 256) * wg_per_cu;
+            // every workgroup of a chain launch must be resident: a device with fewer slots than one image has tiles cannot run it
+            if (slots < tiles)
                 return fail(F8_ERR_STATE, "f8_net_run: a stage-chain launch needs %d co-resident workgroups per image, the device has %d compute units (plan with fuse_chain = 0 / fuse_bchain = 0)", tiles, net->num_cu);
-            a.N = N; a.NG = chain_groups(N, (net->num_cu > 0 ? std::min(net->num_cu, 256) : 256) / tiles);
+            a.N = N; a.NG = chain_groups(N, slots / tiles);
             fill_out(&a.out32, a.q);
             if (!net->d_chain) return fail(F8_ERR_STATE, "f8_net_run: chain scratch missing");
             a.sync = (uint32_t*)(net->d_chain + (size_t)part * net->chain_stride);
-            a.err = a.sync + 512;
+            a.err = a.sync + kChainErrWord;
             a.xchg = (int8_t*)(net->d_chain + (size_t)part * net->chain_stride + 4096);
             a.timeout_ticks = (uint32_t)std::min<long long>((long long)net->opt.chain_timeout_ms * 100000ll, 0x7fffffffll);
             e = launch_chain(a, C, MID, oT.H, oT.W, tail ? hf.cd.cin : a0.cd.cin, s);
@@ -2214,7 +2220,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             fill_out(&a.out32, a.q);
             if (!net->d_chain) return fail(F8_ERR_STATE, "f8_net_run: chain scratch missing");
             a.sync = (uint32_t*)(net->d_chain + (size_t)part * net->chain_stride);
-            a.err = a.sync + 512;
+            a.err = a.sync + kChainErrWord;
             a.xchg = (int8_t*)(net->d_chain + (size_t)part * net->chain_stride + 4096);
             a.timeout_ticks = (uint32_t)std::min<long long>((long long)net->opt.chain_timeout_ms * 100000ll, 0x7fffffffll);
             e = launch_bchain(a, x.C, x.H, x.W, s);
@@ -2329,7 +2335,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             OutArgs a{};
             a.x = (const int32_t*)fp(sT.forms[st.src_f]); a.N = N; a.C = sT.C; a.HW = sT.H * sT.W; a.Cs = sT.Cs;
             a.out = (char*)output + (size_t)n0 * sT.C * sT.H * sT.W * 4; a.as_float = net->out_float;
-            a.err = net->d_chain ? (const uint32_t*)(net->d_chain + (size_t)part * net->chain_stride + 2048) : nullptr;
+            a.err = net->d_chain ? (const uint32_t*)(net->d_chain + (size_t)part * net->chain_stride + kChainErrWord * 4) : nullptr;
             e = launch_output(a, s);
             break;
         }
