@@ -329,14 +329,17 @@ bool conv3x3_patch_config(int cin, int H, int W, int coutP, int* R, int* IMGS, i
     if (coutP < 64) return false;
     if (cin == 128 && W == 28 && H % 4 == 0) { *R = 4; *IMGS = 1; *BN = 128; return true; }
     if (cin == 256 && W == 14 && H % 7 == 0) { *R = 7; *IMGS = 1; *BN = 128; return true; }
-    if (cin == 512 && W == 7 && H == 7) { *R = 7; *IMGS = 2; *BN = 64; return true; }
+#ifndef F8_P3_BN7
+#define F8_P3_BN7 64              // cout tile of the 7x7x512 instance (64: two workgroups share an image pair's patch; tuning builds)
+#endif
+    if (cin == 512 && W == 7 && H == 7) { *R = 7; *IMGS = 2; *BN = F8_P3_BN7; return true; }
     return false;
 }
 
 hipError_t launch_conv3x3_patch(const ConvArgs& a, int cin, hipStream_t s) {
     if (cin == 128 && a.W == 28) return launch_patch_t<128, 28, 4, 1, 128, 128>(a, s);
     if (cin == 256 && a.W == 14) return launch_patch_t<256, 14, 7, 1, 128, 128>(a, s);
-    if (cin == 512 && a.W == 7) return launch_patch_t<512, 7, 7, 2, 64, 256>(a, s);
+    if (cin == 512 && a.W == 7) return launch_patch_t<512, 7, 7, 2, F8_P3_BN7, F8_P3_BN7 == 64 ? 256 : 128>(a, s);
     return hipErrorInvalidValue;
 }
 
