@@ -21,6 +21,13 @@
 #include <cstdio>
 #include <cstdlib>
 
+// Waves per workgroup.  8 = two per SIMD, four pixel tiles per wave (the default).  16 (tuning builds) = four per SIMD, two tiles per wave, 128 VGPRs:
+// tried in round 4 because the limiter is latency (rocprof_r04_r18_valu.md) — bit-exact and SLOWER on every instance (123 vs 119, 84 vs 78, 73 vs 66 us
+// per 128 images, same box): a weight fragment then feeds two MFMAs instead of four, twice the waves meet at every barrier, 8-28 bytes of scratch.
+#ifndef F8_BCH_NW
+#define F8_BCH_NW 8
+#endif
+
 namespace f8 {
 
 template <int C, int W, int H, int R, bool DS = false>
@@ -65,12 +72,13 @@ __device__ __forceinline__ int bopaque(int v) { asm volatile("" : "+s"(v)); retu
 
 // FAST: ReLU after the first conv and after the join, every int8 format of the chain unsigned with a right shift, the stream never shifted
 // DS: the chain starts with the stage-opening block (3x3 / 2 -> 3x3, 1x1 / 2 shortcut; C / 2 input channels at twice the resolution)
-template <int C, int W, int H, int R, int NB, int NBUF, int FAST, bool DS>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <int C, int W, int H, int R, int NB, int NBUF, int FAST, bool DS, int NW = 8>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
 bchain_kernel(const BChainArgs a) {
+    constexpr int NT = NW * 64;                                 // threads: 8 waves (two per SIMD) or 16 (four per SIMD: half the tiles per wave)
     using Cfg = BChainCfg<C, W, H, R, DS>;
     constexpr int T = Cfg::T, NPT = Cfg::NPT, PW = Cfg::PW, CS = Cfg::CS, ROWB = Cfg::ROWB;
-    constexpr int CT = C / 32, PG = 8 / CT, NPW = (NPT + PG - 1) / PG;
+    constexpr int CT = C / 32, PG = NW / CT, NPW = (NPT + PG - 1) / PG;
     constexpr int CTI = Cfg::CIN / 32, PWI = Cfg::PWI, IS = Cfg::IS;
     static_assert(CT == 2 || CT == 4 || CT == 8, "8 waves = CT channel tiles x PG pixel-tile groups");
     static_assert(NB <= CT && CT % NB == 0 && (!DS || (NB <= CTI && CTI % NB == 0)), "a batch of K steps stays inside one tap");
@@ -87,15 +95,15 @@ bchain_kernel(const BChainArgs a) {
     int* const misc = bias_lds + Cfg::BIAS_BYTES / 4;
 
     const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & (NW - 1);
     const int ct = wave & (CT - 1), pg = wave / CT;
 
     if (tid == 0) { misc[0] = (int)__hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); misc[1] = 0; }
     for (int b = 0; b < a.nblk; ++b) {
         const BChainBlk& B = a.blk[b];
-        for (int i = tid; i < 2 * C; i += 512) bias_lds[b * 2 * C + i] = i < C ? B.ba[i] : B.bb[i - C];
+        for (int i = tid; i < 2 * C; i += NT) bias_lds[b * 2 * C + i] = i < C ? B.ba[i] : B.bb[i - C];
     }
-    if constexpr (DS) for (int i = tid; i < C; i += 512) bias_lds[kBChainMaxBlocks * 2 * C + i] = a.bsc[i];
+    if constexpr (DS) for (int i = tid; i < C; i += NT) bias_lds[kBChainMaxBlocks * 2 * C + i] = a.bsc[i];
     __syncthreads();
     const int L = __builtin_amdgcn_readfirstlane(misc[0]);
     const int grp = L / T, ti = L - grp * T;
@@ -155,7 +163,7 @@ bchain_kernel(const BChainArgs a) {
             ++seq;
             constexpr int RCH = ROWB / 16, CPE = C / 16;
             const __amdgpu_buffer_rsrc_t rxc = __builtin_amdgcn_make_buffer_rsrc((void*)a.xchg, 0, (unsigned)kChainXchgBytes, 0x00020000);
-            const int side = tid >> 8, idx = tid & 255;
+            const int side = tid / (NT / 2), idx = tid % (NT / 2);
             const bool mine = idx < RCH && (side == 0 ? has_up : has_dn);
             if (mine) {
                 const int col = idx / CPE, c16 = idx % CPE;
@@ -179,7 +187,7 @@ bchain_kernel(const BChainArgs a) {
 #endif
             constexpr int RCH = ROWB / 16, CPE = C / 16;
             int t2 = tid; asm volatile("" : "+v"(t2));
-            if ((t2 == 0 && has_up) || (t2 == 256 && has_dn)) {
+            if ((t2 == 0 && has_up) || (t2 == NT / 2 && has_dn)) {
                 unsigned* const f = flags + (t2 == 0 ? L - 1 : L + 1);
                 const unsigned long long t0 = wall_clock64();
                 bool ok = true;
@@ -193,7 +201,7 @@ bchain_kernel(const BChainArgs a) {
                 if (!ok) __hip_atomic_store(a.err, 0x200u + (unsigned)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
-            const int side = t2 >> 8, idx = t2 & 255;
+            const int side = t2 / (NT / 2), idx = t2 % (NT / 2);
             if (idx < RCH && (side == 0 ? has_up : has_dn)) {
                 const __amdgpu_buffer_rsrc_t rxc = __builtin_amdgcn_make_buffer_rsrc((void*)a.xchg, 0, (unsigned)kChainXchgBytes, 0x00020000);
                 const int nb_wg = side == 0 ? L - 1 : L + 1;
@@ -272,7 +280,7 @@ bchain_kernel(const BChainArgs a) {
         auto fill_patchX = [&] {   // patchX <- biased zero (border; the interior is written before it is read)
             const unsigned zq = FAST ? 0x80808080u : a.blk[DS && a.nblk > 1 ? 1 : 0].xorq;
             const v4i zx = {(int)zq, (int)zq, (int)zq, (int)zq};
-            for (int o = tid * 16; o < Cfg::PATCH_BYTES; o += 512 * 16) *(v4i*)(patchX + o) = zx;
+            for (int o = tid * 16; o < Cfg::PATCH_BYTES; o += NT * 16) *(v4i*)(patchX + o) = zx;
         };
         if constexpr (!DS) fill_patchX();
         if constexpr (!DS) {   // ---- stage input (int32 stream) -> registers; its int8 copy -> patchX interior
@@ -300,7 +308,7 @@ bchain_kernel(const BChainArgs a) {
             __syncthreads();
             publish(patchX);
         } else {               // ---- opening block: its int8 input rows (NHWC, twice the resolution) -> patchI; left column / rows outside the image <- biased zero
-            constexpr int CPI = Cfg::CIN / 16, RCHI = 2 * W * CPI, NPC = Cfg::PRI * RCHI, PER = (NPC + 511) / 512;
+            constexpr int CPI = Cfg::CIN / 16, RCHI = 2 * W * CPI, NPC = Cfg::PRI * RCHI, PER = (NPC + NT - 1) / NT;
             const int8_t* const xin = a.x8in + (size_t)n * (2 * H) * (2 * W) * Cfg::CIN;
             const int r0 = 2 * p0 - 1, nr = 2 * rows + 1;
             const v4i zi = {(int)B0.xorq, (int)B0.xorq, (int)B0.xorq, (int)B0.xorq};
@@ -308,7 +316,7 @@ bchain_kernel(const BChainArgs a) {
             v4i v[PER];
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
-                const int idx = t3 + k * 512, pr = idx / RCHI, pc = idx - pr * RCHI;
+                const int idx = t3 + k * NT, pr = idx / RCHI, pc = idx - pr * RCHI;
                 const int ir = r0 + pr;
                 v[k] = zi;
                 if (idx < NPC && pr < nr && ir >= 0 && ir < 2 * H) v[k] = *(const v4i*)(xin + (size_t)ir * (2 * W * Cfg::CIN) + pc * 16);
@@ -316,13 +324,13 @@ bchain_kernel(const BChainArgs a) {
             w_prime(ic_cti{}, B0.wa, (unsigned)((t3 & 63) * 16));
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
-                const int idx = t3 + k * 512, pr = idx / RCHI, pc = idx - pr * RCHI;
+                const int idx = t3 + k * NT, pr = idx / RCHI, pc = idx - pr * RCHI;
                 if (idx < NPC) *(v4i*)(patchI + (pr * PWI + pc / CPI + 1) * IS + (pc % CPI) * 16) = v[k];
             }
-            for (int idx = t3; idx < Cfg::PRI * CPI; idx += 512) *(v4i*)(patchI + ((idx / CPI) * PWI) * IS + (idx % CPI) * 16) = zi;
+            for (int idx = t3; idx < Cfg::PRI * CPI; idx += NT) *(v4i*)(patchI + ((idx / CPI) * PWI) * IS + (idx % CPI) * 16) = zi;
             // the shortcut's operand: the pixels (2r, 2c) of the block input in the SHORTCUT's int8 format -> [R][W][IS] where patchX will be
             const int8_t* const xsc = a.x8sc + (size_t)n * (2 * H) * (2 * W) * Cfg::CIN;
-            for (int idx = t3; idx < npx * CPI; idx += 512) {
+            for (int idx = t3; idx < npx * CPI; idx += NT) {
                 const int px = idx / CPI, c16 = idx - px * CPI, pr = px / W, pc = px - pr * W;
                 *(v4i*)(patchX + px * IS + c16 * 16) = *(const v4i*)(xsc + ((size_t)(2 * (p0 + pr)) * (2 * W) + 2 * pc) * Cfg::CIN + c16 * 16);
             }
@@ -346,7 +354,7 @@ bchain_kernel(const BChainArgs a) {
             {   // ============ first conv: mid = requant(relu(conv3x3(x8) + ba)) -> patchM interior
                 {   // patchM <- biased zero (border, halo rows outside the image); nobody reads it before the barriers of this conv
                     const v4i zm = {(int)xor1, (int)xor1, (int)xor1, (int)xor1};
-                    for (int o = tid * 16; o < Cfg::PATCH_BYTES; o += 512 * 16) *(v4i*)(patchM + o) = zm;
+                    for (int o = tid * 16; o < Cfg::PATCH_BYTES; o += NT * 16) *(v4i*)(patchM + o) = zm;
                 }
                 v16i acc[NPW];
                 bool opened = false;
@@ -449,7 +457,7 @@ bchain_kernel(const BChainArgs a) {
         // ---- the first int8 form of the stage output: patchX interior -> whole NHWC rows in HBM
         if (a.q[0].ptr) {
             constexpr int CH = C / 16;
-            for (int idx = tid; idx < npx * CH; idx += 512) {
+            for (int idx = tid; idx < npx * CH; idx += NT) {
                 const int px = idx / CH, c16 = idx % CH;
                 const int pr = px / W, pc = px - pr * W;
                 const v4i v = *(const v4i*)(patchX + ((pr + 1) * PW + pc + 1) * CS + c16 * 16);
@@ -515,7 +523,7 @@ static hipError_t launch_bchain_t(const BChainArgs& a, hipStream_t s) {
     using Cfg = BChainCfg<C, W, H, R, DS>;
     static unsigned long long attr_done = 0; int attr_dev = -1;
     if (!dyn_lds_opted_in(&attr_done, &attr_dev)) {
-        hipError_t e = hipFuncSetAttribute((const void*)bchain_kernel<C, W, H, R, NB, NBUF, FAST, DS>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)bchain_kernel<C, W, H, R, NB, NBUF, FAST, DS, F8_BCH_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
         if (attr_dev >= 0) attr_done |= 1ull << attr_dev;
     }
@@ -527,7 +535,7 @@ static hipError_t launch_bchain_t(const BChainArgs& a, hipStream_t s) {
     BChainArgs b = a;
     const bool tracing = (count++ == want);
     if (tracing) { if (!tbuf) (void)hipMalloc((void**)&tbuf, (size_t)1 << 16); (void)hipMemsetAsync(tbuf, 0, (size_t)grid * 64, s); b.trace = tbuf; }
-    hipLaunchKernelGGL((bchain_kernel<C, W, H, R, NB, NBUF, FAST, DS>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, b);
+    hipLaunchKernelGGL((bchain_kernel<C, W, H, R, NB, NBUF, FAST, DS, F8_BCH_NW>), dim3(grid), dim3(F8_BCH_NW * 64), Cfg::LDS_BYTES, s, b);
     if (tracing) {
         (void)hipStreamSynchronize(s);
         static unsigned long long hb[256 * 8];
@@ -538,20 +546,20 @@ static hipError_t launch_bchain_t(const BChainArgs& a, hipStream_t s) {
     }
     return hipGetLastError();
 #else
-    hipLaunchKernelGGL((bchain_kernel<C, W, H, R, NB, NBUF, FAST, DS>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((bchain_kernel<C, W, H, R, NB, NBUF, FAST, DS, F8_BCH_NW>), dim3(grid), dim3(F8_BCH_NW * 64), Cfg::LDS_BYTES, s, a);
     return hipGetLastError();
 #endif
 }
 
 // K steps per register batch, batches in rotation (NB, NBUF) per instance (tuning builds override)
 #ifndef F8_BCH_S0
-#define F8_BCH_S0 2, 3
+#define F8_BCH_S0 2, (F8_BCH_NW == 16 ? 2 : 3)
 #endif
 #ifndef F8_BCH_S1
-#define F8_BCH_S1 2, 3
+#define F8_BCH_S1 2, (F8_BCH_NW == 16 ? 2 : 3)
 #endif
 #ifndef F8_BCH_S2
-#define F8_BCH_S2 2, 3
+#define F8_BCH_S2 2, (F8_BCH_NW == 16 ? 2 : 3)
 #endif
 hipError_t launch_bchain(const BChainArgs& a, int C, int H, int W, hipStream_t s) {
     if (a.nblk < 1 || a.nblk > kBChainMaxBlocks) return hipErrorInvalidValue;
