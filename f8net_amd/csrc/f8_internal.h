@@ -180,6 +180,7 @@ struct FusedArgs {
     void* trace;                           // tuning builds (F8_TRACE) only
     int32_t stride2;                       // stage-opening block with a stride-2 3x3 (f8_opener.hip): H, W are the INPUT map
     int32_t stg;                           // Options::opener_stg
+    int32_t acc_ok, rq_int;                // P12: both convs' accumulators bounded (conv_acc_bounded) / Options::requant_float == 0 (see DwArgs)
     int32_t p12only;                       // f8_opener.hip: body.0 + body.2 only, q[0] = body.2's output (NHWC int8, MID channels); the join runs as the
                                            // first block of the stage's chain launch (ChainArgs::tail)
 };

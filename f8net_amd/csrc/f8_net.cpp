@@ -1465,7 +1465,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     st.bytes_const = (double)na.coutP * (na.ktot + 4) + (double)nd.coutP * (nd.ktot + 4);
                     st.name = std::string(nd.p12_s2 ? "fused_opener_s2_p12_R" + std::to_string(nd.fb_R) + ":" : "fused_p12:") + tname(net, na.out) + "+" + tname(net, nd.out);
                     char kb[96];
-                    if (nd.p12_s2) snprintf(kb, sizeof kb, "f8::fused_opener_kernel<%d, %d, %d, %d, %d, false, true>", na.cd.cin, na.cd.cout, x.W, nd.fb_R, 4 * na.cd.cout);
+                    if (nd.p12_s2) snprintf(kb, sizeof kb, "f8::fused_opener_kernel<%d, %d, %d, %d, %d, false, true, %d>", na.cd.cin, na.cd.cout, x.W, nd.fb_R, 4 * na.cd.cout, opt.requant_float ? 1 : 2);
                     else snprintf(kb, sizeof kb, "f8::fused_p12_kernel<%d, %d>", na.cd.cin, na.cd.cout);
                     st.kernel = kb;
                     break;
@@ -2242,7 +2242,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
                 a.relu_a = na.cd.relu; a.relu_b = nd.cd.relu;
                 fill_out(&a.out32, a.q);
                 a.n2 = a.q[0].n; a.lo2 = a.q[0].lo; a.hi2 = a.q[0].hi; a.xor2 = a.q[0].bias_xor;      // mid2's one form = body.4's input format
-                a.stride2 = 1; a.p12only = 1;
+                a.stride2 = 1; a.p12only = 1; a.acc_ok = conv_acc_bounded(na) && conv_acc_bounded(nd); a.rq_int = !net->opt.requant_float;
                 e = launch_fused_opener(a, s);
                 break;
             }

@@ -53,7 +53,10 @@ struct OpenerCfg {
 // P12 (round 4): only body.0 and body.2 — mid2 (body.2's output in body.4's int8 input format) goes to HBM (a.q[0], NHWC, MID channels) and
 // the launch ends; the join of the block (body.4 + strided shortcut) is then the FIRST BLOCK of the stage's chain launch (f8_chain.hip, TAIL),
 // which keeps its result in registers: the block's 205 MB int32 output (per 128 images) is neither written here nor read back there.
-template <int C, int MID, int W, int R, int COUT, bool STG, bool P12 = false>
+// FQ (P12 instances; round 4): both requantisations are ReLU -> unsigned 8-bit right shifts: the bias is the accumulators' start value, the ReLU the clamp's
+// lower bound, and the shift runs through the float converter (FQ = 1, bounded accumulators, shifts <= 16: 3 operations per value) or as requant_shr +
+// packing (FQ = 2) instead of bias add + max + requant1 + packing (10): P1's epilogue requantises 504 x 128 values per tile.
+template <int C, int MID, int W, int R, int COUT, bool STG, bool P12 = false, int FQ = 0>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 fused_opener_kernel(const FusedArgs a) {
     using Cfg = OpenerCfg<C, MID, W, R, COUT>;
@@ -73,6 +76,7 @@ fused_opener_kernel(const FusedArgs a) {
     static_assert(X1_BYTES % 8192 == 0 && (MID * 4) % 512 == 0 && WL4 >= 1 && WLS >= 1, "every wave issues every DMA instruction (compile-time wait counts)");
     constexpr int L1 = XL1 + WL0, L3 = WL4 + WLS;
 
+    if constexpr (FQ == 1) set_fp_round_nearest_even();
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const patch = lds;
     char* const regA = lds + Cfg::PATCH_BYTES;
@@ -227,11 +231,16 @@ fused_opener_kernel(const FusedArgs a) {
     {
         v16i acc[NP1W][CMW];
 #pragma unroll
-        for (int j = 0; j < NP1W; ++j)
+        for (int i = 0; i < CMW; ++i)
 #pragma unroll
-            for (int i = 0; i < CMW; ++i)
+            for (int g = 0; g < 4; ++g) {
+                v4i bv = {0, 0, 0, 0};
+                if constexpr (FQ != 0) bv = *(const v4i*)(a.b0 + (wb * CMW + i) * 32 + 8 * g + 4 * lh);     // FQ: bias = the accumulators' start value
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][i][r] = 0;
+                for (int j = 0; j < NP1W; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j][i][4 * g + e] = bv[e];
+            }
         issue_p1(0, 0);
         static_for<NK1>([&](auto kc) {
             constexpr int KS = decltype(kc)::value;
@@ -261,6 +270,8 @@ fused_opener_kernel(const FusedArgs a) {
         for (int k = 0; k < NS2 - 1; ++k) issue_w2(k, k);
 
         const int floor0 = a.relu_a ? 0 : INT32_MIN;
+        const float sc1 = FQ == 1 ? requant_u8_scale(a.n1) : 0.0f;
+        (void)floor0; (void)sc1;
 #pragma unroll
         for (int j = 0; j < NP1W; ++j) {
             const int pix = (wa + 4 * j) * 32 + l31;
@@ -273,11 +284,15 @@ fused_opener_kernel(const FusedArgs a) {
                 unsigned d[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const v4i bv = *(const v4i*)(bias_lds + ct * 32 + 8 * g + 4 * lh);
-                    int y[4];
+                    if constexpr (FQ != 0) {
+                        d[g] = requant_u8x4_sel<FQ == 2 ? 2 : 1>(acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3], a.n1, sc1) ^ 0x80808080u;
+                    } else {
+                        const v4i bv = *(const v4i*)(bias_lds + ct * 32 + 8 * g + 4 * lh);
+                        int y[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) y[e] = requant1(max((int)((unsigned)acc[j][i][4 * g + e] + (unsigned)bv[e]), floor0), a.n1, a.lo1, a.hi1);
-                    d[g] = pack4(y[0], y[1], y[2], y[3]) ^ a.xor1;
+                        for (int e = 0; e < 4; ++e) y[e] = requant1(max((int)((unsigned)acc[j][i][4 * g + e] + (unsigned)bv[e]), floor0), a.n1, a.lo1, a.hi1);
+                        d[g] = pack4(y[0], y[1], y[2], y[3]) ^ a.xor1;
+                    }
                 }
                 auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
                 auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
@@ -343,16 +358,22 @@ fused_opener_kernel(const FusedArgs a) {
         }
 
         const int floor0 = a.relu_b ? 0 : INT32_MIN;
+        const float sc2 = FQ == 1 ? requant_u8_scale(a.n2) : 0.0f;
+        (void)floor0; (void)sc2;
 #pragma unroll
         for (int i = 0; i < CMW; ++i) {
             const int ct = wb * CMW + i;
             unsigned d[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                int y[4];
+                if constexpr (FQ != 0) {
+                    d[g] = requant_u8x4_sel<FQ == 2 ? 2 : 1>(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3], a.n2, sc2) ^ 0x80808080u;
+                } else {
+                    int y[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = requant1(max(acc[i][4 * g + e], floor0), a.n2, a.lo2, a.hi2);
-                d[g] = pack4(y[0], y[1], y[2], y[3]) ^ a.xor2;
+                    for (int e = 0; e < 4; ++e) y[e] = requant1(max(acc[i][4 * g + e], floor0), a.n2, a.lo2, a.hi2);
+                    d[g] = pack4(y[0], y[1], y[2], y[3]) ^ a.xor2;
+                }
             }
             auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
             auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
@@ -473,12 +494,12 @@ fused_opener_kernel(const FusedArgs a) {
 #endif
 }
 
-template <int C, int MID, int W, int R, int COUT, bool STG, bool P12 = false>
+template <int C, int MID, int W, int R, int COUT, bool STG, bool P12 = false, int FQ = 0>
 static hipError_t launch_opener_t(const FusedArgs& a, hipStream_t s) {
     using Cfg = OpenerCfg<C, MID, W, R, COUT>;
     static unsigned long long attr_done = 0; int attr_dev = -1;
     if (!dyn_lds_opted_in(&attr_done, &attr_dev)) {
-        hipError_t e = hipFuncSetAttribute((const void*)fused_opener_kernel<C, MID, W, R, COUT, STG, P12>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)fused_opener_kernel<C, MID, W, R, COUT, STG, P12, FQ>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
         if (attr_dev >= 0) attr_done |= 1ull << attr_dev;
     }
@@ -489,7 +510,7 @@ static hipError_t launch_opener_t(const FusedArgs& a, hipStream_t s) {
     FusedArgs b = a;
     const bool tracing = (count++ == want);
     if (tracing) { if (!tbuf) (void)hipMalloc((void**)&tbuf, (size_t)1 << 22); (void)hipMemsetAsync(tbuf, 0, (size_t)grid * 64, s); b.trace = tbuf; }
-    hipLaunchKernelGGL((fused_opener_kernel<C, MID, W, R, COUT, STG, P12>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, b);
+    hipLaunchKernelGGL((fused_opener_kernel<C, MID, W, R, COUT, STG, P12, FQ>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, b);
     if (tracing) {
         (void)hipStreamSynchronize(s);
         unsigned long long* h = new unsigned long long[(size_t)grid * 8];
@@ -502,7 +523,7 @@ static hipError_t launch_opener_t(const FusedArgs& a, hipStream_t s) {
     }
     return hipGetLastError();
 #else
-    hipLaunchKernelGGL((fused_opener_kernel<C, MID, W, R, COUT, STG, P12>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((fused_opener_kernel<C, MID, W, R, COUT, STG, P12, FQ>), dim3(grid), dim3(512), Cfg::LDS_BYTES, s, a);
     return hipGetLastError();
 #endif
 }
@@ -510,7 +531,18 @@ static hipError_t launch_opener_t(const FusedArgs& a, hipStream_t s) {
 hipError_t launch_fused_opener(const FusedArgs& a, hipStream_t s) {
     const int stg = a.stg;
     if (a.C == 256 && a.MID == 128 && a.COUT == 512 && a.W == 56 && a.R == 4) {
-        if (a.p12only) return a.q[0].ptr && !a.q[1].ptr && !a.out32 ? launch_opener_t<256, 128, 56, 4, 512, false, true>(a, s) : hipErrorInvalidValue;
+        if (a.p12only) {
+            if (!(a.q[0].ptr && !a.q[1].ptr && !a.out32)) return hipErrorInvalidValue;
+            // FQ: ReLU -> unsigned 8-bit right shifts after both convs (1: float converter where it is provably exact, 2: integer form)
+            const bool fqf = a.relu_a && a.relu_b && a.n1 > 0 && a.n2 > 0 && a.n1 <= 30 && a.n2 <= 30 && a.lo1 == 0 && a.lo2 == 0 && a.hi1 == 255 && a.hi2 == 255 &&
+                             a.xor1 == 0x80808080u && a.xor2 == 0x80808080u;
+#ifndef F8_OPENER_FQ
+#define F8_OPENER_FQ 1             // 0 (tuning builds): the general epilogues
+#endif
+            const int fq = (!fqf || !F8_OPENER_FQ) ? 0 : ((a.rq_int || !a.acc_ok || a.n1 > kRequantU8MaxShift || a.n2 > kRequantU8MaxShift) ? 2 : 1);
+            return fq == 1 ? launch_opener_t<256, 128, 56, 4, 512, false, true, 1>(a, s) : fq == 2 ? launch_opener_t<256, 128, 56, 4, 512, false, true, 2>(a, s)
+                                                                                               : launch_opener_t<256, 128, 56, 4, 512, false, true, 0>(a, s);
+        }
         return stg ? launch_opener_t<256, 128, 56, 4, 512, true>(a, s) : launch_opener_t<256, 128, 56, 4, 512, false>(a, s);
     }
     return hipErrorInvalidValue;
