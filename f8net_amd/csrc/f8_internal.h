@@ -26,6 +26,8 @@ struct Options {
     int wreg = 1;                // late 1x1 convs on conv1x1_wreg_kernel (weights straight to registers, f8_wreg.hip)
     int fuse_bchain = 2;         // consecutive BasicBlock identity blocks of a stage in ONE launch (f8_bchain.hip); 2: with the stage-opening block in front of them
     int fuse_chain = 1;          // all consecutive bottleneck blocks of a stage in ONE launch, int32 residual stream in registers (f8_chain.hip)
+    int chain_fill = 0;          // 1: a chain launch takes every resident image group (252 of 256 CUs at 14 / 7 tiles per image) instead of the smallest number
+                                 // with the same number of rounds (224): groups that finish a round early free their CUs for the next batch's launches
     int chain_r2 = 0;            // stage chains with a 2-row / two-workgroups-per-CU instance use it (tuning builds with -DF8_CH_R2_S0=1 only: measured slower, f8_chain.hip)
     int fuse_tail = 1;           // ... and the JOIN of a stride-2 stage-opening block as the first block of its stage's chain (its body.0 + body.2 on f8_opener.hip, P12)
     int chain_timeout_ms = 10000; // bound of its halo-exchange spins (another process holding the CUs for longer: sticky error word, logits poisoned, f8_net_check)
