@@ -29,6 +29,7 @@ struct Options {
     int chain_fill = 0;          // 1: a chain launch takes every resident image group (252 of 256 CUs at 14 / 7 tiles per image) instead of the smallest number
                                  // with the same number of rounds (224): groups that finish a round early free their CUs for the next batch's launches
     int chain_r2 = 0;            // stage chains with a 2-row / two-workgroups-per-CU instance use it (tuning builds with -DF8_CH_R2_S0=1 only: measured slower, f8_chain.hip)
+    int fuse_pool = 1;           // the network's last 1x1 conv (+ residual join) and the average pool behind it in one launch (f8_pool.hip)
     int fuse_tail = 1;           // ... and the JOIN of a stride-2 stage-opening block as the first block of its stage's chain (its body.0 + body.2 on f8_opener.hip, P12)
     int chain_timeout_ms = 10000; // bound of its halo-exchange spins (another process holding the CUs for longer: sticky error word, logits poisoned, f8_net_check)
     int fuse_p12 = 1;            // 7x7 identity blocks: body.0 + body.2 in one launch, split over a workgroup pair per image (f8_p12.hip)
@@ -364,6 +365,9 @@ hipError_t launch_stem_pool(const StemPoolArgs& a, hipStream_t s);
 hipError_t launch_dwconv(const DwArgs& a, hipStream_t s);
 hipError_t launch_maxpool(const PoolArgs& a, hipStream_t s);
 hipError_t launch_avgpool(const AvgArgs& a, hipStream_t s);
+// last 1x1 conv (+ residual join) + average pool in one launch (f8_pool.hip); ConvArgs::w = fragment order, out32 / q[] = the POOLED forms [N][coutP]
+bool conv1x1_pool_supported(int ck, int coutP, int pq);
+hipError_t launch_conv1x1_pool(const ConvArgs& a, hipStream_t s);
 hipError_t launch_add(const AddArgs& a, hipStream_t s);
 hipError_t launch_input(const InArgs& a, hipStream_t s);
 hipError_t launch_output(const OutArgs& a, hipStream_t s);

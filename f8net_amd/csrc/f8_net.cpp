@@ -80,6 +80,7 @@ struct Node {
     int absorbed_by = -1;              // conv swallowed by a fused bottleneck launch (node id of its last conv)
     int fb_a = -1, fb_b = -1, fb_R = 0;  // last conv of a fused bottleneck: its first two convs, rows per tile
     int sp_pool = -1, sp_conv = -1;      // stem conv <-> max-pool fused into one launch (f8_stem.hip)
+    int pool = -1, pool_host = -1;       // 1x1 conv (hosting its residual join or not) <-> the average pool behind it, one launch (f8_pool.hip)
     int fbd_a = -1, fbd_b = -1;          // shortcut conv hosting a fused stage-opening block (DS): body.0 / body.2 (body.4 = `dual`)
     bool fbd_s2 = false;                 // ... whose 3x3 and shortcut have stride 2 (f8_opener.hip)
     bool wreg = false;                   // 1x1 conv on conv1x1_wreg_kernel (f8_wreg.hip)
@@ -252,6 +253,7 @@ static const OptKey kOptKeys[] = {
     {"fuse_p12", "F8_FUSE_P12", &Options::fuse_p12, 0, 1, true},
     {"fuse_chain", "F8_FUSE_CHAIN", &Options::fuse_chain, 0, 1, true},
     {"fuse_tail", "F8_FUSE_TAIL", &Options::fuse_tail, 0, 1, true},
+    {"fuse_pool", "F8_FUSE_POOL", &Options::fuse_pool, 0, 1, true},
     {"chain_r2", "F8_CHAIN_R2", &Options::chain_r2, 0, 1, false},
     {"chain_fill", "F8_CHAIN_FILL", &Options::chain_fill, 0, 1, false},
     {"fuse_bchain", "F8_FUSE_BCHAIN", &Options::fuse_bchain, 0, 2, true},
@@ -1132,6 +1134,25 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         c.h2_head = ta.prod; c.h2_dw = tb.prod;
     }
 
+    // ---- 1i. the network's last 1x1 conv (hosting its residual join, or a plain conv + ReLU) and the average pool behind it: ONE launch that sums the map's
+    //          pixels in the epilogue (f8_pool.hip); the conv's int32 result — read by nobody but the pool — never exists
+    for (int i = 0; opt.fuse_pool && i < nn; ++i) {
+        Node& p = ND[i];
+        if (p.kind != N_AVGPOOL || p.a == net->out_t || T[p.a].consumers.size() != 1) continue;
+        const Tensor& t = T[p.a];
+        if (t.prod < 0) continue;
+        int ci = t.prod;
+        if (ND[ci].kind == N_ADD) { if (ND[ci].fused_into < 0) continue; ci = ND[ci].fused_into; }
+        Node& c = ND[ci];
+        if (c.kind != N_CONV || c.absorbed_by >= 0 || c.dual >= 0 || c.dual_host >= 0 || c.fb_a >= 0 || c.fbd_a >= 0 || c.chain_into >= 0 || c.bchain_into >= 0 ||
+            c.ir_a >= 0 || c.p12_a >= 0 || c.bb_a >= 0 || c.h2_head >= 0 || c.cd.groups != 1 || c.cd.kernel != 1 || c.cd.stride != 1 || c.cd.pad != 0 || !c.cd.quant_input) continue;
+        if ((c.fused_add >= 0 ? ND[c.fused_add].out : c.out) != p.a) continue;
+        if (c.fused_add < 0 && T[c.out].consumers.size() != 1) continue;
+        const int ckp = round_up(c.cd.cin, 32), coutP = round_up(c.cd.cout, 32);
+        if (!conv1x1_pool_supported(ckp, coutP, t.H * t.W)) continue;
+        c.pool = i; p.pool_host = ci;
+    }
+
     // ---- 2. which forms does each tensor need?  (reverse order: consumers before producers)
     {
         Tensor& O = T[net->out_t];
@@ -1226,7 +1247,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 break;
             }
             case N_AVGPOOL:
-                add_form(T[nd.a], FORM_I32, 0, 0);
+                if (nd.pool_host < 0) add_form(T[nd.a], FORM_I32, 0, 0);      // fused behind its conv (1i): the pool's input has no form
                 break;
             default: break;
         }
@@ -1258,6 +1279,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         if (nd.kind == N_CONV && nd.chain_into >= 0 && nd.chain_into != i) continue;      // runs inside the chain launch of a later block
         if (nd.kind == N_CONV && nd.bchain_into >= 0 && nd.bchain_into != i) continue;
         if (nd.kind == N_MAXPOOL && nd.sp_conv >= 0) continue;
+        if (nd.kind == N_AVGPOOL && nd.pool_host >= 0) continue;     // runs in its conv's launch
         Step st; st.node = i;
         std::vector<int> extra;
         int out_t = nd.out;
@@ -1583,6 +1605,10 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     st.relu1 = ad.relu;
                     out_t = ad.out;
                 }
+                if (nd.pool >= 0) {                      // ... and the average pool: the step's outputs are the POOLED tensor's forms
+                    out_t = ND[nd.pool].out;
+                    if (T[out_t].forms.empty()) add_form(T[out_t], FORM_I32, 0, 0);
+                }
                 Tensor& o = T[out_t];
                 if (o.dense_out) { st.dense = true; st.out.t = out_t; }
                 else select_outputs(net, out_t, &st.out, &extra);
@@ -1597,8 +1623,9 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     st.ops_per_img += 2.0 * opix * g.cd.cout * g.cd.cin;
                 }
                 if (st.dense) b += (double)d.cout * 4;
-                if (st.out.f32 >= 0) b += opix * o.Cs * 4;
-                for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += opix * o.Cs;
+                const double outpix = nd.pool >= 0 ? 1.0 : opix;
+                if (st.out.f32 >= 0) b += outpix * o.Cs * 4;
+                for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += outpix * o.Cs;
                 st.bytes_per_img = b;
                 st.bytes_const = nd.depthwise ? (double)s.Cs * 13 : (double)nd.coutP * (nd.ktot + 4);
                 if (nd.dual >= 0) st.bytes_const += (double)ND[nd.dual].coutP * (ND[nd.dual].ktot + 4);
@@ -1612,6 +1639,14 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 }
                 // 1x1 convs (plain, with the residual join, or as the dual GEMM of a stage-opening block) whose weight slice per wave
                 // fits the register file: weight-stationary kernel, when a launch gives every workgroup a few pixel tiles to walk
+                if (nd.pool >= 0) {
+                    pack_frag_weights(net, nd);
+                    const size_t colon = st.name.find(':');
+                    st.name = std::string(st.res_t >= 0 ? "conv1x1_res+avgpool" : "conv1x1+avgpool") + (colon == std::string::npos ? ":" + tname(net, nd.out) : st.name.substr(colon));
+                    char kb[96];
+                    snprintf(kb, sizeof kb, "f8::conv1x1_pool_kernel<%d, %s>", nd.ck, st.res_t >= 0 ? "true" : "false");
+                    st.kernel = kb;
+                } else
                 if (opt.wstat && !nd.depthwise && !nd.stem && d.kernel == 1 && d.pad == 0 && d.groups == 1 && !st.dense) {
                     const int k1 = nd.dual >= 0 ? ND[nd.dual].ktot : 0;
                     const bool has_res = nd.dual < 0 && st.res_t >= 0;
@@ -1638,7 +1673,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     }
                 }
                 // the stride-2 3x3 of a late stage-opening block, int8 outputs only: input patch in LDS, weights straight to registers
-                if (opt.s2wreg && !nd.depthwise && !nd.stem && d.kernel == 3 && d.stride == 2 && d.pad == 1 && d.groups == 1 && nd.fused_add < 0 &&
+                if (nd.pool < 0 && opt.s2wreg && !nd.depthwise && !nd.stem && d.kernel == 3 && d.stride == 2 && d.pad == 1 && d.groups == 1 && nd.fused_add < 0 &&
                     nd.dual < 0 && st.out.f32 < 0 && !st.dense && nd.ck == d.cin && s.H == 2 * T[nd.out].H && s.W == 2 * T[nd.out].W &&
                     conv3x3s2_wreg_supported(nd.ck, T[nd.out].H, T[nd.out].W, nd.coutP)) {
                     nd.s2w = true;
@@ -1649,7 +1684,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     st.kernel = kb;
                 }
                 // late, weight-heavy 1x1 convs with int8 outputs only: weights straight to registers (f8_wreg.hip)
-                if (!nd.wstat && opt.wreg && !nd.depthwise && !nd.stem && d.kernel == 1 && d.stride == 1 && d.pad == 0 && d.groups == 1 && nd.fused_add < 0 &&
+                if (nd.pool < 0 && !nd.wstat && opt.wreg && !nd.depthwise && !nd.stem && d.kernel == 1 && d.stride == 1 && d.pad == 0 && d.groups == 1 && nd.fused_add < 0 &&
                     nd.dual < 0 && st.out.f32 < 0 && !st.dense && conv1x1_wreg_supported(nd.ck, nd.coutP)) {
                     nd.wreg = true;
                     pack_frag_weights(net, nd);
@@ -1998,7 +2033,8 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             if (st.dense) {
                 a.w = (const int8_t*)(net->d_w + nd.wf_off);
                 e = launch_fc_dense(a, (char*)output + (size_t)n0 * oT.C * 4, oT.C, net->out_float, net->d_chain ? (const uint32_t*)(net->d_chain + (size_t)part * net->chain_stride + kChainErrWord * 4) : nullptr, s);
-            } else if (nd.s2w) { a.w = (const int8_t*)(net->d_w + nd.wf_off); e = launch_conv3x3s2_wreg(a, s); }
+            } else if (nd.pool >= 0) { a.w = (const int8_t*)(net->d_w + nd.wf_off); e = launch_conv1x1_pool(a, s); }
+            else if (nd.s2w) { a.w = (const int8_t*)(net->d_w + nd.wf_off); e = launch_conv3x3s2_wreg(a, s); }
             else if (nd.wstat) {
                 a.w = (const int8_t*)(net->d_w + nd.wf_off);
                 if (nd.dual >= 0) a.w2 = (const int8_t*)(net->d_w + net->nodes[nd.dual].wf_off);
