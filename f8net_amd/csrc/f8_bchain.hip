@@ -51,16 +51,12 @@ struct BChainCfg {
 template <int FAST, bool ACC = false, class Y>
 __device__ __forceinline__ v4i bquant_tile16(const Y& y, int n, int lo, int hi, unsigned x_or) {
     unsigned d[4];
-    // FAST: lo == 0, hi == 255, 1 <= n <= 16.  ACC: y is a conv accumulator (bounded: BChainArgs::acc_ok) -> 3 operations per value (f8_device.h);
-    // the stream can hold any int32, its `v + 2^(n-1)` may wrap like the reference's: the 4-operation float form (no packing operations)
+    // FAST == 1: every requantised value is bounded by the planner (BChainArgs::acc_ok, ::stream_ok) -> the 3-operation float form; 2: integer form
     const float sc = FAST == 1 ? requant_u8_scale(n) : 0.0f;
-    const unsigned half = FAST ? (1u << (n - 1)) : 0u;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        if constexpr (FAST == 1 && !ACC) d[g] = requant_u8x4_wrap(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], sc, half) ^ x_or;
-        else if constexpr (FAST == 1) d[g] = requant_u8x4(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], sc) ^ x_or;
-        else if constexpr (FAST == 2) d[g] = pack4(requant_shr(y[4 * g], n, half, 0u, 0, 255), requant_shr(y[4 * g + 1], n, half, 0u, 0, 255),
-                                                   requant_shr(y[4 * g + 2], n, half, 0u, 0, 255), requant_shr(y[4 * g + 3], n, half, 0u, 0, 255)) ^ x_or;
+        if constexpr (FAST == 1) d[g] = requant_u8x4(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], sc) ^ x_or;
+        else if constexpr (FAST == 2) d[g] = requant_u8x4_int(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], n) ^ x_or;
         else d[g] = pack4(requant1(y[4 * g], n, lo, hi), requant1(y[4 * g + 1], n, lo, hi), requant1(y[4 * g + 2], n, lo, hi), requant1(y[4 * g + 3], n, lo, hi)) ^ x_or;
     }
     auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
@@ -515,7 +511,7 @@ int bchain_fast(const BChainArgs& a) {
         if (!(a.q[0].n > 0 && a.q[0].n <= 30 && a.q[0].lo == 0)) return 0;
         f16 = f16 && a.q[0].n <= kRequantU8MaxShift;
     }
-    return (a.rq_int || !a.acc_ok || !f16) ? 2 : 1;
+    return (a.rq_int || !a.acc_ok || !a.stream_ok || !f16) ? 2 : 1;
 }
 
 template <int C, int W, int H, int R, int NB, int NBUF, int FAST, bool DS>

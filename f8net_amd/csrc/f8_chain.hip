@@ -62,22 +62,19 @@ struct ChainCfg {
 // 16 accumulator values of one 32x32 tile (this lane: one pixel, channels 8g + 4 lh + e) -> this lane's 16 bytes of the int8 row:
 // channels [16 lh, 16 lh + 16) of the tile (two v_permlane32_swap put a lane's four dwords side by side).
 // FAST: unsigned 8-bit behind a ReLU with a right shift; otherwise either direction, any clamp.  FAST == 1: through the float converter
-// (1 <= n <= 16: 3 / 4 operations per value, f8_device.h; planned unless the handle's option `requant_float` is 0); FAST == 2: the
-// INTEGER form of the same function (requant_shr: v_bfe_u32, v_add3_u32, v_ashrrev_i32, v_med3_i32 + packing — no float instruction;
-// exact for every int32, the reference's wrap included, and any shift).
+// (requant_u8x4, 3 operations per value, f8_device.h) — planned only where every shift is 1 .. 16 and the planner has BOUNDED every value that is
+// requantised: the conv accumulators (ChainArgs::acc_ok) and, since round 4, the int32 stream itself (ChainArgs::stream_ok: the stream of a chain
+// that starts with a stage-opening block is a sum of bounded accumulators — the 4-operation wrap-exact float form round 3 used for it cost the
+// 56x56 launch 6.5 %); FAST == 2: the INTEGER form (requant_u8x4_int: v_bfe_u32, v_add3_u32, v_ashr_pk_u8_i32 — no float instruction; exact for
+// every int32, the reference's wrap included, and any shift): option requant_float = 0, or anything unbounded.
 template <int FAST, bool ACC = false>
 __device__ __forceinline__ v4i quant_tile16(const v16i& y, int n, int lo, int hi, unsigned x_or) {
     unsigned d[4];
-    // FAST: lo == 0, hi == 255, 1 <= n <= 16.  ACC: y is a conv accumulator (bounded: ChainArgs::acc_ok) -> 3 operations per value (f8_device.h);
-    // the stream can hold any int32, its `v + 2^(n-1)` may wrap like the reference's: the 4-operation float form (no packing operations)
     const float sc = FAST == 1 ? requant_u8_scale(n) : 0.0f;
-    const unsigned half = FAST ? (1u << (n - 1)) : 0u;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        if constexpr (FAST == 1 && !ACC) d[g] = requant_u8x4_wrap(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], sc, half) ^ x_or;
-        else if constexpr (FAST == 1) d[g] = requant_u8x4(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], sc) ^ x_or;
-        else if constexpr (FAST == 2) d[g] = pack4(requant_shr(y[4 * g], n, half, 0u, 0, 255), requant_shr(y[4 * g + 1], n, half, 0u, 0, 255),
-                                                   requant_shr(y[4 * g + 2], n, half, 0u, 0, 255), requant_shr(y[4 * g + 3], n, half, 0u, 0, 255)) ^ x_or;
+        if constexpr (FAST == 1) d[g] = requant_u8x4(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], sc) ^ x_or;
+        else if constexpr (FAST == 2) d[g] = requant_u8x4_int(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], n) ^ x_or;
         else d[g] = pack4(requant1(y[4 * g], n, lo, hi), requant1(y[4 * g + 1], n, lo, hi), requant1(y[4 * g + 2], n, lo, hi), requant1(y[4 * g + 3], n, lo, hi)) ^ x_or;
     }
     auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
@@ -920,7 +917,7 @@ int chain_fast(const ChainArgs& a) {
         if (!(a.q[0].n > 0 && a.q[0].n <= 30 && a.q[0].lo == 0)) return 0;
         f16 = f16 && a.q[0].n <= kRequantU8MaxShift;
     }
-    return (a.rq_int || !a.acc_ok || !f16) ? 2 : 1;
+    return (a.rq_int || !a.acc_ok || !a.stream_ok || !f16) ? 2 : 1;
 }
 
 hipError_t launch_chain(const ChainArgs& a, int C, int MID, int H, int W, int cin0, hipStream_t s) {

@@ -66,15 +66,24 @@ __device__ __forceinline__ unsigned requant_u8x4(int a, int b, int c, int d, flo
     r = __builtin_amdgcn_cvt_pk_u8_f32((float)c * scale, 2u, r);
     return __builtin_amdgcn_cvt_pk_u8_f32((float)d * scale, 3u, r);
 }
-// The same for ANY int32 value, the reference's wrap included, in FOUR operations: s = v + 2^(n-1) (v_add_u32: wraps exactly where the
-// reference's int32 add does, and a wrapped s is negative -> 0 like the reference's clamp), v_cvt_f32_i32, v_fma_f32 (s * 2^-n - 0.5 =
-// v / 2^n, exact below 2^24, saturating above), v_cvt_pk_u8_f32.  Same probe (mode 1: against the wrapping integer form, every int32 value,
-// n in 1 .. 16).  For the int32 STREAM of the chain kernels, which may hold anything.
-__device__ __forceinline__ unsigned requant_u8x4_wrap(int a, int b, int c, int d, float scale, unsigned half) {
-    unsigned r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)(int)((unsigned)a + half), scale, -0.5f), 0u, 0u);
-    r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)(int)((unsigned)b + half), scale, -0.5f), 1u, r);
-    r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)(int)((unsigned)c + half), scale, -0.5f), 2u, r);
-    return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)(int)((unsigned)d + half), scale, -0.5f), 3u, r);
+// The same function for ANY int32 value and any shift 1 .. 30, the reference's wrap included, in INTEGER operations only (round 4, gfx950):
+//   t = v + (2^(n-1) - 1) + bit n of v     v_bfe_u32, v_add3_u32 per value (requant_shr's rounding term: wraps exactly where the reference's
+//                                          `input + 2^(n-1)` does, a tie goes to the even neighbour)
+//   {byte 0, byte 1} = sat_u8(t_a >> n), sat_u8(t_b >> n)     ONE v_ashr_pk_u8_i32 per PAIR (arithmetic shift, saturate to [0, 255], pack)
+//   the two halves -> one dword             one v_perm_b32 per four values
+// = 2 3/4 operations per value instead of requant_shr + pack4's 4 3/4.  Compared on the device with the reference's wrapping int32 arithmetic for
+// EVERY int32 value in both operand positions and every shift 1 .. 30 (tools/ubench/cvt_u8_probe.hip mode 1, tests/test_gpu_requant_probe.py).
+// What every FAST / FQ == 2 instance uses: option requant_float = 0, a shift beyond 16, or values the planner cannot bound (conv accumulators:
+// conv_acc_bounded; the int32 stream of a chain launch: tensor_amax, f8_net.cpp) — the float form above is never used on an unbounded value.
+__device__ __forceinline__ unsigned requant_u8x4_int(int a, int b, int c, int d, int n) {
+    const unsigned hm1 = (1u << (n - 1)) - 1u;
+    const int ta = (int)((unsigned)a + hm1 + __builtin_amdgcn_ubfe((unsigned)a, (unsigned)n, 1u)), tb = (int)((unsigned)b + hm1 + __builtin_amdgcn_ubfe((unsigned)b, (unsigned)n, 1u));
+    const int tc = (int)((unsigned)c + hm1 + __builtin_amdgcn_ubfe((unsigned)c, (unsigned)n, 1u)), td = (int)((unsigned)d + hm1 + __builtin_amdgcn_ubfe((unsigned)d, (unsigned)n, 1u));
+    // (as asm: the builtin returns 16 bits and the compiler zero-extends them with a v_and_b32 each before the v_perm_b32 that only takes bytes 0 and 1)
+    unsigned lo, hi;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3" : "=v"(lo) : "v"(ta), "v"(tb), "s"(n));
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3" : "=v"(hi) : "v"(tc), "v"(td), "s"(n));
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);                                    // {lo.b0, lo.b1, hi.b0, hi.b1}
 }
 
 // q = n / d for a divisor known on the host: q = (t + ((n - t) >> sh1)) >> sh2, t = mulhi(n, magic)
@@ -92,15 +101,12 @@ __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d) {
 }
 
 // The same function — ReLU -> unsigned 8-bit, right shift n >= 1 — by compile-time choice of arithmetic.  RQ == 1: the float-converter form
-// above (n <= 16, bounded accumulators); RQ == 2: INTEGER ONLY (requant_shr + v_perm packing: 4 3/4 operations per value, exact for every
+// above (n <= 16, bounded accumulators); RQ == 2: INTEGER ONLY (requant_u8x4_int: 2 3/4 operations per value, exact for every
 // int32 and shift; what the handle's option `requant_float = 0` plans everywhere).
 template <int RQ>
 __device__ __forceinline__ unsigned requant_u8x4_sel(int a, int b, int c, int d, int n, float scale) {
     if constexpr (RQ == 1) return requant_u8x4(a, b, c, d, scale);
-    else {
-        const unsigned half = 1u << (n - 1);
-        return pack4(requant_shr(a, n, half, 0u, 0, 255), requant_shr(b, n, half, 0u, 0, 255), requant_shr(c, n, half, 0u, 0, 255), requant_shr(d, n, half, 0u, 0, 255));
-    }
+    else return requant_u8x4_int(a, b, c, d, n);
 }
 
 // int32 tensors live in an MFMA-fragment-tiled layout ("I32T"), not NHWC: blocks of 32 pixels x 32

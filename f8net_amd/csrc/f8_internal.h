@@ -202,7 +202,8 @@ struct ChainBlk {
 constexpr int kChainMaxBlocks = 6;
 struct ChainArgs {
     ChainBlk blk[kChainMaxBlocks]; int32_t nblk;
-    int32_t acc_ok;                        // body.0 / body.2 accumulators of every block bounded (see DwArgs::acc_ok); the stream is not
+    int32_t acc_ok;                        // body.0 / body.2 accumulators of every block bounded (see DwArgs::acc_ok)
+    int32_t stream_ok;                     // ... and so is the int32 stream after every block (and the stream a chain of identity blocks reads): f8_net.cpp tensor_amax
     int32_t rq_int;                        // Options::requant_float == 0: integer requantisation everywhere (no float-converter instance)
 
     const int32_t* xr;                     // first block an identity block: the stage's int32 stream (I32T) — its int8 form is computed in the launch
@@ -237,6 +238,7 @@ constexpr int kBChainMaxBlocks = 6;
 struct BChainArgs {
     BChainBlk blk[kBChainMaxBlocks]; int32_t nblk;
     int32_t acc_ok;                        // first-conv accumulators of every block bounded (see DwArgs::acc_ok)
+    int32_t stream_ok;                     // ... and the int32 stream after every block / the stream an identity-block chain reads (see ChainArgs)
     int32_t rq_int;                        // Options::requant_float == 0 (see ChainArgs)
 
     const int32_t* xr;                     // the stage's int32 stream (I32T): chains of identity blocks

@@ -59,6 +59,7 @@ struct Form {
 struct Tensor {
     int C = 0, H = 0, W = 0, Cs = 0, fl = 0;
     int prod = -1;
+    mutable int64_t amax = -2;         // tensor_amax(), cached (-2: not computed yet)
     std::vector<int> consumers;        // node ids
     std::vector<Form> forms;
     std::string label;
@@ -70,6 +71,7 @@ struct Node {
     f8_conv_desc cd{};                 // conv / linear (as 1x1 conv)
     std::vector<int8_t> w; std::vector<int32_t> bias;   // raw OIHW int8 + bias
     mutable int acc_ok = -1;           // conv_acc_bounded(), cached
+    mutable int64_t acc_max = -2;      // conv_acc_max(), cached (-2: not computed yet)
     int relu = 0;                      // add
     int pk = 0, pstride = 0, ppad = 0; // maxpool
     int shift = 0;                     // avgpool
@@ -189,22 +191,56 @@ int new_tensor(f8_net* net, int C, int H, int W, int fl, int prod) {
 // range (255 unsigned / raw, 127 signed).  Then `v + 2^(n-1)` of the reference's int32 arithmetic (fix_quant_ops.py:100-104) cannot wrap for
 // n <= 16 and the three-operation float requantisation (requant_u8x4, f8_device.h) is the same function; real nets are 10^2 - 10^3 below
 // the limit, a net that is not keeps the integer form (generic kernel instances).  Cached per node.
-static bool conv_acc_bounded(const Node& nd) {
-    if (nd.acc_ok >= 0) return nd.acc_ok != 0;
-    bool ok = nd.cd.cout > 0 && !nd.w.empty() && nd.w.size() % (size_t)nd.cd.cout == 0;
-    if (ok) {
+constexpr int64_t kAccLimit = (int64_t(1) << 31) - (int64_t(1) << 16) - 1;
+// max over the output channels of  sum |w| * max |x| + |b|  (-1: no weights to look at)
+static int64_t conv_acc_max(const Node& nd) {
+    if (nd.acc_max != -2) return nd.acc_max;
+    int64_t m = -1;
+    if (nd.cd.cout > 0 && !nd.w.empty() && nd.w.size() % (size_t)nd.cd.cout == 0) {
         const size_t per = nd.w.size() / (size_t)nd.cd.cout;
-        const int64_t xmax = (nd.cd.quant_input && nd.cd.input_signed) ? 127 : 255, limit = (int64_t(1) << 31) - (int64_t(1) << 16) - 1;
-        for (int o = 0; o < nd.cd.cout && ok; ++o) {
+        const int64_t xmax = (nd.cd.quant_input && nd.cd.input_signed) ? 127 : 255;
+        m = 0;
+        for (int o = 0; o < nd.cd.cout; ++o) {
             int64_t s = 0;
             for (size_t k = 0; k < per; ++k) { const int v = nd.w[(size_t)o * per + k]; s += v < 0 ? -v : v; }
             const int64_t b = o < (int)nd.bias.size() ? (int64_t)nd.bias[o] : 0;
-            if (s * xmax + (b < 0 ? -b : b) > limit) ok = false;
+            m = std::max(m, s * xmax + (b < 0 ? -b : b));
         }
     }
-    nd.acc_ok = ok ? 1 : 0;
-    return ok;
+    nd.acc_max = m;
+    return m;
 }
+static bool conv_acc_bounded(const Node& nd) {
+    if (nd.acc_ok >= 0) return nd.acc_ok != 0;
+    const int64_t m = conv_acc_max(nd);
+    nd.acc_ok = (m >= 0 && m <= kAccLimit) ? 1 : 0;
+    return nd.acc_ok != 0;
+}
+// A bound on the magnitude of every value an int32 tensor can hold, from the graph alone (round 4): a conv's output by conv_acc_max (a ReLU behind
+// it only shrinks it), a max-pool's by its input's, an align-add's (fix_resnet.py:56-76: the operand with the smaller fraclen is shifted left) by the
+// shifted sum of its operands' — which makes the int32 residual STREAM of a ResNet stage a bounded quantity: real nets sit at 2^20 .. 2^27.  -1 =
+// unknown or beyond 2^40 (the network input, pooled sums).  The chain launches requantise the stream through the float converter only below
+// kAccLimit (ChainArgs::stream_ok); beyond it `v + 2^(n-1)` may wrap as the reference's int32 add does, and the integer instances run.
+static int64_t tensor_amax(const f8_net* net, int t, int depth = 0) {
+    if (t < 0 || t >= (int)net->tensors.size() || depth > 256) return -1;
+    const Tensor& T = net->tensors[t];
+    if (T.amax != -2) return T.amax;
+    int64_t m = -1;
+    if (T.prod >= 0) {
+        const Node& nd = net->nodes[T.prod];
+        if (nd.kind == N_CONV) m = conv_acc_max(nd);
+        else if (nd.kind == N_MAXPOOL) m = tensor_amax(net, nd.a, depth + 1);
+        else if (nd.kind == N_ADD) {
+            const int64_t a = tensor_amax(net, nd.a, depth + 1), b = tensor_amax(net, nd.b, depth + 1);
+            const int sa = T.fl - net->tensors[nd.a].fl, sb = T.fl - net->tensors[nd.b].fl;      // out fraclen = the larger one (f8_net_add)
+            if (a >= 0 && b >= 0 && sa >= 0 && sb >= 0 && sa <= 31 && sb <= 31) m = (a << sa) + (b << sb);
+        }
+    }
+    if (m > (int64_t(1) << 40)) m = -1;
+    T.amax = m;
+    return m;
+}
+static bool stream_bounded(const f8_net* net, int t) { const int64_t m = tensor_amax(net, t); return m >= 0 && m <= kAccLimit; }
 
 // shift / clamp of a consumer's int_op_only_fix_quant; validates what the reference asserts
 int consumer_format(const Tensor& src, const f8_conv_desc& d, int* n, const char* who) {
@@ -2171,7 +2207,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
                     B.wsc = (const int8_t*)(net->d_w + hh.wf_off); B.bsc = (const int32_t*)(net->d_w + hh.b_off);
                     B.nq = B.n1 = B.n2 = 1; B.hiq = B.hi1 = B.hi2 = 255; B.xorq = B.xor1 = B.xor2 = 0x80808080u;     // (unused: no body.0 / body.2 here)
                     B.relu_a = B.relu_b = 1; B.relu1 = net->nodes[hh.fused_add].relu;
-                    a.acc_ok = 1; a.rq_int = !net->opt.requant_float;
+                    a.acc_ok = 1; a.stream_ok = stream_bounded(net, net->nodes[hh.fused_add].out) ? 1 : 0; a.rq_int = !net->opt.requant_float;
                     const int dfl = T[hh.out].fl - T[g4.out].fl;             // (shortcut << acc_shl) + (body.4 << res_shl)
                     B.acc_shl = dfl < 0 ? -dfl : 0; B.res_shl = dfl > 0 ? dfl : 0;
                     continue;
@@ -2187,8 +2223,9 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
                 fmt(nb, T[nb.a], &B.n1, &B.lo1, &B.hi1, &B.xor1);
                 fmt(ng, T[ng.a], &B.n2, &B.lo2, &B.hi2, &B.xor2);
                 B.relu_a = na.cd.relu; B.relu_b = nb.cd.relu; B.relu1 = net->nodes[hh.fused_add].relu;
-                if (k == 0) { a.acc_ok = 1; a.rq_int = !net->opt.requant_float; }
+                if (k == 0) { a.acc_ok = 1; a.rq_int = !net->opt.requant_float; a.stream_ok = (hds || stream_bounded(net, na.a)) ? 1 : 0; }   // identity first block: the stream it reads
                 a.acc_ok = a.acc_ok && conv_acc_bounded(na) && conv_acc_bounded(nb);
+                a.stream_ok = a.stream_ok && stream_bounded(net, net->nodes[hh.fused_add].out);
                 // identity: (body.4 << acc_shl) + (block input << res_shl); opening block: (shortcut << acc_shl) + (body.4 << res_shl)
                 const int dfl = T[hh.out].fl - (hds ? T[ng.out].fl : xin.fl);
                 B.acc_shl = dfl < 0 ? -dfl : 0; B.res_shl = dfl > 0 ? dfl : 0;
@@ -2239,8 +2276,9 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
                 fmt(c1, xin, &B.nq, &B.loq, &B.hiq, &B.xorq);
                 fmt(c2, T[c2.a], &B.n1, &B.lo1, &B.hi1, &B.xor1);
                 B.relu_a = c1.cd.relu; B.relu1 = net->nodes[hk.fused_add].relu;
-                if (k == 0) { a.acc_ok = 1; a.rq_int = !net->opt.requant_float; }
+                if (k == 0) { a.acc_ok = 1; a.rq_int = !net->opt.requant_float; a.stream_ok = (hds || stream_bounded(net, c1.a)) ? 1 : 0; }   // identity first block: the stream it reads
                 a.acc_ok = a.acc_ok && conv_acc_bounded(c1);
+                a.stream_ok = a.stream_ok && stream_bounded(net, net->nodes[hk.fused_add].out);
                 // identity: (second conv << acc_shl) + (block input << res_shl); opening block: (second conv << acc_shl) + (shortcut << res_shl)
                 const int dfl = T[c2.out].fl - (hds ? T[hk.out].fl : xin.fl);
                 B.acc_shl = dfl < 0 ? -dfl : 0; B.res_shl = dfl > 0 ? dfl : 0;

@@ -47,6 +47,7 @@ OPK(k_cvt_pk_i16_i32, "v_cvt_pk_i16_i32 %0, %0, %1")
 OPK(k_lshl_or, "v_lshl_or_b32 %0, %0, %3, %1")
 OPK(k_and_or, "v_and_or_b32 %0, %0, %1, %2")
 OPK(k_permlane_swap, "v_permlane32_swap_b32 %0, %0")
+OPK(k_ashr_pk_u8, "v_ashr_pk_u8_i32 %0, %0, %1, %3")
 
 // 64-bit (register pair) packed fp32
 __global__ void __launch_bounds__(512) k_pk_mul(int iters, int sn, int* out, unsigned long long* cyc) {
@@ -104,7 +105,7 @@ int main() {
 #define R(k) run(#k, k)
     R(k_lshl_add); R(k_max_i32); R(k_add_u32); R(k_xor); R(k_cvt_f32_i32); R(k_cvt_i32_f32); R(k_mul_f32); R(k_fma_f32); R(k_cvt_pk_u8); R(k_bfe); R(k_add3); R(k_ashr); R(k_med3);
     R(k_perm); R(k_mul_lo); R(k_mad_i24); R(k_sat_pk_u8_i16); R(k_pk_add_i16); R(k_pk_max_i16); R(k_pk_ashr_i16); R(k_alignbit); R(k_mov_dpp); R(k_add_dpp); R(k_cvt_pk_i16_i32);
-    R(k_lshl_or); R(k_and_or); R(k_permlane_swap); R(k_pk_mul); R(k_pk_fma);
+    R(k_lshl_or); R(k_and_or); R(k_permlane_swap); R(k_ashr_pk_u8); R(k_pk_mul); R(k_pk_fma);
     printf("(s_memtime counts at a fixed 100 MHz on some parts: compare rows, and the v_fma_f32 row with the guide's 2 cycles)\n");
     return 0;
 }
