@@ -386,8 +386,8 @@ def main():
                                    f'int32 NCHW input resident in HBM' + ('' if headline else ' [not the headline configuration]'),
                        'global_batch': BS * world, 'parallelism': f'dp{world} (batch shards + RCCL all-gather of logits)',
                        'launches_per_step': sum(net.step_launches(i, BS) for i in range(n_l)), 'sub_batches': parts, 'autotuned_launches': retiled,
-                       'requant': 'float-converter (exact, probed): v_cvt_f32_i32, v_mul_f32 by 2^-n, v_cvt_pk_u8_f32 where the planner bounds the accumulators, '
-                                  'integer shift/round/clamp elsewhere; value_int_requant = the same steps with option requant_float = 0' if rq_float else 'int',
+                       'requant': 'float-converter (exact, probed): v_cvt_f32_i32, v_mul_f32 by 2^-n, v_cvt_pk_u8_f32 where the planner bounds the value (conv accumulators, '
+                                  'the chain launches\' int32 stream), integer shift/round/clamp (v_ashr_pk_u8_i32) elsewhere; value_int_requant = the same steps with option requant_float = 0' if rq_float else 'int',
                        'schedule': {0: 'runs back to back (two concurrent sub-batches per run)',
                                     1: 'pipelined: sub-batches of consecutive runs overlap (f8_net_set_pipelined(1))',
                                     2: f'pipelined: {depth} consecutive batches in flight (one arena copy each), each launch covers a whole batch '

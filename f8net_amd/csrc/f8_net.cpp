@@ -1410,7 +1410,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     st.ops_per_img = ops; st.bytes_per_img = b; st.bytes_const = wbytes;
                     st.name = "basic_chain_x" + std::to_string(ch.size()) + (ds ? "_ds:" : ":") + tname(net, f1.out) + ".." + tname(net, nd.out);
                     char kb[160];
-                    snprintf(kb, sizeof kb, "f8::bchain_kernel<%d, %d, %d, %d, 2, 3, %d, %s>", o.C, o.W, o.H, o.C == 64 ? 8 : 7, opt.requant_float ? 1 : 2, ds ? "true" : "false");   // keep in sync with launch_bchain
+                    snprintf(kb, sizeof kb, "f8::bchain_kernel<%d, %d, %d, %d, 2, 3, %d, %s, 8>", o.C, o.W, o.H, o.C == 64 ? 8 : 7, opt.requant_float ? 1 : 2, ds ? "true" : "false");   // keep in sync with launch_bchain
                     st.kernel = kb;
                     break;
                 }

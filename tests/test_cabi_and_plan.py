@@ -251,3 +251,28 @@ def test_intmodel_parameter_fingerprint_sees_rebound_storage():
     with torch.no_grad():
         w[0, 0, 0, 0] += 1                         # in-place edit: version counter
     assert m._param_version() != v1
+
+
+def test_every_planned_kernel_name_is_a_symbol_of_the_library():
+    """`launch_kernel(i)` is the device symbol as rocprofv3 prints it: bench.py joins its live timings with the stamped counter files of profiles/ on that
+    string.  A template parameter added to a kernel without its name string following (round 4: bchain_kernel's wave count) silently detaches the
+    counters from the bench line; checked here, without a GPU, against the library's own symbol table for the four nets' default plans."""
+    import shutil
+    import subprocess
+    nm = shutil.which('nm')
+    if nm is None:
+        pytest.skip('needs binutils nm')
+    syms = subprocess.run([nm, '-C', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    have = set(re.findall(r'(?:void )?(f8::[A-Za-z0-9_]+(?:<[^()]*>)?)\(', syms))
+    assert len(have) > 50, 'no kernel symbols found'
+    for arch, kw in (('resnet50', dict(normalize=True)), ('resnet18', {}), ('mobilenet_v2', {}), ('mobilenet_v1', {})):
+        spec = topology.get(arch, **kw)
+        for opts in ({}, {'requant_float': 0}):
+            net = build_net(spec, synth.reference_params(spec), max_batch=128, hw=224, options=opts)
+            for i in range(net.num_launches):
+                k = net.launch_kernel(i)
+                if not k:
+                    continue
+                # a name without template arguments stands for a family whose instance is picked at run time (input / output kernels)
+                ok = k in have if '<' in k else any(h == k or h.startswith(k + '<') for h in have)
+                assert ok, f'{arch} {opts}: launch {i} ({net.launch_info(i, 128)[0]}) names {k!r}, which the library does not define'
