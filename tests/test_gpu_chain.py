@@ -89,6 +89,15 @@ def test_stage_chain_integer_requant_instances(dev, cfg, mode):
                          big_bias=(mode != 'requant_float=0'))
 
 
+def test_stage_chain_whose_stream_the_planner_cannot_bound(dev):
+    """The int32 stream is requantised through the float converter only while the planner can bound it (f8_net.cpp tensor_amax: the shifted sum of
+    the blocks' accumulator bounds).  A body.4 bias next to 2^31 leaves body.0 / body.2 bounded and the STREAM unbounded: its `v + 2^(n-1)` wraps in
+    the reference (the value turns negative, the clamp makes it 0 where the float form would saturate to 255) — the launch must take the integer
+    instance by itself and equal the oracle."""
+    for tail in ('int32_out', 'int8_out'):
+        _run_stage_chain(dev, CHAINS[5], 'acc_shifts_left', tail, big_bias='stream')
+
+
 def _run_stage_chain(dev, cfg, variant, tail, options=None, big_bias=False):
     C, MID, HW, nblk, cin0, N = cfg
     blocks, fls = _stage(C, MID, nblk, cin0, variant)
@@ -98,7 +107,13 @@ def _run_stage_chain(dev, cfg, variant, tail, options=None, big_bias=False):
     fls['tail.0'], fls['tail.1'] = (3, 6), (5, 7)
     tail2.signed_in = True
     params = _params(convs + [tailc, tail2], fls, 11, variant)
-    if big_bias:      # accumulators within 2^(n-1) of 2^31 in body.0 and body.2 of the second block: the rounding add wraps
+    if big_bias == 'stream':
+        # channel C - 1 of the stream is a CONSTANT through the first two blocks (zero weights, biases only), chosen below so that after the second
+        # block it sits inside the last 2^(n-1) values below 2^31: the next body.0's rounding add wraps for every pixel of that channel
+        for k in ('s.0.body.4', 's.0.shortcut.0', 's.1.body.4'):
+            params[k + '.weight'][C - 1] = 0
+        params['s.0.body.4.bias'][C - 1], params['s.0.shortcut.0.bias'][C - 1] = 12345, 54321
+    elif big_bias:    # accumulators within 2^(n-1) of 2^31 in body.0 and body.2 of the second block: the rounding add wraps
         params['s.1.body.0.bias'][[3, MID - 1]] = [2 ** 31 - 50, 2 ** 31 - 2 ** 12]
         params['s.1.body.2.bias'][[0, 17]] = [2 ** 31 - 2 ** 10, 2 ** 31 - 7]
     x_fl = 9
@@ -108,6 +123,17 @@ def _run_stage_chain(dev, cfg, variant, tail, options=None, big_bias=False):
         x.reshape(-1)[:3] = [2**31 - 1, -2**31, 2**30]       # wrap / clamp corners of the residual join
     else:
         x = np.abs(x)
+
+    if big_bias == 'stream':
+        w0, fl0 = oracle.block_forward(blocks[0], params, x, x_fl)
+        z0 = int(w0[0, C - 1, 0, 0])
+        assert (w0[:, C - 1] == z0).all() and z0 > 0
+        acc_shl = fl0 - sum(fls['s.1.body.4'])                 # the stream keeps its fraclen, body.4's accumulator shifts left ('acc_shifts_left')
+        half = 1 << (fl0 - fls['s.2.body.0'][0] - 1)
+        assert acc_shl >= 0 and half >= 2 ** acc_shl
+        target = 2 ** 31 - 1 - ((2 ** 31 - 1 - z0) % (1 << acc_shl))
+        assert 2 ** 31 - half <= target < 2 ** 31
+        params['s.1.body.4.bias'][C - 1] = (target - z0) >> acc_shl
 
     net = F8Net()
     for k, v in (options or {}).items():
@@ -142,7 +168,10 @@ def _run_stage_chain(dev, cfg, variant, tail, options=None, big_bias=False):
     w, fl = x, x_fl
     for b in blocks:
         w, fl = oracle.block_forward(b, params, w, fl)
-    if big_bias:      # the wrap really happens in the oracle: those mid channels requantise to 0 although their accumulators are huge
+    if big_bias == 'stream':     # the stream channel sits in the wrap window in the oracle (and stays a plain positive int32 there)
+        w1, _ = oracle.block_forward(blocks[1], params, w0, fl0)
+        assert (w1[:, C - 1] == target).all()
+    elif big_bias:    # the wrap really happens in the oracle: those mid channels requantise to 0 although their accumulators are huge
         w0, fl0 = oracle.block_forward(blocks[0], params, x, x_fl)
         m1, _ = oracle._conv_layer(blocks[1].body[0], params, w0, fl0)
         assert ((m1[:, 3] == 0) | (m1[:, 3] > 2 ** 30)).all() and (m1[:, 3] == 0).any() and (m1[:, 3] > 2 ** 30).any()   # some sums passed 2^31, wrapped, and the ReLU made them 0
