@@ -839,14 +839,14 @@ bool chain_tail_supported(int C, int MID, int H, int W, int cin0) {
 int chain_max_blocks(int C, int MID, int H, int W, int cin0, bool tail) { (void)C; (void)MID; (void)H; (void)W; (void)cin0; (void)tail; return kChainMaxBlocks; }
 // Tried in round 4 and NOT kept in the default build: a 2-row instance of the 56x56 opening-block chain — half the tile, 64 stream registers, 128 VGPRs,
 // 78 KB of LDS, TWO workgroups per CU (four waves per SIMD) so that one workgroup's exchange / barrier waits hide behind the other's work.  Bit-exact
-// (tests/test_gpu_chain.py with -DF8_CH_R2_S0=1, option chain_r2 = 1) and SLOWER: 264-271 vs 231-234 us per 128 images, same box — twice the halo rows,
+// (tests/test_gpu_chain.py on a build with -DF8_CH_R2_S0=1) and SLOWER: 264-271 vs 231-234 us per 128 images, same box — twice the halo rows,
 // 12.5 % padding in the 32-pixel tiles, a weight fragment feeds one MFMA instead of two in P1 / P2, 40 bytes per lane of scratch.
 #ifndef F8_CH_R2_S0
-#define F8_CH_R2_S0 0             // 1 (tuning builds): compile that instance; option chain_r2 = 1 then selects it
+#define F8_CH_R2_S0 0             // 1 (tuning builds): compile that instance and use it
 #endif
-void chain_shape(int C, int MID, int H, int W, int cin0, bool tail, int r2, int* R, int* wg_per_cu) {
+void chain_shape(int C, int MID, int H, int W, int cin0, bool tail, int* R, int* wg_per_cu) {
     *R = 4; *wg_per_cu = 1;
-    if (F8_CH_R2_S0 && r2 && !tail && C == 256 && MID == 64 && H == 56 && W == 56 && cin0 == 64) { *R = 2; *wg_per_cu = 2; }
+    if (F8_CH_R2_S0 && !tail && C == 256 && MID == 64 && H == 56 && W == 56 && cin0 == 64) { *R = 2; *wg_per_cu = 2; }
 }
 
 template <int C, int MID, int W, int H, int R, int CIN0, int NB, int NBUF, int FAST, bool ROT, bool TAIL = false>

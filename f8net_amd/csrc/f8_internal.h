@@ -26,9 +26,7 @@ struct Options {
     int wreg = 1;                // late 1x1 convs on conv1x1_wreg_kernel (weights straight to registers, f8_wreg.hip)
     int fuse_bchain = 2;         // consecutive BasicBlock identity blocks of a stage in ONE launch (f8_bchain.hip); 2: with the stage-opening block in front of them
     int fuse_chain = 1;          // all consecutive bottleneck blocks of a stage in ONE launch, int32 residual stream in registers (f8_chain.hip)
-    int chain_fill = 0;          // 1: a chain launch takes every resident image group (252 of 256 CUs at 14 / 7 tiles per image) instead of the smallest number
                                  // with the same number of rounds (224): groups that finish a round early free their CUs for the next batch's launches
-    int chain_r2 = 0;            // stage chains with a 2-row / two-workgroups-per-CU instance use it (tuning builds with -DF8_CH_R2_S0=1 only: measured slower, f8_chain.hip)
     int fuse_pool = 1;           // the network's last 1x1 conv (+ residual join) and the average pool behind it in one launch (f8_pool.hip)
     int fuse_tail = 1;           // ... and the JOIN of a stride-2 stage-opening block as the first block of its stage's chain (its body.0 + body.2 on f8_opener.hip, P12)
     int chain_timeout_ms = 10000; // bound of its halo-exchange spins (another process holding the CUs for longer: sticky error word, logits poisoned, f8_net_check)
@@ -328,8 +326,8 @@ hipError_t launch_fused_opener(const FusedArgs& a, hipStream_t s);
 bool chain_supported(int C, int MID, int H, int W, int cin0);
 bool chain_tail_supported(int C, int MID, int H, int W, int cin0);   // ... a stride-2 opening block's join as the first block (H, W = the stage's resolution)
 int chain_max_blocks(int C, int MID, int H, int W, int cin0, bool tail);
-// rows per tile (4, or 2: the two-workgroups-per-CU instance, option chain_r2) and resident workgroups per CU of the instance that runs the shape
-void chain_shape(int C, int MID, int H, int W, int cin0, bool tail, int r2, int* R, int* wg_per_cu);
+// rows per tile (4, or 2: the two-workgroups-per-CU instance of tuning builds, -DF8_CH_R2_S0=1) and resident workgroups per CU of the instance that runs the shape
+void chain_shape(int C, int MID, int H, int W, int cin0, bool tail, int* R, int* wg_per_cu);
 hipError_t launch_chain(const ChainArgs& a, int C, int MID, int H, int W, int cin0, hipStream_t s);
 // consecutive BasicBlock identity blocks of a stage in one launch (f8_bchain.hip)
 bool bchain_supported(int C, int H, int W);

@@ -290,8 +290,6 @@ static const OptKey kOptKeys[] = {
     {"fuse_chain", "F8_FUSE_CHAIN", &Options::fuse_chain, 0, 1, true},
     {"fuse_tail", "F8_FUSE_TAIL", &Options::fuse_tail, 0, 1, true},
     {"fuse_pool", "F8_FUSE_POOL", &Options::fuse_pool, 0, 1, true},
-    {"chain_r2", "F8_CHAIN_R2", &Options::chain_r2, 0, 1, false},
-    {"chain_fill", "F8_CHAIN_FILL", &Options::chain_fill, 0, 1, false},
     {"fuse_bchain", "F8_FUSE_BCHAIN", &Options::fuse_bchain, 0, 2, true},
     {"chain_timeout_ms", "F8_CHAIN_TIMEOUT_MS", &Options::chain_timeout_ms, 1, 1 << 20, false},
     {"wreg", "F8_WREG", &Options::wreg, 0, 1, true},
@@ -1458,7 +1456,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     char kb[160];
                     const int C = o.C, MID = tail ? a0.cd.cin : a0.cd.cout;
                     int cR = 4, cW = 1;
-                    chain_shape(C, MID, o.H, o.W, tail ? hf.cd.cin : a0.cd.cin, tail, opt.chain_r2, &cR, &cW);
+                    chain_shape(C, MID, o.H, o.W, tail ? hf.cd.cin : a0.cd.cin, tail, &cR, &cW);
                     snprintf(kb, sizeof kb, "f8::chain_kernel<%d, %d, %d, %d, %d, %d, %s, %d, false, %s>", C, MID, o.W, o.H, cR, tail ? hf.cd.cin : a0.cd.cin, MID == 256 ? "2, 4" : (MID == 64 ? "2, 2" : "2, 3"), opt.requant_float ? 1 : 2, tail ? "true" : "false");   // keep in sync with launch_chain (the FAST instance: real fraclen tables)
                     st.kernel = kb;
                     break;
@@ -1958,9 +1956,9 @@ int f8_net_launch_kernel(const f8_net* net, int i, char* buf, size_t cap) {
 // ceil(N / groups) images, so of all group counts that need the same number of rounds the SMALLEST is taken — every group then
 // has the same number of images (128 images on 18 groups of 14 tiles is 8 rounds for 2 groups and 7 for 16; on 16 groups it is 8
 // for all, in the same time, on 224 CUs instead of 252) and the CUs left over run the other batches in flight.
-static int chain_groups(int N, int max_groups, int fill = 0) {
+// (taking every resident group instead — uneven rounds, the groups that finish early free their CUs — measured 1-3 % slower, round 4)
+static int chain_groups(int N, int max_groups) {
     const int g = std::max(1, std::min(N, max_groups));
-    if (fill) return g;                                        // option chain_fill: every resident group, uneven rounds (groups that finish early free their CUs)
     const int rounds = (N + g - 1) / g;
     return (N + rounds - 1) / rounds;
 }
@@ -2239,13 +2237,13 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             const Tensor& oT = T[st.out.t];
             const int C = oT.C, MID = tail ? a0.cd.cin : a0.cd.cout;
             int wg_per_cu = 1;
-            chain_shape(C, MID, oT.H, oT.W, tail ? hf.cd.cin : a0.cd.cin, tail, net->opt.chain_r2, &a.R, &wg_per_cu);
+            chain_shape(C, MID, oT.H, oT.W, tail ? hf.cd.cin : a0.cd.cin, tail, &a.R, &wg_per_cu);
             const int tiles = (oT.H + a.R - 1) / a.R;
             const int slots = (net->num_cu > 0 ? std::min(net->num_cu, 256) : 256) * wg_per_cu;
             // every workgroup of a chain launch must be resident: a device with fewer slots than one image has tiles cannot run it
             if (slots < tiles)
                 return fail(F8_ERR_STATE, "f8_net_run: a stage-chain launch needs %d co-resident workgroups per image, the device has %d compute units (plan with fuse_chain = 0 / fuse_bchain = 0)", tiles, net->num_cu);
-            a.N = N; a.NG = chain_groups(N, slots / tiles, net->opt.chain_fill);
+            a.N = N; a.NG = chain_groups(N, slots / tiles);
             fill_out(&a.out32, a.q);
             if (!net->d_chain) return fail(F8_ERR_STATE, "f8_net_run: chain scratch missing");
             a.sync = (uint32_t*)(net->d_chain + (size_t)part * net->chain_stride);
@@ -2292,7 +2290,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             // every workgroup of a chain launch must be resident (one per CU): a device with fewer CUs than one image has tiles cannot run it
             if ((net->num_cu > 0 ? std::min(net->num_cu, 256) : 256) < tiles)
                 return fail(F8_ERR_STATE, "f8_net_run: a stage-chain launch needs %d co-resident workgroups per image, the device has %d compute units (plan with fuse_chain = 0 / fuse_bchain = 0)", tiles, net->num_cu);
-            a.N = N; a.NG = chain_groups(N, (net->num_cu > 0 ? std::min(net->num_cu, 256) : 256) / tiles, net->opt.chain_fill);
+            a.N = N; a.NG = chain_groups(N, (net->num_cu > 0 ? std::min(net->num_cu, 256) : 256) / tiles);
             fill_out(&a.out32, a.q);
             if (!net->d_chain) return fail(F8_ERR_STATE, "f8_net_run: chain scratch missing");
             a.sync = (uint32_t*)(net->d_chain + (size_t)part * net->chain_stride);
