@@ -11,12 +11,14 @@ cd /tmp && export TMPDIR=/tmp
 export F8_SPLIT_STREAMS=0
 export F8_BENCH_LEAN=1      # the headline loop only: keeps the counter databases small
 CMD="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline $*"
+# the kernel-trace pass runs longer: a 7-pass run ends before the clocks have settled (round 4: its averages sat 7 % above bench.py's live HIP-event figure on the fast boxes)
+TRACE_CMD="python $REPO/bench.py --steps 60 --warmup 10 --no-cpu-baseline $*"
 echo "$*" > $OUT/bench_args.txt
 python - > $OUT/csrc_sha256.txt <<PY
 import sys; sys.path.insert(0, '$REPO')
 import bench; print(bench.csrc_sha256())
 PY
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $TRACE_CMD > $OUT/trace.log 2>&1
 # counters: their own runs, --pmc only (TCC: FETCH_SIZE and WRITE_SIZE do not fit one pass)
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $CMD > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $CMD > $OUT/pmc_write.log 2>&1

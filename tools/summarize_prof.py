@@ -41,12 +41,12 @@ def main():
     arch = bargs[bargs.index('--arch') + 1] if '--arch' in bargs else 'resnet50'
     bs = int(bargs[bargs.index('--bs') + 1]) if '--bs' in bargs else 128
     workload = f'{arch}/bs{bs}'
-    cmd = 'python bench.py --steps 5 --warmup 2 --no-cpu-baseline ' + ' '.join(bargs)
+    cmd = 'python bench.py --steps 60 --warmup 10 --no-cpu-baseline ' + ' '.join(bargs)     # the kernel-trace pass of tools/profile.sh (the counter passes: --steps 5 --warmup 2)
     c = sqlite3.connect(os.path.join(src, 'trace', 'trace_results.db'))
     rows = list(c.execute('select name, total_calls, total_duration, average, percentage from top_kernels'))
     with open(os.path.join(out, f'rocprof_{tag}_kernel_stats.md'), 'w') as f:
         f.write(f'# rocprofv3 --kernel-trace --stats — `{cmd.strip()}` ({tag}, {workload}, kernel sources {stamp[:16]})\n\n')
-        f.write('Durations in microseconds (forward passes of the timed loops + 7 profiled passes; every launch covers the whole batch — '
+        f.write('Durations in microseconds (forward passes of the warm-up and timed loops + 7 profiled passes; every launch covers the whole batch — '
                 'pipelining mode 2, F8_SPLIT_STREAMS=0 so that no two runs overlap).\n\n')
         f.write('| kernel | calls | total us | avg us | % |\n|---|---:|---:|---:|---:|\n')
         for name, calls, tot, avg, pct in rows:
