@@ -1408,7 +1408,14 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     st.ops_per_img = ops; st.bytes_per_img = b; st.bytes_const = wbytes;
                     st.name = "basic_chain_x" + std::to_string(ch.size()) + (ds ? "_ds:" : ":") + tname(net, f1.out) + ".." + tname(net, nd.out);
                     char kb[160];
-                    snprintf(kb, sizeof kb, "f8::bchain_kernel<%d, %d, %d, %d, 2, 3, %d, %s, 8>", o.C, o.W, o.H, o.C == 64 ? 8 : 7, opt.requant_float ? 1 : 2, ds ? "true" : "false");   // keep in sync with launch_bchain
+                    // the instance's arithmetic as launch_bchain picks it (bchain_fast): the float converter only for values the planner bounds
+                    bool bounded = true;
+                    for (size_t k = 0; k < ch.size(); ++k) {
+                        const Node& hk = ND[ch[k]];
+                        const Node& c1 = ND[hk.bds_a >= 0 ? hk.bds_a : hk.bb_a];
+                        bounded = bounded && conv_acc_bounded(c1) && stream_bounded(net, ND[hk.fused_add].out) && (k > 0 || hk.bds_a >= 0 || stream_bounded(net, c1.a));
+                    }
+                    snprintf(kb, sizeof kb, "f8::bchain_kernel<%d, %d, %d, %d, 2, 3, %d, %s, 8>", o.C, o.W, o.H, o.C == 64 ? 8 : 7, (opt.requant_float && bounded) ? 1 : 2, ds ? "true" : "false");   // keep in sync with launch_bchain
                     st.kernel = kb;
                     break;
                 }
@@ -1457,7 +1464,17 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     const int C = o.C, MID = tail ? a0.cd.cin : a0.cd.cout;
                     int cR = 4, cW = 1;
                     chain_shape(C, MID, o.H, o.W, tail ? hf.cd.cin : a0.cd.cin, tail, &cR, &cW);
-                    snprintf(kb, sizeof kb, "f8::chain_kernel<%d, %d, %d, %d, %d, %d, %s, %d, false, %s>", C, MID, o.W, o.H, cR, tail ? hf.cd.cin : a0.cd.cin, MID == 256 ? "2, 4" : (MID == 64 ? "2, 2" : "2, 3"), opt.requant_float ? 1 : 2, tail ? "true" : "false");   // keep in sync with launch_chain (the FAST instance: real fraclen tables)
+                    // the instance's arithmetic as launch_chain picks it (chain_fast): the float converter only for values the planner bounds
+                    bool bounded = true;
+                    for (size_t k = 0; k < ch.size(); ++k) {
+                        const Node& hh = ND[ch[k]];
+                        bounded = bounded && stream_bounded(net, ND[hh.fused_add].out);
+                        if (hh.tail) continue;
+                        const bool hds = hh.fbd_a >= 0;
+                        const Node& na = ND[hds ? hh.fbd_a : hh.fb_a]; const Node& nb = ND[hds ? hh.fbd_b : hh.fb_b];
+                        bounded = bounded && conv_acc_bounded(na) && conv_acc_bounded(nb) && (k > 0 || hds || stream_bounded(net, na.a));
+                    }
+                    snprintf(kb, sizeof kb, "f8::chain_kernel<%d, %d, %d, %d, %d, %d, %s, %d, false, %s>", C, MID, o.W, o.H, cR, tail ? hf.cd.cin : a0.cd.cin, MID == 256 ? "2, 4" : (MID == 64 ? "2, 2" : "2, 3"), (opt.requant_float && bounded) ? 1 : 2, tail ? "true" : "false");   // keep in sync with launch_chain (the FAST instance: real fraclen tables)
                     st.kernel = kb;
                     break;
                 }
