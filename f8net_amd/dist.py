@@ -45,10 +45,12 @@ class ShardedForward:
     """Data-parallel forward: `forward_local` maps this rank's images to fp32 logits (on the GPU:
     `F8Net.run`); the logits of all ranks are all-gathered in rank order."""
 
-    def __init__(self, forward_local, num_classes: int, group=None):
+    def __init__(self, forward_local, num_classes: int, group=None, force_collective=False):
         self.forward_local = forward_local
         self.num_classes = num_classes
         self.group = group
+        # tests on a 1-GPU box: a process group of ONE rank still issues the collective (RCCL's stream, its ordering against the net's streams)
+        self.force_collective = bool(force_collective)
 
     @property
     def world(self):
@@ -57,7 +59,7 @@ class ShardedForward:
     def gather(self, local_logits, n_total=None):
         """All-gather per-rank logits [n_r, classes] -> [sum n_r, classes] on every rank."""
         world = self.world
-        if world == 1:
+        if world == 1 and not self.force_collective:
             return local_logits
         n_local = local_logits.shape[0]
         if n_total is None or n_total == n_local * world:
@@ -83,8 +85,8 @@ class PipelinedShardedForward(ShardedForward):
     buffer pairs alternate, and a pair is only reused after its collective has been waited for.  The tensor returned by
     `__call__` is complete after `finish()` (or after the pair comes round again).  Equal shards only."""
 
-    def __init__(self, forward_local, num_classes: int, n_local: int, device, group=None, lagged=False, depth=2):
-        super().__init__(forward_local, num_classes, group)
+    def __init__(self, forward_local, num_classes: int, n_local: int, device, group=None, lagged=False, depth=2, force_collective=False):
+        super().__init__(forward_local, num_classes, group, force_collective)
         self.n_local = n_local
         self.depth = depth = max(2, int(depth))     # buffer pairs = runs the net keeps in flight (option pipeline_depth)
         # lagged: the net runs with f8_net_set_pipelined(1), whose contract wants a buffer free ONE CALL before the run that
@@ -94,7 +96,7 @@ class PipelinedShardedForward(ShardedForward):
         self.local = [torch.empty((n_local, num_classes), dtype=torch.float32, device=device) for _ in range(depth)]
         world = self.world
         self.full = [torch.empty((n_local * world, num_classes), dtype=torch.float32, device=device) for _ in range(depth)] \
-            if world > 1 else self.local
+            if (world > 1 or self.force_collective) else self.local
         self.work = [None] * depth
         self.i = 0
 
@@ -107,7 +109,7 @@ class PipelinedShardedForward(ShardedForward):
                 self.work[j].wait()        # a pair's previous collective is done before its buffers are rewritten
                 self.work[j] = None
         self.forward_local(x_local, self.local[k])
-        if self.world > 1:
+        if self.world > 1 or self.force_collective:
             self.work[k] = dist.all_gather_into_tensor(self.full[k], self.local[k], group=self.group, async_op=True)
         return self.full[k]
 

@@ -238,7 +238,7 @@ def test_mobilenet_v2_corner_formats(dev, case):
     np.testing.assert_array_equal(got, want)
 
 
-def _nccl_worker(rank, world, port, q):
+def _nccl_worker(rank, world, port, q, force=False):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                       HSA_ENABLE_IPC_MODE_LEGACY='0')
@@ -247,6 +247,9 @@ def _nccl_worker(rank, world, port, q):
     from f8net_amd import synth as sy, topology as tp
     from f8net_amd.net import build_net
     r, w, lr = f8dist.init_from_env(backend='nccl')
+    if force and w == 1:                                 # a group of ONE rank: init_from_env needs none, the forced collective does
+        th.cuda.set_device(lr)
+        th.distributed.init_process_group(backend='nccl', rank=0, world_size=1)
     assert th.distributed.get_backend() == 'nccl'        # RCCL, not a silent gloo fallback
     dev = th.device('cuda', lr)
     th.cuda.set_device(dev)
@@ -255,7 +258,7 @@ def _nccl_worker(rank, world, port, q):
     n_local = 8
     net = build_net(spec, params, max_batch=n_local, hw=224)
     net.set_pipelined(2)
-    pf = f8dist.PipelinedShardedForward(lambda t, out: net.run(t, out=out), spec.num_classes, n_local, dev, lagged=True)
+    pf = f8dist.PipelinedShardedForward(lambda t, out: net.run(t, out=out), spec.num_classes, n_local, dev, lagged=True, force_collective=force)
     xs = [sy.make_input(spec, params, n_local * w, 224, seed=300 + i)[0] for i in range(3)]
     outs = []
     for rep in range(6):
@@ -296,6 +299,27 @@ def test_two_ranks_over_rccl_match_oracle(dev):
         want = oracle.net_forward(spec, params, x, fl)
         for rank in (0, 1):
             np.testing.assert_array_equal(got[rank][rep], want)
+
+
+def test_one_rank_over_rccl_issues_the_collective(dev):
+    """What a 1-GPU box can say about §8e: a process group of ONE rank over nccl (= RCCL) with the collective forced — the asynchronous
+    all-gather on RCCL's stream, ordered against the net's own streams under the pipelined schedule bench.py uses, waited for before a buffer
+    pair is reused; the gathered logits equal the oracle's.  (Rendezvous of several ranks: tests/test_dist_gloo.py and, with >= 2 GPUs, the
+    test above.)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29400 + os.getpid() % 200
+    p = ctx.Process(target=_nccl_worker, args=(0, 1, port, q, True))
+    p.start()
+    rank, got = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    spec = topology.get('resnet50', normalize=True)
+    params = synth.reference_params(spec, seed=1234)
+    for rep in (4, 5):
+        x, fl = synth.make_input(spec, params, 8, 224, seed=300 + rep % 3)
+        np.testing.assert_array_equal(got[rep], oracle.net_forward(spec, params, x, fl))
 
 
 def test_output_conv_with_relu_is_rectified(dev):
