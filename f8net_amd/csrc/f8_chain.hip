@@ -122,6 +122,16 @@ chain_kernel(const ChainArgs a) {
 #define F8_CH_EARLY 1
 #endif
     constexpr bool EARLY = F8_CH_EARLY != 0 && T > 1 && !ROT;
+    // SPLIT (round 4, late): a wave's pixel tiles are CONSECUTIVE (pg * NPW + j instead of pg + PG * j), so a wave touches the tile's first row or its
+    // last row, never both, and walks the taps of body.2 in the order that needs ITS halo row last: centre, bottom, top for the waves of the first
+    // rows (and the waves in the middle, which need none), centre, top, bottom for the waves of the last row — the neighbours' rows are then waited for
+    // after two thirds of the 3x3 instead of one (the wait is the neighbours' skew: §4.1 of DESIGN.md).  Instances whose tiles are whole (no ragged
+    // last tile) and whose first pixel-tile group holds the whole first row and none of the last (the 56x56 and 28x28 instances).
+#ifndef F8_CH_SPLIT
+#define F8_CH_SPLIT 1
+#endif
+    constexpr int PG_ = 8 / (MID / 32), NPW_ = ((R * W + 31) / 32 + PG_ - 1) / PG_;
+    constexpr bool SPLIT = F8_CH_SPLIT != 0 && EARLY && PG_ >= 2 && T * R == H && W <= NPW_ * 32 && (R - 1) * W >= NPW_ * 32;
     static_assert(NB <= CM && CM % NB == 0 && NK1 % NB == 0, "a batch of K steps stays inside one 3x3 tap / one weight tile");
     static_assert(!DS0 || KS % NB == 0, "stage-opening block: whole batches");
     static_assert(!ROT || (NK1 % 8 == 0 && CM == 8), "rotation: groups of 8 K steps (256 bytes of a row), whole taps");
@@ -152,7 +162,8 @@ chain_kernel(const ChainArgs a) {
     F8_LANES;                                                                                                                           \
     unsigned p12x[NPW], p12m[NPW], p12i[NPW]; int p12_pix[NPW];                                                                          \
     _Pragma("unroll") for (int j = 0; j < NPW; ++j) {                                                                                    \
-        const int pt = (pg + PG * j) < NPT ? (pg + PG * j) : NPT - 1;                                                                    \
+        const int pt0_ = SPLIT ? pg * NPW + j : pg + PG * j;                                                                             \
+        const int pt = pt0_ < NPT ? pt0_ : NPT - 1;                                                                                      \
         p12_pix[j] = pt * 32 + l31;                                                                                                     \
         p12x[j] = (unsigned)(pt * 32 * XS) + xlane; p12m[j] = (unsigned)(pt * 32 * MS) + mlane; p12i[j] = (unsigned)(pt * 32 * IS) + ilane; \
     }                                                                                                                                   \
@@ -211,8 +222,8 @@ chain_kernel(const ChainArgs a) {
 
     // ---- weight streams (fragment order: [tile][K32 step][lane][16 B]).  step -> K index: identity, or rotated in coarse groups.
     auto k1_of = [&](int g, int nk) { return ROT ? (((g >> 3) + opaque(rot)) & (nk / 8 - 1)) * 8 + (g & 7) : g; };       // body.0: groups of 8 steps
-    auto tap_of = [&](int t) {                                  // body.2: whole taps
-        if constexpr (EARLY) return t < 3 ? t + 3 : (t < 6 ? t - 3 : t);         // centre row first (taps 3, 4, 5), then the rows that read a halo row
+    auto tap_of = [&](int t, int ord = 0) {                     // body.2: whole taps.  ord (SPLIT): 1 = centre, bottom, top; 0 = centre, top, bottom
+        if constexpr (EARLY) return t < 3 ? t + 3 : (ord ? (t < 6 ? t + 3 : t - 6) : (t < 6 ? t - 3 : t));   // centre row first (taps 3, 4, 5), then the rows that read a halo row
         else if constexpr (!ROT) return t;
         else { int q = t + (int)((unsigned)opaque(rot) % 9u); return q >= 9 ? q - 9 : q; }
     };
@@ -237,8 +248,9 @@ chain_kernel(const ChainArgs a) {
         static_for<(NBUF - 1 < NBAT ? NBUF - 1 : NBAT)>([&](auto bc) { constexpr int Bi = decltype(bc)::value; w1_load(w0, nkc, wbuf[Bi], Bi, wl); });
     };
     constexpr int NBAT2 = NK2 / NB, BPTAP = CM / NB;            // body.2: batches, batches per tap
-    auto w2_load = [&](const int8_t* w2, v4i (&dst)[NB], int bi, unsigned wl) {
-        const int k0 = tap_of(bi / BPTAP) * CM + (bi % BPTAP) * NB;
+    static_assert(!SPLIT || (NBUF - 1) * NB <= 3 * CM, "the batches requested ahead of body.2 lie in the centre taps, which both tap orders start with");
+    auto w2_load = [&](const int8_t* w2, v4i (&dst)[NB], int bi, unsigned wl, int ord = 0) {
+        const int k0 = tap_of(bi / BPTAP, ord) * CM + (bi % BPTAP) * NB;
 #pragma unroll
         for (int s = 0; s < NB; ++s) dst[s] = ldw(w2, (k0 + s) * 1024, (unsigned)(mt * NK2 * 1024) + wl);
     };
@@ -577,26 +589,43 @@ chain_kernel(const ChainArgs a) {
                         const int orow = oc / W, ocol = oc - orow * W;
                         bpb[j] = (unsigned)((orow * PW + ocol) * MS + lh * 16);
                     }
+                    v4i xfa[NPW], xfb[NPW];
+                    constexpr int GH = SPLIT ? 6 * CM : (EARLY ? 3 * CM : NK2 + 1);     // first K step of a tap that may read a halo row
+                    // SPLIT: the waves whose tiles hold pixels of the LAST row take the bottom taps last (ord 0), every other wave the top taps (ord 1; no
+                    // ragged tile: rows == R).  ONE copy of the K loop: the order only moves the patch ROW of the second and third tap group, i.e. two
+                    // more per-lane base registers per pixel tile (two copies of the loop cost 29 registers here and spilled the 28x28 instances)
+                    const int ord = (SPLIT && !((pg + 1) * NPW * 32 > (R - 1) * W)) ? 1 : 0;
+                    unsigned bpb2[NPW], bpb3[NPW];
+#pragma unroll
+                    for (int j = 0; j < NPW; ++j) { bpb2[j] = bpb[j] + (unsigned)(ord ? 2 * PW * MS : 0); bpb3[j] = bpb[j] + (unsigned)(ord ? 0 : 2 * PW * MS); }
                     auto rd = [&](v4i (&xf)[NPW], auto gc) {
                         constexpr int G = decltype(gc)::value, TAP0 = G / CM, CI = G % CM;
-                        constexpr int TAP = EARLY ? (TAP0 < 3 ? TAP0 + 3 : (TAP0 < 6 ? TAP0 - 3 : TAP0)) : TAP0;
-                        if constexpr (ROT) {
-                            const int tp = tap_of(TAP);
-                            const int tr = tp / 3, ts = tp - tr * 3;
-                            const unsigned eo = (unsigned)((tr * PW + ts) * MS + CI * 32);
+                        if constexpr (SPLIT) {
+                            constexpr int GRP = TAP0 / 3, DX = TAP0 % 3;             // tap group: centre row, then the two halo-side rows in this wave's order
 #pragma unroll
-                            for (int j = 0; j < NPW; ++j) xf[j] = *(const v4i*)(patch + bpb[j] + eo);
+                            for (int j = 0; j < NPW; ++j) {
+                                if constexpr (GRP == 0) xf[j] = *(const v4i*)(patch + bpb[j] + (PW + DX) * MS + CI * 32);
+                                else if constexpr (GRP == 1) xf[j] = *(const v4i*)(patch + bpb2[j] + DX * MS + CI * 32);
+                                else xf[j] = *(const v4i*)(patch + bpb3[j] + DX * MS + CI * 32);
+                            }
                         } else {
+                            constexpr int TAP = EARLY ? (TAP0 < 3 ? TAP0 + 3 : (TAP0 < 6 ? TAP0 - 3 : TAP0)) : TAP0;
+                            if constexpr (ROT) {
+                                const int tp = tap_of(TAP);
+                                const int tr = tp / 3, ts = tp - tr * 3;
+                                const unsigned eo = (unsigned)((tr * PW + ts) * MS + CI * 32);
 #pragma unroll
-                            for (int j = 0; j < NPW; ++j) xf[j] = *(const v4i*)(patch + bpb[j] + ((TAP / 3) * PW + TAP % 3) * MS + CI * 32);
+                                for (int j = 0; j < NPW; ++j) xf[j] = *(const v4i*)(patch + bpb[j] + eo);
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < NPW; ++j) xf[j] = *(const v4i*)(patch + bpb[j] + ((TAP / 3) * PW + TAP % 3) * MS + CI * 32);
+                            }
                         }
                     };
-                    v4i xfa[NPW], xfb[NPW];
                     rd(xfa, std::integral_constant<int, 0>{});
-                    constexpr int GH = EARLY ? 3 * CM : NK2 + 1;        // first K step of a tap that reads a halo row
                     static_for<NK2>([&](auto gc) {
                         constexpr int G = decltype(gc)::value, Bi = G / NB, S = G % NB;
-                        if constexpr (S == 0 && Bi + NBUF - 1 < NBAT2) w2_load(pw2, wbuf[(Bi + NBUF - 1) % NBUF], Bi + NBUF - 1, wl16);
+                        if constexpr (S == 0 && Bi + NBUF - 1 < NBAT2) w2_load(pw2, wbuf[(Bi + NBUF - 1) % NBUF], Bi + NBUF - 1, wl16, ord);
                         v4i (&cur)[NPW] = (G & 1) ? xfb : xfa;
                         v4i (&nxt)[NPW] = (G & 1) ? xfa : xfb;
                         if constexpr (G == GH) { F8_CT(3); consume(); F8_CT(2); rd(cur, gc); }
