@@ -1,5 +1,5 @@
 """Soak test of the pipelined schedules: thousands of overlapping runs on varying inputs, every result compared on the GPU
-with the strictly ordered result of the same input.  `python tools/soak.py [runs]`"""
+with the strictly ordered result of the same input.  `python tools/soak.py [runs]` (F8_SOAK_ARCH, F8_SOAK_BS: another net / batch)"""
 import os
 import sys
 
@@ -10,9 +10,10 @@ from f8net_amd import synth, topology
 from f8net_amd.net import build_net
 
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
-spec = topology.get('resnet50', normalize=True)
-params = synth.make_params(spec, seed=1234, fraclens=topology.R50_NVIDIA_FRACLENS)
-n = 128
+arch = os.environ.get('F8_SOAK_ARCH', 'resnet50')              # resnet50 (default) | resnet18 | mobilenet_v2 | mobilenet_v1
+spec = topology.get(arch, normalize=(arch == 'resnet50'))
+params = synth.reference_params(spec, seed=1234)
+n = int(os.environ.get('F8_SOAK_BS', '128'))
 whole = os.environ.get('F8_SOAK_WHOLE', '1') == '1'      # plan as bench.py does: a launch covers the whole batch under mode 2
 depth = int(os.environ.get('F8_SOAK_DEPTH', '3'))             # batches in flight under mode 2 (bench.py: 3)
 net = build_net(spec, params, max_batch=n, hw=224, options={'whole_batch_launches': 1, 'arena_copies': depth, 'pipeline_depth': depth} if whole else None)
