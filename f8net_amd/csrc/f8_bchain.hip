@@ -192,9 +192,9 @@ bchain_kernel(const BChainArgs a) {
                 while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
                     __builtin_amdgcn_s_sleep(1);
                     if (wall_clock64() - t0 > t_limit) { ok = false; break; }
-                    if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                    if ((__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 8) == a.epoch) break;   // another tile of THIS run gave up
                 }
-                if (!ok) __hip_atomic_store(a.err, 0x200u + (unsigned)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!ok) __hip_atomic_store(a.err, (a.epoch << 8) | 0x80u | ((unsigned)seq & 0x3fu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
             const int side = t2 / (NT / 2), idx = t2 % (NT / 2);

@@ -552,9 +552,9 @@ chain_kernel(const ChainArgs a) {
                         while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
                             __builtin_amdgcn_s_sleep(2);
                             if (wall_clock64() - t0 > t_limit) { ok = false; break; }
-                            if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                            if ((__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 8) == a.epoch) break;   // another tile of THIS run gave up
                         }
-                        if (!ok) __hip_atomic_store(a.err, 0x100u + (unsigned)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (!ok) __hip_atomic_store(a.err, (a.epoch << 8) | 0x40u | ((unsigned)seq & 0x3fu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     F8_CT(12);
                     __syncthreads();

@@ -12,7 +12,7 @@
 namespace f8 {
 
 template <int K>
-__global__ void __launch_bounds__(512) fc_dense_kernel(const ConvArgs a, void* const out, const int classes, const int as_float, const uint32_t* const err) {
+__global__ void __launch_bounds__(512) fc_dense_kernel(const ConvArgs a, void* const out, const int classes, const int as_float, const uint32_t* const err, const uint32_t epoch) {
     constexpr int NK = K / 32, NKW = NK / 8;             // K32 steps, steps per wave
     static_assert(NK % 8 == 0, "eight K slices");
     __shared__ int part[8][16][64];                      // [wave][accumulator register][lane]
@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(512) fc_dense_kernel(const ConvArgs a, void* c
             const int v = (int)(sum + (unsigned)a.bias[c]);
             // a stage-chain launch of this run gave up a halo wait (sticky error word): the logits are POISONED (NaN / INT32_MIN), so that a
             // caller that never calls f8_net_check cannot take them for results
-            const bool bad = err != nullptr && *err != 0u;
+            const bool bad = err != nullptr && (*err >> 8) == epoch;
             if (as_float) ((float*)out)[(size_t)m * classes + c] = bad ? __builtin_nanf("") : (float)v;
             else ((int*)out)[(size_t)m * classes + c] = bad ? INT32_MIN : v;
         }
@@ -62,16 +62,16 @@ __global__ void __launch_bounds__(512) fc_dense_kernel(const ConvArgs a, void* c
 bool fc_dense_supported(int ck, int coutP) { return (ck == 512 || ck == 1024 || ck == 1280 || ck == 2048) && coutP % 32 == 0; }
 
 template <int K>
-static hipError_t launch_fc_t(const ConvArgs& a, void* out, int classes, int as_float, const uint32_t* err, hipStream_t s) {
-    hipLaunchKernelGGL((fc_dense_kernel<K>), dim3((a.M + 31) / 32, a.coutP / 32), dim3(512), 0, s, a, out, classes, as_float, err);
+static hipError_t launch_fc_t(const ConvArgs& a, void* out, int classes, int as_float, const uint32_t* err, uint32_t epoch, hipStream_t s) {
+    hipLaunchKernelGGL((fc_dense_kernel<K>), dim3((a.M + 31) / 32, a.coutP / 32), dim3(512), 0, s, a, out, classes, as_float, err, epoch);
     return hipGetLastError();
 }
 
-hipError_t launch_fc_dense(const ConvArgs& a, void* out, int classes, int as_float, const uint32_t* err, hipStream_t s) {
-    if (a.CK == 512) return launch_fc_t<512>(a, out, classes, as_float, err, s);
-    if (a.CK == 1024) return launch_fc_t<1024>(a, out, classes, as_float, err, s);
-    if (a.CK == 1280) return launch_fc_t<1280>(a, out, classes, as_float, err, s);
-    if (a.CK == 2048) return launch_fc_t<2048>(a, out, classes, as_float, err, s);
+hipError_t launch_fc_dense(const ConvArgs& a, void* out, int classes, int as_float, const uint32_t* err, uint32_t epoch, hipStream_t s) {
+    if (a.CK == 512) return launch_fc_t<512>(a, out, classes, as_float, err, epoch, s);
+    if (a.CK == 1024) return launch_fc_t<1024>(a, out, classes, as_float, err, epoch, s);
+    if (a.CK == 1280) return launch_fc_t<1280>(a, out, classes, as_float, err, epoch, s);
+    if (a.CK == 2048) return launch_fc_t<2048>(a, out, classes, as_float, err, epoch, s);
     return hipErrorInvalidValue;
 }
 

@@ -161,7 +161,7 @@ struct InArgs {                            // network input: int32 NCHW -> NHWC 
 struct OutArgs {                           // NHWC int32 -> NCHW int32 / float32
     const int32_t* x; int32_t N, C, HW, Cs;
     void* out; int32_t as_float;
-    const uint32_t* err;                   // the run's stage-chain error word or nullptr: when set, the outputs are poisoned (NaN / INT32_MIN)
+    const uint32_t* err; uint32_t epoch;   // the run's stage-chain error word (or nullptr) and tag: when the word carries THIS run's tag, the outputs are poisoned (NaN / INT32_MIN)
 };
 
 // One launch for a ResNet bottleneck identity block (f8_fused.hip).
@@ -213,7 +213,9 @@ struct ChainArgs {
     int32_t N, NG;                         // images; image groups resident at once (grid = NG * tiles per image)
     int32_t* out32; QuantOut q[2];         // forms of the last block's output
     uint32_t* sync;                        // [0] ticket, [16 + workgroup] halo flag; zeroed before every launch
-    uint32_t* err;                         // sticky error word (a halo spin timed out): read by f8_net_check
+    uint32_t* err;                         // error word (a halo spin timed out): (epoch << 8) | code; read by f8_net_check
+    uint32_t epoch;                        // this run's tag (1 .. 2^24 - 1): only an error of THIS run ends waits early / poisons the logits —
+                                           // a word left by an earlier run stays for f8_net_check to report and changes nothing else
     int8_t* xchg;                          // halo rows between vertically adjacent tiles: [workgroup][parity][side][W * MID]
     uint32_t timeout_ticks;                // bound of every spin (100 MHz wall clock)
     void* trace;
@@ -246,7 +248,7 @@ struct BChainArgs {
     const int8_t* wsc; const int32_t* bsc; // shortcut conv, fragment order / offset-corrected bias
     int32_t N, NG;
     int32_t* out32; QuantOut q[2];
-    uint32_t* sync; uint32_t* err; int8_t* xchg; uint32_t timeout_ticks;   // as ChainArgs
+    uint32_t* sync; uint32_t* err; uint32_t epoch; int8_t* xchg; uint32_t timeout_ticks;   // as ChainArgs
     void* trace;
 };
 
@@ -342,7 +344,7 @@ bool conv1x1_wreg_supported(int ck, int coutP);
 hipError_t launch_conv1x1_wreg(const ConvArgs& a, hipStream_t s);
 // classifier: integer linear + int32 -> float32 / int32 [N][classes] into the caller's buffer (f8_fc.hip); ConvArgs::w = fragment order
 bool fc_dense_supported(int ck, int coutP);
-hipError_t launch_fc_dense(const ConvArgs& a, void* out, int classes, int as_float, const uint32_t* err, hipStream_t s);   // err: the run's chain error word (logits poisoned when set) or nullptr
+hipError_t launch_fc_dense(const ConvArgs& a, void* out, int classes, int as_float, const uint32_t* err, uint32_t epoch, hipStream_t s);   // err / epoch: the run's chain error word and tag (logits poisoned when the word carries the tag) or nullptr
 // 3x3 / stride 2 / pad 1 with the input patch in LDS and the weights streamed into registers (f8_s2conv.hip); ConvArgs::w = fragment order
 bool conv3x3s2_wreg_supported(int ck, int HO, int WO, int coutP);
 hipError_t launch_conv3x3s2_wreg(const ConvArgs& a, hipStream_t s);

@@ -863,7 +863,7 @@ __global__ void __launch_bounds__(256) output_kernel(const OutArgs a) {
         const int c = (int)(t % a.C);
         const int n = (int)(t / a.C);
         const int v = a.x[i32t_index(n * a.HW + i, c, a.Cs)];
-        const bool bad = a.err != nullptr && *a.err != 0u;     // f8_fc.hip: a chain launch of this run gave up a halo wait
+        const bool bad = a.err != nullptr && (*a.err >> 8) == a.epoch;     // f8_fc.hip: a chain launch of this run gave up a halo wait
         if (a.as_float) ((float*)a.out)[idx] = bad ? __builtin_nanf("") : (float)v;
         else ((int*)a.out)[idx] = bad ? INT32_MIN : v;
     }

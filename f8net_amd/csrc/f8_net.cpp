@@ -144,6 +144,7 @@ struct f8_net {
     // device
     char* d_arena = nullptr; char* d_w = nullptr; bool uploaded = false;
     uint32_t* d_err = nullptr;         // sticky device error words: [0] an int32 input value outside the head's 8-bit format
+    uint32_t epoch = 0;                // tag of the run being issued (1 .. 2^24 - 1, f8_net_run): chain error words carry it (ChainArgs::epoch)
     char* d_chain = nullptr; size_t chain_stride = 0;   // per arena copy: sync words + halo exchange rows of the stage-chain launches
     hipEvent_t* events = nullptr; int n_events = 0;
     bool aux_shared = false;           // aux[] belong to the per-device pool (run_common), not to this handle
@@ -233,7 +234,8 @@ static int64_t tensor_amax(const f8_net* net, int t, int depth = 0) {
         else if (nd.kind == N_ADD) {
             const int64_t a = tensor_amax(net, nd.a, depth + 1), b = tensor_amax(net, nd.b, depth + 1);
             const int sa = T.fl - net->tensors[nd.a].fl, sb = T.fl - net->tensors[nd.b].fl;      // out fraclen = the larger one (f8_net_add)
-            if (a >= 0 && b >= 0 && sa >= 0 && sb >= 0 && sa <= 31 && sb <= 31) m = (a << sa) + (b << sb);
+            constexpr int64_t cap = int64_t(1) << 40;       // the shifted operands stay below 2^41: no int64 overflow (an operand of 2^40 shifted by 31 would wrap)
+            if (a >= 0 && b >= 0 && sa >= 0 && sb >= 0 && sa <= 31 && sb <= 31 && a <= (cap >> sa) && b <= (cap >> sb)) m = (a << sa) + (b << sb);
         }
     }
     if (m > (int64_t(1) << 40)) m = -1;
@@ -447,8 +449,10 @@ int f8_net_check(f8_net* net) {
         uint32_t w = 0;
         if ((e = hipMemcpy(&w, net->d_chain + (size_t)p * net->chain_stride + kChainErrWord * 4, 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e, "f8_net_check: hipMemcpy");
         if (w) {
-            (void)hipMemset(net->d_chain + (size_t)p * net->chain_stride + kChainErrWord * 4, 0, 4);
-            return fail(F8_ERR_HIP, "f8_net_check: a stage-chain launch gave up waiting for a neighbouring tile (code 0x%x, arena copy %d): its outputs are invalid", w, p);
+            // ticket, workgroups-out counter, halo flags and the error word of this arena copy: re-armed from the host (the device is idle —
+            // the synchronize above — and a launch that did not run to completion would have left them dirty)
+            (void)hipMemset(net->d_chain + (size_t)p * net->chain_stride, 0, 4096);
+            return fail(F8_ERR_HIP, "f8_net_check: a stage-chain launch gave up waiting for a neighbouring tile (code 0x%x of run tag %u, arena copy %d): the outputs of that run are invalid", w & 0xffu, w >> 8, p);
         }
     }
     return F8_OK;
@@ -937,15 +941,20 @@ int f8_net_finalize(f8_net* net, int max_batch) {
             if (h.fbd_a >= 0 && h.fbd_s2 && opt.fuse_tail) {
                 // stage-opening block with a stride-2 3x3 (1d fused it on f8_opener.hip): candidate for body.0 + body.2 there and the JOIN as the
                 // first block of the stage's chain (geometry of the chain = the block's OUTPUT map)
-                const Node& a0 = ND[h.fbd_a]; const Tensor& y = T[ND[h.fused_add].out];
-                *bk = Blk{i, h.a, ND[h.fused_add].out, h.cd.cout, a0.cd.cout, y.H, y.W, a0.cd.cin, true, true};
-                return true;
+                // chain_kernel<TAIL> addresses the shortcut's operand as [N][2H][2W][CIN0]: only an input map of exactly twice the output's sides
+                // (a 55x55 map also gives 28x28: the generic dual GEMM takes that one)
+                const Node& a0 = ND[h.fbd_a]; const Tensor& y = T[ND[h.fused_add].out]; const Tensor& x = T[h.a];
+                if (x.H == 2 * y.H && x.W == 2 * y.W) {
+                    *bk = Blk{i, h.a, ND[h.fused_add].out, h.cd.cout, a0.cd.cout, y.H, y.W, a0.cd.cin, true, true};
+                    return true;
+                }
             }
             if (h.dual >= 0 && h.fbd_a < 0 && h.cd.stride == 2 && h.cd.kernel == 1 && h.cd.quant_input && opt.fuse_tail) {
                 // the same for an opening block whose convs run as separate launches (stages 2 / 3 of ResNet-50; stage 1 when body.0 and the shortcut
                 // read different int8 forms): the dual-GEMM join (1c) becomes the chain's first block, body.2's int8 output is its mid2
-                const Node& g = ND[h.dual]; const Tensor& y = T[ND[h.fused_add].out];
-                if (g.cd.kernel == 1 && g.cd.stride == 1 && g.cd.quant_input && !g.cd.relu && !h.cd.relu) {
+                const Node& g = ND[h.dual]; const Tensor& y = T[ND[h.fused_add].out]; const Tensor& x = T[h.a]; const Tensor& m2 = T[g.a];
+                if (g.cd.kernel == 1 && g.cd.stride == 1 && g.cd.quant_input && !g.cd.relu && !h.cd.relu && h.cd.pad == 0 && g.cd.pad == 0 &&
+                    x.H == 2 * y.H && x.W == 2 * y.W && m2.H == y.H && m2.W == y.W) {
                     *bk = Blk{i, h.a, ND[h.fused_add].out, h.cd.cout, g.cd.cin, y.H, y.W, h.cd.cin, true, true};
                     return true;
                 }
@@ -2083,7 +2092,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             fill_out(&a.out32, a.q);
             if (st.dense) {
                 a.w = (const int8_t*)(net->d_w + nd.wf_off);
-                e = launch_fc_dense(a, (char*)output + (size_t)n0 * oT.C * 4, oT.C, net->out_float, net->d_chain ? (const uint32_t*)(net->d_chain + (size_t)part * net->chain_stride + kChainErrWord * 4) : nullptr, s);
+                e = launch_fc_dense(a, (char*)output + (size_t)n0 * oT.C * 4, oT.C, net->out_float, net->d_chain ? (const uint32_t*)(net->d_chain + (size_t)part * net->chain_stride + kChainErrWord * 4) : nullptr, net->epoch, s);
             } else if (nd.pool >= 0) { a.w = (const int8_t*)(net->d_w + nd.wf_off); e = launch_conv1x1_pool(a, s); }
             else if (nd.s2w) { a.w = (const int8_t*)(net->d_w + nd.wf_off); e = launch_conv3x3s2_wreg(a, s); }
             else if (nd.wstat) {
@@ -2264,7 +2273,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             fill_out(&a.out32, a.q);
             if (!net->d_chain) return fail(F8_ERR_STATE, "f8_net_run: chain scratch missing");
             a.sync = (uint32_t*)(net->d_chain + (size_t)part * net->chain_stride);
-            a.err = a.sync + kChainErrWord;
+            a.err = a.sync + kChainErrWord; a.epoch = net->epoch;
             a.xchg = (int8_t*)(net->d_chain + (size_t)part * net->chain_stride + 4096);
             a.timeout_ticks = (uint32_t)std::min<long long>((long long)net->opt.chain_timeout_ms * 100000ll, 0x7fffffffll);
             e = launch_chain(a, C, MID, oT.H, oT.W, tail ? hf.cd.cin : a0.cd.cin, s);
@@ -2311,7 +2320,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             fill_out(&a.out32, a.q);
             if (!net->d_chain) return fail(F8_ERR_STATE, "f8_net_run: chain scratch missing");
             a.sync = (uint32_t*)(net->d_chain + (size_t)part * net->chain_stride);
-            a.err = a.sync + kChainErrWord;
+            a.err = a.sync + kChainErrWord; a.epoch = net->epoch;
             a.xchg = (int8_t*)(net->d_chain + (size_t)part * net->chain_stride + 4096);
             a.timeout_ticks = (uint32_t)std::min<long long>((long long)net->opt.chain_timeout_ms * 100000ll, 0x7fffffffll);
             e = launch_bchain(a, x.C, x.H, x.W, s);
@@ -2426,7 +2435,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             OutArgs a{};
             a.x = (const int32_t*)fp(sT.forms[st.src_f]); a.N = N; a.C = sT.C; a.HW = sT.H * sT.W; a.Cs = sT.Cs;
             a.out = (char*)output + (size_t)n0 * sT.C * sT.H * sT.W * 4; a.as_float = net->out_float;
-            a.err = net->d_chain ? (const uint32_t*)(net->d_chain + (size_t)part * net->chain_stride + kChainErrWord * 4) : nullptr;
+            a.err = net->d_chain ? (const uint32_t*)(net->d_chain + (size_t)part * net->chain_stride + kChainErrWord * 4) : nullptr; a.epoch = net->epoch;
             e = launch_output(a, s);
             break;
         }
@@ -2595,6 +2604,10 @@ static int run_common(f8_net* net, const int32_t* input, void* output, int N, vo
             return fail(F8_ERR_STATE, "f8_net_run: current device %d, but this net lives on device %d (hipSetDevice before the call; one handle per device)", dev, net->device);
     }
     hipStream_t s = (hipStream_t)stream;
+    // this run's tag for the chain error words: a word an EARLIER run left behind (a transient halo time-out nobody collected with
+    // f8_net_check) neither cuts this run's waits short nor poisons its logits; it stays where it is for f8_net_check to report.
+    // (A replayed hipGraph carries the tag of its capture: there the word is sticky until f8_net_check, as it was before round 5.)
+    net->epoch = net->epoch % 0xffffffu + 1u;
     if (in_ready) {                    // the producer of this run's input (f8_net_set_input_ready); every schedule forks from / runs on `s`
         (void)hipStreamWaitEvent(s, in_ready, 0);
     }

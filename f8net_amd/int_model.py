@@ -107,12 +107,13 @@ class IntModel(nn.Module):
         ts = self._ptensors
         if ts is None:
             ts = self._ptensors = tuple(self.state_dict(keep_vars=True).values())
-        # ... and an XOR of the storage pointers: `param.data = new_tensor` — how the reference itself installs integer weights
-        # (fix_quant_ops.py:705-706) — bumps no version counter, it only rebinds the storage
+        # ... and an ORDER-SENSITIVE fold of the storage pointers: `param.data = new_tensor` — how the reference itself installs integer
+        # weights (fix_quant_ops.py:705-706) — bumps no version counter, it only rebinds the storage; a plain XOR would miss
+        # two parameters swapping their storages, the multiply-add chain does not
         v = p = 0
         for t in ts:
             v += t._version
-            p ^= t.data_ptr()
+            p = (p * 1000003 + t.data_ptr()) & 0xFFFFFFFFFFFFFFFF
         return (v, p)
 
     def _head_fraclen(self):

@@ -251,6 +251,24 @@ def test_intmodel_parameter_fingerprint_sees_rebound_storage():
     with torch.no_grad():
         w[0, 0, 0, 0] += 1                         # in-place edit: version counter
     assert m._param_version() != v1
+    # two parameters of one shape swapping their storages: no version moves, the SET of pointers is the same (an XOR fold missed it)
+    a, b = m.stage_0_layer_0.body[0].weight, m.stage_0_layer_0.body[2].weight
+    assert a.shape == b.shape
+    v2 = m._param_version()
+    a.data, b.data = b.data, a.data
+    assert m._param_version() != v2
+
+
+def test_tail_chain_is_planned_only_for_an_input_map_of_exactly_twice_the_output():
+    """chain_kernel<TAIL> addresses the stride-2 shortcut's operand as [N][2H][2W][CIN0]: a 55x55 stage-0 map (hw 217..220) also
+    gives a 28x28 stage 1, and a 27x27 one (hw 209..216) a 14x14 stage 2 — those joins must stay on the generic dual GEMM."""
+    r50 = topology.get('resnet50', normalize=True)
+    p = synth.make_params(r50, seed=3, fraclens=topology.R50_NVIDIA_FRACLENS)
+    assert build_net(r50, p, max_batch=2, hw=224).describe().count('_tail:') == 2
+    plan = build_net(r50, p, max_batch=2, hw=220).describe()      # 55 -> 28 -> 14: stage 1's join stays generic, stage 2's (28 = 2 x 14) is a TAIL
+    assert plan.count('_tail:') == 1 and '_tail:stage_2_layer_0' in plan and '_dual:stage_1_layer_0' in plan, plan
+    plan = build_net(r50, p, max_batch=2, hw=212).describe()      # 53 -> 27 -> 14
+    assert '_tail:' not in plan, plan
 
 
 def test_every_planned_kernel_name_is_a_symbol_of_the_library():

@@ -53,6 +53,21 @@ def test_fused_net_matches_oracle_fresh_seed(arch, dev):
     np.testing.assert_array_equal(got2, want[:2])
 
 
+@pytest.mark.parametrize('hw', [220, 212, 200])
+def test_resnet50_input_sizes_whose_stage_maps_are_not_halved_exactly(hw, dev):
+    """hw 220: stage 0 is 55x55 and stage 1 28x28; hw 212: stage 1 is 27x27 and stage 2 14x14 — output maps the TAIL chain instances exist for,
+    fed by input maps that are NOT twice their size (the planner took them, the kernel read a 55-wide map with stride 56).  The planner
+    leaves those joins to the generic dual GEMM; logits == oracle."""
+    from f8net_amd.net import build_net
+    spec = topology.get('resnet50', normalize=True)
+    params = synth.make_params(spec, seed=5, fraclens=topology.R50_NVIDIA_FRACLENS)
+    n = 3
+    x, x_fl = synth.make_input(spec, params, n, hw, seed=9)
+    net = build_net(spec, params, max_batch=n, hw=hw)
+    got = net.run(torch.from_numpy(x).to(dev)).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.net_forward(spec, params, x, x_fl), err_msg=f'hw{hw}: {net.describe()}')
+
+
 @pytest.mark.parametrize('arch', ['resnet18', 'mobilenet_v2'])
 def test_op_level_path_equals_fused_path(arch, dev):
     """The reference's control flow over our op-level kernels == the fused plan == the oracle."""
