@@ -19,8 +19,13 @@ Other BASELINE.json configurations:  --arch resnet18 --bs 128 (C2), --arch mobil
 --arch resnet50 --bs 256 (C4), --gpus 8 --bs 256 (C5: 2048 images over 8 GPUs).
 
 value            : the timed region is EXACTLY --steps steps with F8_PIPELINE_DEPTH (default 3) batches in flight (f8_net_set_pipelined(2),
-                   options arena_copies = pipeline_depth = 3).
+                   options arena_copies = pipeline_depth = 3), on the library's DEFAULT plan: integer-only requantisation in every epilogue
+                   (option requant_float = 0: shift / round-half-even / clamp, no float instruction — BASELINE north_star).  The timed loop
+                   rotates NX = 4 DISTINCT device-resident input batches (308 MB at bs 128: no step re-reads the batch of the step before).
+value_float_requant: the same steps on a handle planned with requant_float = 1 (float-converter requantisation where the planner bounds the value).
 value_unpipelined: the same steps, one batch in flight (runs back to back; each run = two concurrent sub-batches).
+latency          : per-batch latency (submission on the host -> logits complete on the device), closed loop with 1 and with `depth` batches
+                   outstanding: p50 / p99 over the batches, beside the closed-loop rate.
 roofline         : dominant kernel symbol by time; achieved = sum(algorithmic bytes of its launches) / sum(their
                    durations), durations from HIP events on the launch stream (f8_net_run_profiled).  `traffic` (HBM bytes per
                    launch, separate rocprofv3 --pmc passes) and `mfma` (INT8-MFMA busy fraction, rocprofv3 --pmc) are taken from
@@ -157,6 +162,7 @@ def main():
     fr_name = {'resnet50': 'NVIDIA-pretrained fraclens (normalize: True)', 'mobilenet_v2': "the reference log's learned fraclens (mbv2_fix_quant.out)"}.get(
         args.arch, 'seeded fraclens (weight_format [8,7]-style)')
     x_np, x_fl = synth.make_input(spec, params, BS, args.hw, seed=1 + rank)
+    NX = 4                          # distinct input batches the timed loops rotate (one tensor re-read every step stays warm in the 256 MB memory-side cache)
     pipe_mode = int(os.environ.get('F8_BENCH_PIPELINED', '2'))
     # planning hint: under pipelining mode 2 every launch covers the whole batch (matters for the 14x14 fusion rule at bs 64..127)
     # ... and `depth` whole batches are in flight, one arena copy each (a run with ONE batch in flight still cuts it `split` = 2 ways)
@@ -177,6 +183,7 @@ def main():
         net.upload()
         retiled = net.autotune(BS, dev) if args.autotune else 0      # one-time, outside the timed region
     x = torch.from_numpy(x_np).to(dev)
+    xs = [x] + [torch.from_numpy(synth.make_input(spec, params, BS, args.hw, seed=1 + rank + 7919 * j)[0]).to(dev) for j in range(1, NX)]
     # the all-gather of step i overlaps the compute of step i+1 (double-buffered logits); fence() completes every
     # outstanding collective before the clock stops
     # consecutive steps overlap inside the library as well (f8_net_set_pipelined: static input, double-buffered outputs)
@@ -193,24 +200,55 @@ def main():
             dev_sync()
 
         out = None
-        for _ in range(warmup):
-            sharded(x)
+        for j in range(warmup):
+            sharded(xs[j % NX])
         fence()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            out = sharded(x)
+        for j in range(steps):
+            out = sharded(xs[(warmup + j) % NX])
         fence()
-        dt = time.perf_counter() - t0
+        dt_own = dt = time.perf_counter() - t0
         if world > 1:
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         assert out.shape == (BS * world, spec.num_classes)
-        net.check()                         # sticky device error words (a chain launch's halo wait timed out; int32 input outside the head's format): raises
-        return dt, sharded.local[0]
+        net.check()                         # device error words (a chain launch's halo wait timed out; int32 input outside the head's format): raises
+        # the LAST step: index of its input batch, its local logits, the gathered logits, this rank's own clock
+        last = {'x': (warmup + steps - 1) % NX, 'local': sharded.local[(sharded.i - 1) % sharded.depth], 'full': out, 'dt_own': dt_own}
+        return dt, last
+
+    def closed_loop(mode, outstanding, steps, warmup):
+        """Per-batch latency: a batch is submitted only while fewer than `outstanding` are in flight (the host waits for the oldest one's logits);
+        latency = host submission -> completion event of that batch's logits (device timeline anchored to the host clock at a synchronised start)."""
+        net.set_pipelined(mode)
+        nb = max(2, depth) + 1
+        outs = [torch.empty((BS, spec.num_classes), dtype=torch.float32, device=dev) for _ in range(nb)]
+        for j in range(warmup):
+            net.run(xs[j % NX], out=outs[j % nb])
+        dev_sync()
+        base = torch.cuda.Event(enable_timing=True)
+        ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        base.record()
+        base.synchronize()
+        t0 = time.perf_counter()
+        sub_t = []
+        for j in range(steps):
+            if j >= outstanding:
+                ends[j - outstanding].synchronize()
+            sub_t.append(time.perf_counter() - t0)
+            net.run(xs[j % NX], out=outs[j % nb])
+            ends[j].record()
+        dev_sync()
+        dtc = time.perf_counter() - t0
+        lat = sorted(base.elapsed_time(ends[j]) - 1e3 * sub_t[j] for j in range(steps))
+        net.check()
+        return {'outstanding': outstanding, 'p50_ms': round(lat[len(lat) // 2], 4), 'p99_ms': round(lat[min(len(lat) - 1, int(0.99 * len(lat)))], 4),
+                'max_ms': round(lat[-1], 4), 'img_per_s': round(BS * steps / dtc, 1), 'batches': steps}
 
     if dry:
-        dt, logits = timed(pipe_mode, args.steps, args.warmup)
+        dt, last = timed(pipe_mode, args.steps, args.warmup)
+        selfcheck = f8dist.verify_gather(last['local'], last['full'], BS, args.steps, last['dt_own'])
         # every rank's gathered logits must hold every rank's shard, in rank order (the stub forward is a function of the images alone)
         full = f8dist.ShardedForward(lambda t: net.run(t, out=torch.empty((BS, spec.num_classes))), spec.num_classes)(x)
         for r in range(world):
@@ -223,6 +261,7 @@ def main():
             print(json.dumps({'metric': f'images/sec at bs={BS} ({PRETTY.get(args.arch, args.arch)} INT8)', 'value': round(BS * world * args.steps / dt, 1), 'unit': 'img/s',
                               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 4), 'higher_is_better': True,
                               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int8 x int8 -> int32 (exact integer)', 'data': 'synthetic',
+                              'multi_gpu': selfcheck,
                               'dry_run': 'gloo on CPU with a stub forward: NOT a measurement (rendezvous, sharding, fence, max over ranks and this line only)',
                               'config': {'workload': f'{spec.arch} dry run', 'global_batch': BS * world, 'parallelism': f'dp{world} (batch shards + all-gather of logits)'}}))
         return
@@ -232,7 +271,7 @@ def main():
     # headline region does not start on a cold device (measured at --steps 20: 5 warm-up steps from idle 81.7 k, from a busy
     # device 83.2 k img/s — power state / caches, not arithmetic).
     # (1) the same K steps with ONE batch in flight (every rank takes part: the loop holds collectives)
-    dt0, logits0 = timed(0, args.steps, min(args.warmup, 5)) if (pipe_mode != 0 and not lean) else (None, None)
+    dt0, _ = timed(0, args.steps, min(args.warmup, 5)) if (pipe_mode != 0 and not lean) else (None, None)
     # (2) per-launch durations for the roofline (rank 0; HIP events on the launch stream; the pipelining mode is set so that the
     #     profiled pass issues the launches the headline region issues: whole batch vs sub-batches)
     samples = []
@@ -240,12 +279,16 @@ def main():
         net.set_pipelined(pipe_mode)
         scratch = torch.empty((BS, spec.num_classes), dtype=torch.float32, device=dev)
         for _ in range(7):
-            _, ms_ = net.run_profiled(x, out=scratch)
+            _, ms_ = net.run_profiled(xs[len(samples) % NX], out=scratch)
             samples.append(ms_)
     if world > 1:
         dist.barrier()
     # (3) the headline: W warm-up steps, then EXACTLY K timed steps
-    dt, logits = timed(pipe_mode, args.steps, args.warmup)
+    dt, last = timed(pipe_mode, args.steps, args.warmup)
+    logits, x_last = last['local'], last['x']
+    # N > 1: the first multi-GPU launch verifies itself: the ranks RCCL really connected, each rank's own rate, and every rank's
+    # gathered block against a checksum its owner computed
+    selfcheck = f8dist.verify_gather(last['local'], last['full'], BS, args.steps, last['dt_own']) if world > 1 else None
     if dt0 is None:
         dt0 = dt
     # a timed region under MIN_TIMED_S is dominated by pipeline fill / drain and launch jitter: report a longer one beside it
@@ -258,20 +301,29 @@ def main():
             print(f'bench.py: the timed region of {args.steps} steps lasted {dt * 1e3:.1f} ms (< {MIN_TIMED_S} s); also timed {k2} steps '
                   f'({dte * 1e3:.1f} ms) -> value_extended', file=sys.stderr)
     net.set_pipelined(pipe_mode)
-    # (4b) the same K steps with INTEGER-ONLY requantisation (option requant_float = 0: shift / round-half-even / clamp in every epilogue, no
-    #      float instruction); the headline plan routes ReLU -> unsigned 8-bit right shifts of bounded accumulators through the float converter
-    #      (exact, compared over all 2^32 values on the device: tests/test_gpu_requant_probe.py).  Same logits, two arithmetic paths.
+    # (4b) the same K steps with the FLOAT-CONVERTER requantisation (option requant_float = 1: ReLU -> unsigned 8-bit right shifts of values the planner
+    #      bounds run v_cvt_f32_i32, v_mul_f32 by 2^-n, v_cvt_pk_u8_f32 — exact, compared over all 2^32 values on the device:
+    #      tests/test_gpu_requant_probe.py).  The headline plan above is the library default: INTEGER shift / round-half-even / clamp in every
+    #      epilogue, no float instruction.  Same logits, two arithmetic paths.
     rq_float = bool(net.get_option('requant_float'))
+    assert not rq_float or os.environ.get('F8_REQUANT_FLOAT') == '1', 'the headline runs the integer-only plan'
     extra_rq = {}
-    if world == 1 and not lean and rq_float:
-        opts_i = {'requant_float': 0}
+    if world == 1 and not lean and not rq_float:
+        opts_f = {'requant_float': 1}
         if pipe_mode == 2:
-            opts_i.update({'whole_batch_launches': 1, 'arena_copies': depth, 'pipeline_depth': depth})
-        net_i = build_net(spec, params, max_batch=BS, hw=224, options=opts_i)
-        net_i.upload()
-        dti, logits_i = timed(pipe_mode, args.steps, args.warmup, net=net_i)
-        extra_rq = {'value_int_requant': round(BS * args.steps / dti, 1), 'int_requant_matches': bool(torch.equal(logits_i[:BS], logits[:BS]))}
-        del net_i
+            opts_f.update({'whole_batch_launches': 1, 'arena_copies': depth, 'pipeline_depth': depth})
+        net_f = build_net(spec, params, max_batch=BS, hw=args.hw, options=opts_f)
+        net_f.upload()
+        dtf, last_f = timed(pipe_mode, args.steps, args.warmup, net=net_f)
+        extra_rq = {'value_float_requant': round(BS * args.steps / dtf, 1), 'float_requant_matches': bool(last_f['x'] == x_last and torch.equal(last_f['local'][:BS], logits[:BS]))}
+        del net_f
+        net.set_pipelined(pipe_mode)
+    # (4c) per-batch latency, closed loop: one batch outstanding (mode 0) and `depth` outstanding (the headline's schedule)
+    latency = None
+    if world == 1 and not lean:
+        nlat = max(20, min(args.steps, 200))
+        latency = {'definition': 'host submission -> logits complete on the device, closed loop (a batch is submitted when fewer than `outstanding` are in flight)',
+                   'depth1': closed_loop(0, 1, nlat, 3), f'depth{depth}': closed_loop(pipe_mode, depth, nlat, depth + 2) if pipe_mode == 2 else None}
         net.set_pipelined(pipe_mode)
 
     # (5) the drop-in module path and the host-fed path (single GPU, full runs only): the same K steps
@@ -284,7 +336,7 @@ def main():
         from f8net_amd import int_model, stream_eval
         m = int_model.from_params(spec, params).to(dev)
         m.set_pipelined(pipe_mode if pipe_mode else 0, depth=depth)
-        xi = x.clone(); setattr(xi, 'output_fraclen', x_fl)
+        xi = xs[x_last].clone(); setattr(xi, 'output_fraclen', x_fl)
         NO = depth + 1
         outs = [torch.empty((BS, spec.num_classes), dtype=torch.float32, device=dev) for _ in range(NO)]
         for i in range(min(args.warmup, 10) + 2):
@@ -299,7 +351,7 @@ def main():
         extra['intmodel_matches'] = bool(torch.equal(outs[(args.steps - 1) % NO], logits[:BS]))
         del m
         if spec.head.cin == 3:
-            hnet = build_net(spec, params, max_batch=BS, hw=224, options={'whole_batch_launches': 1, 'arena_copies': depth, 'pipeline_depth': depth})
+            hnet = build_net(spec, params, max_batch=BS, hw=args.hw, options={'whole_batch_launches': 1, 'arena_copies': depth, 'pipeline_depth': depth})
             ev = stream_eval.StreamEvaluator(hnet, normalize=normalize, mean=stream_eval.IMAGENET_MEAN, std=stream_eval.IMAGENET_STD, device=dev, depth=depth + 1)
             g = torch.Generator().manual_seed(11)
             pool = [torch.randint(0, 256, (BS, 224, 224, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(4)]
@@ -386,8 +438,10 @@ def main():
                                    f'int32 NCHW input resident in HBM' + ('' if headline else ' [not the headline configuration]'),
                        'global_batch': BS * world, 'parallelism': f'dp{world} (batch shards + RCCL all-gather of logits)',
                        'launches_per_step': sum(net.step_launches(i, BS) for i in range(n_l)), 'sub_batches': parts, 'autotuned_launches': retiled,
-                       'requant': 'float-converter (exact, probed): v_cvt_f32_i32, v_mul_f32 by 2^-n, v_cvt_pk_u8_f32 where the planner bounds the value (conv accumulators, '
-                                  'the chain launches\' int32 stream), integer shift/round/clamp (v_ashr_pk_u8_i32) elsewhere; value_int_requant = the same steps with option requant_float = 0' if rq_float else 'int',
+                       'requant': 'integer: shift / round-half-even / clamp in every epilogue (v_bfe_u32, v_add3_u32, v_ashr_pk_u8_i32 / v_ashrrev_i32 + v_med3_i32), no float instruction '
+                                  '(option requant_float = 0, the library default); value_float_requant = the same steps with requant_float = 1' if not rq_float else
+                                  'float-converter where the planner bounds the value (F8_REQUANT_FLOAT=1 in the environment): NOT the headline arithmetic',
+                       'inputs': f'{NX} distinct device-resident batches rotated step by step',
                        'schedule': {0: 'runs back to back (two concurrent sub-batches per run)',
                                     1: 'pipelined: sub-batches of consecutive runs overlap (f8_net_set_pipelined(1))',
                                     2: f'pipelined: {depth} consecutive batches in flight (one arena copy each), each launch covers a whole batch '
@@ -411,17 +465,25 @@ def main():
                           'hbm_frac_structural_bytes': round(value / world * STRUCT_BYTES_PER_IMG.get(args.arch, 0.0) / 1e9 / HBM_PEAK_GBS, 4),
                           'hbm_frac_algorithmic_bytes': round(value / world * sum(r[3] for r in rows) / BS / 1e9 / HBM_PEAK_GBS, 4),
                           'alg_bytes_per_img': round(sum(r[3] for r in rows) / BS, 0)},
+            # per kernel symbol: launches per step, live duration (HIP events), algorithmic ops / bytes per step — tools/summarize_prof.py divides the
+            # MFMA instructions the counters saw by the algorithmic ones (issued / algorithmic: halo recompute, tile padding)
+            'per_kernel': {k: {'launches': e['launches'], 'us': round(1e3 * e['ms'], 2), 'alg_ops': round(e['ops'], 0), 'alg_bytes': round(e['bytes'], 0)}
+                           for k, e in by_kernel.items() if e['ms'] > 0},
             'build': {'csrc_sha256': stamp[:16]},
         }
         result.update(extra)
         result.update(extra_rq)
+        if latency is not None:
+            result['latency'] = latency
+        if selfcheck is not None:
+            result['multi_gpu'] = selfcheck
         if ext is not None:
             result['value_extended'] = round(BS * world * ext[0] / ext[1], 1)
             result['steps_extended'] = ext[0]
         if notes:
             result['notes'] = notes
         if world == 1 and not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline(spec, params, x_np, x_fl, logits[:BS].cpu().numpy())
+            result['cpu_baseline'] = cpu_baseline(spec, params, xs[x_last].cpu().numpy(), x_fl, logits[:BS].cpu().numpy())
             result['cpu_baseline']['c1'] = cpu_config1()
         elif world == 1:
             result['cpu_baseline'] = None

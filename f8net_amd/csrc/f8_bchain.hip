@@ -194,7 +194,10 @@ bchain_kernel(const BChainArgs a) {
                     if (wall_clock64() - t0 > t_limit) { ok = false; break; }
                     if ((__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 8) == a.epoch) break;   // another tile of THIS run gave up
                 }
-                if (!ok) __hip_atomic_store(a.err, (a.epoch << 8) | 0x80u | ((unsigned)seq & 0x3fu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!ok) {
+                    __hip_atomic_store(a.err, (a.epoch << 8) | 0x80u | ((unsigned)seq & 0x3fu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (a.err_host) __hip_atomic_store(a.err_host, (a.epoch << 8) | 0x80u | ((unsigned)seq & 0x3fu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
             __syncthreads();
             const int side = t2 / (NT / 2), idx = t2 % (NT / 2);

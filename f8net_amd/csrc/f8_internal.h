@@ -56,8 +56,9 @@ struct Options {
     int graph = 0;               // hipGraph capture / replay of a run
     int stagger = -1, stagger_pipelined = 2;
     int check_device = 1;        // f8_net_run fails if the current device is not the one the handle was uploaded to
-    int requant_float = 1;       // 1: ReLU -> unsigned 8-bit right shifts may run through the float converter (v_cvt_f32_i32, v_mul_f32 by 2^-n,
-                                 // v_cvt_pk_u8_f32: exact where planned, f8_device.h); 0: integer shift / round / clamp in every kernel
+    int requant_float = 0;       // 0 (default since round 5: BASELINE north_star — no FP32 multiply in any epilogue): integer shift / round-half-even /
+                                 // clamp in every kernel; 1: ReLU -> unsigned 8-bit right shifts of values the planner can bound may run through the
+                                 // float converter (v_cvt_f32_i32, v_mul_f32 by 2^-n, v_cvt_pk_u8_f32: exact where planned, f8_device.h)
     int check_input_range = 1;   // int32 inputs that are NARROWED to the head's 8-bit format (no requant) are range-checked on the device; f8_net_check reports
 };
 void options_from_env(Options* o);                       // f8_net.cpp
@@ -214,6 +215,8 @@ struct ChainArgs {
     int32_t* out32; QuantOut q[2];         // forms of the last block's output
     uint32_t* sync;                        // [0] ticket, [16 + workgroup] halo flag; zeroed before every launch
     uint32_t* err;                         // error word (a halo spin timed out): (epoch << 8) | code; read by f8_net_check
+    uint32_t* err_host;                    // the same word's mirror in host-visible (pinned, mapped) memory: f8_net_run reads it WITHOUT a synchronisation and
+                                           // refuses further runs until f8_net_check has collected the error (nullptr: no mirror)
     uint32_t epoch;                        // this run's tag (1 .. 2^24 - 1): only an error of THIS run ends waits early / poisons the logits —
                                            // a word left by an earlier run stays for f8_net_check to report and changes nothing else
     int8_t* xchg;                          // halo rows between vertically adjacent tiles: [workgroup][parity][side][W * MID]
@@ -248,7 +251,7 @@ struct BChainArgs {
     const int8_t* wsc; const int32_t* bsc; // shortcut conv, fragment order / offset-corrected bias
     int32_t N, NG;
     int32_t* out32; QuantOut q[2];
-    uint32_t* sync; uint32_t* err; uint32_t epoch; int8_t* xchg; uint32_t timeout_ticks;   // as ChainArgs
+    uint32_t* sync; uint32_t* err; uint32_t* err_host; uint32_t epoch; int8_t* xchg; uint32_t timeout_ticks;   // as ChainArgs
     void* trace;
 };
 

@@ -118,3 +118,44 @@ class PipelinedShardedForward(ShardedForward):
             if self.work[k] is not None:
                 self.work[k].wait()
                 self.work[k] = None
+
+
+def verify_gather(local_logits, gathered_logits, n_local: int, steps: int, dt_own: float, group=None):
+    """Self-check of a multi-rank run (bench.py --gpus N), collective on every rank:
+
+    * `rccl_ranks`: the number of distinct rank ids an actual all-gather returned (= the ranks the backend really connected);
+    * `per_rank_img_s`: each rank's OWN rate over its own clock (the headline takes the slowest rank's time);
+    * `logits_gathered_ok`: every rank compares each block of ITS gathered logits with a checksum the owning rank computed from its local
+      logits (an int64 sum and an order-sensitive weighted int64 sum, both exact), then the verdicts are AND-reduced.
+
+    Replaces what the reference's DataParallel gather / metric all-reduce would silently assume (fix_train.py:269, myutils/distributed.py:79-87)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    dev = local_logits.device
+
+    def checksum(t):
+        # the logits are int32 values converted to float32 (integer-valued): summed as int64 the checksum is exact and independent of the reduction
+        # order (int64 wrap-around included); a poisoned buffer (NaN: f8_fc.hip) is marked, not converted
+        t = t.detach().reshape(-1)
+        bad = (~torch.isfinite(t)).sum().to(torch.float64)
+        v = torch.nan_to_num(t, nan=0.0, posinf=0.0, neginf=0.0).to(torch.int64)
+        w = torch.arange(1, v.numel() + 1, dtype=torch.int64, device=v.device) % 65521
+        return torch.stack([v.sum().to(torch.float64), (v * w).sum().remainder(1 << 40).to(torch.float64), bad])
+
+    mine = torch.cat([torch.tensor([float(rank), n_local * steps / max(dt_own, 1e-12)], dtype=torch.float64, device=dev), checksum(local_logits[:n_local])])
+    if world > 1:
+        table = torch.empty((world, mine.numel()), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(table, mine[None].contiguous(), group=group)
+    else:
+        table = mine[None]
+    ok = 1
+    for r in range(world):
+        blk = gathered_logits[r * n_local:(r + 1) * n_local] if world > 1 else local_logits[:n_local]
+        if blk.shape[0] != n_local or not torch.equal(checksum(blk), table[r, 2:]):
+            ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    ids = sorted({int(v) for v in table[:, 0].tolist()})
+    return {'rccl_ranks': len(ids), 'rank_ids': ids, 'backend': dist.get_backend(group) if dist.is_initialized() else None,
+            'per_rank_img_s': [round(float(v), 1) for v in table[:, 1].tolist()], 'logits_gathered_ok': bool(int(flag.item()) == 1)}

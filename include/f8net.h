@@ -240,11 +240,11 @@ int f8_net_check(f8_net* net);
  *               512 -> 256 / 1024 -> 512 reductions of smaller launches),
  *               patch3x3, dual_wide, deep_nk, bk128, dw_dot4, opener_stg, whole_batch_launches (hint: runs will use
  *               f8_net_set_pipelined(2)),
- *               requant_float (default 1: a ReLU -> unsigned-8-bit right shift (1..16) of a value the PLANNER CAN BOUND — conv accumulators, the
- *               int32 stream of a chain launch — runs through the float converter: v_cvt_f32_i32, v_mul_f32 by 2^-n, v_cvt_pk_u8_f32: exact,
- *               compared with the reference's arithmetic over all 2^32 inputs on the device; anything unbounded takes the integer form by
- *               itself; 0: INTEGER shift / round-half-even / clamp in every kernel (fix_quant_ops.py:99-112 literally, on gfx950's
- *               v_ashr_pk_u8_i32; no float instruction in any epilogue).  Same results either way, bit for bit)
+ *               requant_float (default 0: INTEGER shift / round-half-even / clamp in every kernel — fix_quant_ops.py:99-112 literally, on gfx950's
+ *               v_ashr_pk_u8_i32; no float instruction in any epilogue; 1: a ReLU -> unsigned-8-bit right shift (1..16) of a value the PLANNER
+ *               CAN BOUND — conv accumulators, the int32 stream of a chain launch — runs through the float converter: v_cvt_f32_i32, v_mul_f32
+ *               by 2^-n, v_cvt_pk_u8_f32: exact, compared with the reference's arithmetic over all 2^32 inputs on the device; anything
+ *               unbounded takes the integer form by itself.  Same results either way, bit for bit)
  *   scheduling: chunk56 / chunk28 / chunk14 (images per chunk of the fused blocks; -1 = derived from chunk_budget_mb, 0 = whole
  *               batch), chunk_budget_mb (memory-side cache a chunk's int32 stream may occupy), chunk_ds, chunk_opener,
  *               split_streams, graph, stagger, stagger_pipelined, stem_wpc, stem_grid_div (row-walking head on 1 / n of the CUs; 0 = by output form), check_device, check_input_range, pipeline_depth (2..4 runs in flight),

@@ -38,6 +38,13 @@ YMLS = {
     'mobilenet_v1': 'apps/imagenet/mobilenetv1/conventional/mbv1_fix_quant_test_int_op_only_on_cpu.yml',
     'mobilenet_v2': 'apps/imagenet/mobilenetv2/conventional/mbv2_fix_quant_test_int_op_only_on_cpu.yml',
 }
+# Depths the reference's `Model` builds (fix_resnet.py:418-451: block_type_dict / block_setting_dict) but ships no yml for: the yml of the
+# same block type with FLAGS.depth overridden before the model is constructed (round 5: ResNet-34 / -101 / -152 — the 23- and 36-block stages
+# force the chain cut at kChainMaxBlocks and the identity-first chain instances through whole networks)
+DEPTH_OVERRIDE = {'resnet34': ('resnet18', 34), 'resnet101': ('resnet50', 101), 'resnet152': ('resnet50', 152)}
+for _a, (_base, _d) in DEPTH_OVERRIDE.items():
+    YMLS[_a] = YMLS[_base]
+DEEP = list(DEPTH_OVERRIDE)
 
 
 def checksum(a: np.ndarray):
@@ -67,6 +74,8 @@ def build_reference_int_model(arch, yml=None, float_state=None):
     sys.path.insert(0, REF)
     sys.argv = ['gen_golden', f'app:{os.path.join(REF, yml or YMLS[arch])}', 'bs:1']
     from myutils.config import FLAGS
+    if arch in DEPTH_OVERRIDE:
+        FLAGS.depth = DEPTH_OVERRIDE[arch][1]
     model_lib = importlib.import_module(FLAGS.model)
     from models.fix_quant_ops import ReLUClipFXQConvBN, ReLUClipFXQLinear
     torch.manual_seed(0)
@@ -466,7 +475,8 @@ def main():
         child_model(args.child)
     else:
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
-        for c in ['ops'] + list(YMLS) + [f'export:{c}' for c in EXPORT_CASES] + [f'onnx:{a}' for a in list(YMLS) + ['resnet18+lshift']]:
+        base = [a for a in YMLS if a not in DEEP]
+        for c in ['ops'] + list(YMLS) + [f'export:{c}' for c in EXPORT_CASES] + [f'onnx:{a}' for a in base + ['resnet18+lshift']]:
             subprocess.check_call([sys.executable, os.path.abspath(__file__), '--child', c], env=env)
 
 

@@ -285,7 +285,7 @@ def test_every_planned_kernel_name_is_a_symbol_of_the_library():
     assert len(have) > 50, 'no kernel symbols found'
     for arch, kw in (('resnet50', dict(normalize=True)), ('resnet18', {}), ('mobilenet_v2', {}), ('mobilenet_v1', {})):
         spec = topology.get(arch, **kw)
-        for opts in ({}, {'requant_float': 0}):
+        for opts in ({}, {'requant_float': 1}):
             net = build_net(spec, synth.reference_params(spec), max_batch=128, hw=224, options=opts)
             for i in range(net.num_launches):
                 k = net.launch_kernel(i)
@@ -298,20 +298,21 @@ def test_every_planned_kernel_name_is_a_symbol_of_the_library():
 
 def test_planner_bounds_the_residual_stream_before_it_plans_the_float_requantisation():
     """f8_net.cpp tensor_amax: the int32 stream of a chain launch is the shifted sum of bounded conv accumulators; the float-converter instance
-    (template argument 1) is planned only while that bound (and every accumulator's) stays below 2^31 - 2^16 — a bias that lifts ONE stream channel
-    next to 2^31 plans the integer instance (2) for that launch alone, and so does option requant_float = 0 for every launch."""
+    (template argument 1; option requant_float = 1) is planned only while that bound (and every accumulator's) stays below 2^31 - 2^16 — a bias that
+    lifts ONE stream channel next to 2^31 plans the integer instance (2) for that launch alone; the default (requant_float = 0) plans it for every launch."""
     def chains(net):
         return [net.launch_kernel(i) for i in range(net.num_launches) if 'chain_kernel<' in net.launch_kernel(i)]
     r50 = topology.get('resnet50', normalize=True)
     p = synth.reference_params(r50)
-    ks = chains(build_net(r50, p, max_batch=8, hw=224))
+    fl = {'requant_float': 1}
+    ks = chains(build_net(r50, p, max_batch=8, hw=224, options=fl))
     assert len(ks) == 3 and all(re.search(r', 1, false, (false|true)>$', k) for k in ks), ks
-    ks = chains(build_net(r50, p, max_batch=8, hw=224, options={'requant_float': 0}))
+    ks = chains(build_net(r50, p, max_batch=8, hw=224))
     assert len(ks) == 3 and all(re.search(r', 2, false, (false|true)>$', k) for k in ks), ks
     q = {k: (v.copy() if hasattr(v, 'copy') else v) for k, v in p.items()}
     q['stage_1_layer_2.body.4.bias'][5] = 2 ** 31 - 2 ** 18          # body.4 feeds only the stream: no accumulator that is requantised grows
-    ks = chains(build_net(r50, q, max_batch=8, hw=224))
+    ks = chains(build_net(r50, q, max_batch=8, hw=224, options=fl))
     assert [re.search(r', (\d), false, (false|true)>$', k).group(1) for k in ks] == ['1', '2', '1'], ks
     r18 = topology.get('resnet18')
-    ks = chains(build_net(r18, synth.reference_params(r18), max_batch=8, hw=224))
+    ks = chains(build_net(r18, synth.reference_params(r18), max_batch=8, hw=224, options=fl))
     assert len(ks) == 3 and all(re.search(r', 1, (false|true), 8>$', k) for k in ks), ks       # stage 0 reads the max-pooled head output: bounded through the pool node

@@ -169,7 +169,48 @@ def test_bench_dry_run_dist_world2():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['warmup'] == 1 and d['scaling'] == 'weak' and d['higher_is_better'] is True
     assert d['config']['global_batch'] == 4 and d['config']['parallelism'].startswith('dp2') and 'dry_run' in d and d['value'] > 0
+    # the launch verifies itself: ranks the backend connected, each rank's own rate, every rank's gathered blocks vs the owners' checksums
+    mg = d['multi_gpu']
+    assert mg['rccl_ranks'] == 2 and mg['rank_ids'] == [0, 1] and mg['backend'] == 'gloo' and mg['logits_gathered_ok'] is True
+    assert len(mg['per_rank_img_s']) == 2 and all(v > 0 for v in mg['per_rank_img_s'])
     # --gpus must match the world size of the launch
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run-dist', '--bs', '2', '--hw', '32', '--arch', 'resnet18'],
                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r1.returncode != 0 and 'WORLD_SIZE' in (r1.stderr + r1.stdout)
+
+
+def _verify_worker(rank, world, port, corrupt, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch
+    import torch.distributed as dist
+    from f8net_amd import dist as f8dist
+    f8dist.init_from_env(backend='gloo')
+    n, classes = 3, 5
+    local = (torch.arange(n * classes, dtype=torch.float32).reshape(n, classes) + 1000 * rank)
+    full = torch.empty((n * world, classes))
+    dist.all_gather_into_tensor(full, local)
+    if corrupt and rank == 1:
+        full[0, 2] += 1                       # rank 1's copy of rank 0's block differs from what rank 0 computed
+    q.put((rank, f8dist.verify_gather(local, full, n, 10, 0.5)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('corrupt', [False, True])
+def test_verify_gather_flags_a_block_that_differs_from_its_owners_checksum(corrupt):
+    """dist.verify_gather: every rank checks every gathered block against the checksum of the rank that produced it; ONE wrong value on ONE
+    rank turns `logits_gathered_ok` false on EVERY rank (the verdicts are AND-reduced)."""
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29691 + int(corrupt)
+    ps = [ctx.Process(target=_verify_worker, args=(r, 2, port, corrupt, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        assert got[r]['rccl_ranks'] == 2 and got[r]['logits_gathered_ok'] is (not corrupt), got
+        assert got[r]['per_rank_img_s'] == [60.0, 60.0]

@@ -78,15 +78,15 @@ def test_stage_chain_matches_oracle(dev, cfg, variant, tail):
 
 
 @pytest.mark.parametrize('cfg', [CHAINS[0], CHAINS[2], CHAINS[4], CHAINS[5]], ids=lambda g: 'x'.join(map(str, g)))
-@pytest.mark.parametrize('mode', ['requant_float=0', 'bias_near_2^31'])
-def test_stage_chain_integer_requant_instances(dev, cfg, mode):
-    """The float-converter requantisation is planned only where it is provably exact.  `requant_float = 0` plans the INTEGER form
-    (shift / round-half-even / clamp, fix_quant_ops.py:99-112; no float instruction) in every instance; a bias next to 2^31 makes
+@pytest.mark.parametrize('mode', ['requant_float=1', 'bias_near_2^31'])
+def test_stage_chain_float_requant_instances(dev, cfg, mode):
+    """The float-converter requantisation (option `requant_float = 1`; the default plans the INTEGER form — shift / round-half-even / clamp,
+    fix_quant_ops.py:99-112; no float instruction — in every instance) is planned only where it is provably exact; a bias next to 2^31 makes
     body.0 / body.2 accumulators unboundable (f8_net.cpp conv_acc_bounded): the reference's `v + 2^(n-1)` wraps there (the value turns
     negative, the clamp makes it 0) and the launch must take the integer instance by itself — and equal the oracle either way."""
     for tail in ('int32_out', 'int8_out'):
-        _run_stage_chain(dev, cfg, 'acc_shifts_left', tail, options={'requant_float': 0} if mode == 'requant_float=0' else None,
-                         big_bias=(mode != 'requant_float=0'))
+        _run_stage_chain(dev, cfg, 'acc_shifts_left', tail, options={'requant_float': 1},      # (the default, 0, is what every other test of this file runs)
+                         big_bias=(mode != 'requant_float=1'))
 
 
 def test_stage_chain_whose_stream_the_planner_cannot_bound(dev):
@@ -196,13 +196,13 @@ TAIL_CHAINS = [(512, 128, 28, 3, 256, 3), (512, 128, 28, 1, 256, 5), (512, 128, 
 
 
 @pytest.mark.parametrize('cfg', TAIL_CHAINS, ids=lambda g: 'x'.join(map(str, g)))
-@pytest.mark.parametrize('variant', ['body_shifts_left', 'shortcut_shifts_left', 'two_input_forms', 'requant_float=0', 'fuse_tail=0'])
+@pytest.mark.parametrize('variant', ['body_shifts_left', 'shortcut_shifts_left', 'two_input_forms', 'requant_float=1', 'fuse_tail=0'])
 def test_stage_chain_opened_by_a_stride2_block_matches_oracle(dev, cfg, variant):
     """`two_input_forms`: body.0 and the shortcut read the block input in DIFFERENT int8 formats — the planner does not fuse body.0 + body.2 on the
     opener kernel (pass 1d) but the dual-GEMM join still opens the chain; `fuse_tail=0`: the round-3 plan (whole opener in one launch / a dual-GEMM
     launch, identity chain behind it)."""
     C, MID, HW, nid, CIN0, N = cfg
-    if N > 8 and variant not in ('body_shifts_left', 'requant_float=0'):
+    if N > 8 and variant not in ('body_shifts_left', 'requant_float=1'):
         pytest.skip('format variants are covered at the small batch')
     HWI = 2 * HW
     name = 'o.0'
@@ -226,8 +226,8 @@ def test_stage_chain_opened_by_a_stride2_block_matches_oracle(dev, cfg, variant)
     x = synth.rand_normal_int(23, 'tailx' + variant, (N, CIN0, HWI, HWI), 3.0e3).astype(np.int32)
 
     net = F8Net()
-    if variant == 'requant_float=0':
-        net.set_option('requant_float', 0)
+    if variant == 'requant_float=1':
+        net.set_option('requant_float', 1)
     if variant == 'fuse_tail=0':
         net.set_option('fuse_tail', 0)
     t = net.input(CIN0, HWI, HWI, x_fl)
@@ -297,13 +297,13 @@ def test_basic_block_chain_matches_oracle(dev, cfg, variant, tail):
 
 
 @pytest.mark.parametrize('cfg', [BCHAINS[0], (128, 28, 2, 5), (256, 14, 2, 4)], ids=lambda g: 'x'.join(map(str, g)))
-@pytest.mark.parametrize('mode', ['requant_float=0', 'bias_near_2^31'])
-def test_basic_block_chain_integer_requant_instances(dev, cfg, mode):
-    """As test_stage_chain_integer_requant_instances, for bchain_kernel: the integer instance by option, and by itself where the first
+@pytest.mark.parametrize('mode', ['requant_float=1', 'bias_near_2^31'])
+def test_basic_block_chain_float_requant_instances(dev, cfg, mode):
+    """As test_stage_chain_float_requant_instances, for bchain_kernel: the float-converter instance by option, the integer one by itself where the first
     conv's accumulators cannot be bounded (bias next to 2^31: the reference's rounding add wraps)."""
     for tail in ('int32_out', 'int8_out'):
-        _run_basic_chain(dev, cfg, 'acc_shifts_left', tail, options={'requant_float': 0} if mode == 'requant_float=0' else None,
-                         big_bias=(mode != 'requant_float=0'))
+        _run_basic_chain(dev, cfg, 'acc_shifts_left', tail, options={'requant_float': 1},      # (the default, 0, is what every other test of this file runs)
+                         big_bias=(mode != 'requant_float=1'))
 
 
 def _run_basic_chain(dev, cfg, variant, tail, options=None, big_bias=False):

@@ -12,6 +12,7 @@ from f8net_amd import synth, topology
 from oracle import oracle
 
 ARCHS = ['resnet18', 'resnet50', 'mobilenet_v1', 'mobilenet_v2']
+DEEP = ['resnet34', 'resnet101', 'resnet152']      # depths the reference's Model builds without a yml (fix_resnet.py:418-451): chains cut at kChainMaxBlocks, identity-first chain instances
 
 
 @pytest.fixture(scope='module')
@@ -26,7 +27,7 @@ def _golden_setup(arch, golden_dir):
     return g, spec, synth.reference_params(spec, seed=1234)
 
 
-@pytest.mark.parametrize('arch', ARCHS)
+@pytest.mark.parametrize('arch', ARCHS + DEEP)
 def test_fused_net_matches_reference_golden(arch, golden_dir, dev):
     from f8net_amd.net import build_net
     g, spec, params = _golden_setup(arch, golden_dir)
@@ -37,7 +38,7 @@ def test_fused_net_matches_reference_golden(arch, golden_dir, dev):
         np.testing.assert_array_equal(got, g[f's1234_hw{hw}_n{n}/logits'], err_msg=f'{arch} hw{hw}')
 
 
-@pytest.mark.parametrize('arch', ARCHS)
+@pytest.mark.parametrize('arch', ARCHS + DEEP)
 def test_fused_net_matches_oracle_fresh_seed(arch, dev):
     from f8net_amd.net import build_net
     spec = topology.get(arch, normalize=(arch == 'mobilenet_v2'))
@@ -156,9 +157,9 @@ def test_every_inverted_residual_block_fused_matches_golden(dev, golden_dir):
 
 @pytest.mark.parametrize('arch', ARCHS)
 def test_integer_only_requant_plan_matches_golden(arch, golden_dir, dev):
-    """Option requant_float = 0: every kernel requantises with the integer shift / round-half-even / clamp of fix_quant_ops.py:99-112 (no
-    float instruction in any epilogue); the default plan routes ReLU -> unsigned 8-bit right shifts of bounded accumulators through the
-    float converter instead.  Both equal the goldens captured from the reference."""
+    """Option requant_float = 0 (the default since round 5): every kernel requantises with the integer shift / round-half-even / clamp of
+    fix_quant_ops.py:99-112 (no float instruction in any epilogue); requant_float = 1 routes ReLU -> unsigned 8-bit right shifts of bounded
+    accumulators through the float converter instead.  Both equal the goldens captured from the reference."""
     from f8net_amd.net import build_net
     g, spec, params = _golden_setup(arch, golden_dir)
     for hw, n in ((64, 2), (224, 1)):
@@ -185,7 +186,7 @@ def test_mobilenet_v2_fused_launches_where_the_rounding_add_wraps(dev):
     for hw, n in ((64, 3), (224, 2)):
         x, fl = synth.make_input(spec, params, n, hw, seed=3)
         want = oracle.net_forward(spec, params, x, fl)
-        for opts in ({'fuse_ir': 2}, {'fuse_ir': 2, 'requant_float': 0}):
+        for opts in ({'fuse_ir': 2, 'requant_float': 1}, {'fuse_ir': 2, 'requant_float': 0}):
             net = build_net(spec, params, max_batch=n, hw=hw, options=opts)
             plan = net.describe()
             assert 'head3x3s2+dw3x3+1x1' in plan and plan.count('fused_ir_') == 16, plan
@@ -266,3 +267,37 @@ def test_late_stage_kernels_equal_the_tile_per_workgroup_plan_at_every_batch_siz
         got = big.run(xd[:k].contiguous()).cpu().numpy()
         np.testing.assert_array_equal(got, full[:k])
     big.set_pipelined(False)
+
+
+@pytest.mark.parametrize('rq', [0, 1])
+def test_bench_plan_with_three_batches_in_flight_equals_the_oracle(rq, dev):
+    """bench.py's EXACT plan and schedule (VERDICT r4 #5c): ResNet-50, 128 images, `whole_batch_launches = 1, arena_copies = 3,
+    pipeline_depth = 3`, `set_pipelined(2)`, 12 overlapping runs over 4 rotating input batches and 4 rotating output buffers — 8 images of
+    every run (the first 3, the last 3 and two from the middle of the batch: first / last workgroup groups of every launch) against the CPU
+    oracle; rq = 0 is the headline's integer-only requantisation, rq = 1 the float-converter plan bench.py times beside it."""
+    from f8net_amd.net import build_net
+    spec = topology.get('resnet50', normalize=True)
+    params = synth.reference_params(spec, seed=1234)
+    depth, NX, N = 3, 4, 128
+    net = build_net(spec, params, max_batch=N, hw=224, options={'whole_batch_launches': 1, 'arena_copies': depth, 'pipeline_depth': depth, 'requant_float': rq})
+    net.upload()
+    net.set_pipelined(2)
+    pick = [0, 1, 2, 63, 64, 125, 126, 127]
+    xs, wants = [], []
+    for j in range(NX):
+        x, fl = synth.make_input(spec, params, N, 224, seed=100 + j)
+        xs.append(torch.from_numpy(x).to(dev))
+        wants.append(oracle.net_forward(spec, params, np.ascontiguousarray(x[pick]), fl))
+    outs = [torch.empty((N, spec.num_classes), dtype=torch.float32, device=dev) for _ in range(depth + 1)]
+    keep = []
+    for i in range(12):
+        net.run(xs[i % NX], out=outs[i % (depth + 1)])
+        keep.append((i % NX, outs[i % (depth + 1)]))
+        if (i + 1) % (depth + 1) == 0:                     # the output ring is full: collect it before its buffers are rewritten
+            torch.cuda.synchronize()
+            for j, o in keep:
+                np.testing.assert_array_equal(o[pick].cpu().numpy(), wants[j], err_msg=f'run with input {j}, rq {rq}')
+            keep = []
+    torch.cuda.synchronize()
+    net.check()
+    net.set_pipelined(False)

@@ -458,3 +458,50 @@ def test_depthwise_requant_where_the_rounding_add_wraps(dev, big):
     want = oracle.conv2d(q, w2, np.zeros(32, np.int32), 1, 0)
     got = net.run(_t(x, dev)).cpu().numpy().reshape(N, 32, H, H)
     np.testing.assert_array_equal(got, want)
+
+
+def test_chain_halo_timeout_poisons_one_run_is_reported_and_the_handle_recovers():
+    """ADVICE r4 (medium) / VERDICT r4 #5d.  `chain_timeout_ms = 0` makes a stage-chain launch give up at its first unsuccessful poll of a neighbour's
+    flag (a stand-in for "another process held the CUs"): the launch runs on without waiting, so the run's logits are garbage and must be POISONED
+    (NaN); the next f8_net_run must REFUSE (host-visible mirror of the error word, no synchronisation needed); f8_net_check reports and re-arms; with
+    the time-out restored the very same handle equals the oracle again — the error word of the failed run neither cuts later waits short nor poisons
+    later logits (it carries the failed run's tag)."""
+    import numpy as np
+    import torch
+    from f8net_amd import synth, topology
+    from f8net_amd._lib import F8Error
+    from f8net_amd.net import build_net
+    from oracle import oracle
+    spec = topology.get('resnet50', normalize=True)
+    params = synth.make_params(spec, seed=21, fraclens=topology.R50_NVIDIA_FRACLENS)
+    n = 8
+    x, fl = synth.make_input(spec, params, n, 224, seed=2)
+    want = oracle.net_forward(spec, params, x, fl)
+    net = build_net(spec, params, max_batch=n, hw=224)
+    assert 'stage_chain' in net.describe()
+    xd = torch.from_numpy(x).cuda()
+    assert np.array_equal(net.run(xd).cpu().numpy(), want)
+    net.set_option('chain_timeout_ms', 0)
+    failed = None
+    for _ in range(20):                       # 14 tiles per image at 56x56: some neighbour is late in (practically) every launch
+        try:
+            y = net.run(xd)
+        except F8Error as e:                  # the mirror already shows an earlier iteration's time-out
+            failed = str(e)
+            break
+        torch.cuda.synchronize()
+        if torch.isnan(y).any():
+            assert torch.isnan(y).all(), 'a run whose chain launch gave up must poison ALL its logits'
+            with pytest.raises(F8Error, match='gave up waiting'):
+                net.run(xd)                   # refused without a synchronisation: the host-visible mirror is set
+            failed = 'nan'
+            break
+    if failed is None:
+        pytest.skip('no halo wait was ever unsuccessful on this box (nothing to test)')
+    with pytest.raises(F8Error, match='gave up waiting'):
+        net.check()
+    net.set_option('chain_timeout_ms', 10000)
+    for _ in range(3):
+        got = net.run(xd).cpu().numpy()
+        assert np.array_equal(got, want), 'the handle must recover after f8_net_check'
+    net.check()

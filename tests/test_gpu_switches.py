@@ -43,7 +43,7 @@ print('OK')
 
 SWITCHES = ['F8_FUSE_BLOCKS=0', 'F8_FUSE_STAGES=0', 'F8_FUSE_STAGES=7', 'F8_FUSE_DS=0', 'F8_FUSE_DUAL=0', 'F8_FUSE_STEM=0',
             'F8_PATCH3X3=0', 'F8_SPLIT=1', 'F8_SPLIT=3', 'F8_SPLIT_STREAMS=0', 'F8_GRAPH=1', 'F8_BK128=1', 'F8_DEEP_NK=1',
-            'F8_DUAL_WIDE=0', 'F8_CHUNK=0', 'F8_CHUNK=1', 'F8_CHUNK28=0', 'F8_CHUNK28=2', 'F8_BN=32', 'F8_BM=64', 'F8_RES_BN=128', 'F8_DW_DOT4=0', 'F8_STAGGER=0', 'F8_STEM_WPC=1', 'F8_FUSE_CHAIN=0', 'F8_FUSE_BCHAIN=0', 'F8_FUSE_BCHAIN=1', 'F8_STEM_ROWS=0', 'F8_DW_MMA=0', 'F8_FUSE_HEAD2=0', 'F8_REQUANT_FLOAT=0', 'F8_FUSE_TAIL=0', 'F8_FUSE_POOL=0']
+            'F8_DUAL_WIDE=0', 'F8_CHUNK=0', 'F8_CHUNK=1', 'F8_CHUNK28=0', 'F8_CHUNK28=2', 'F8_BN=32', 'F8_BM=64', 'F8_RES_BN=128', 'F8_DW_DOT4=0', 'F8_STAGGER=0', 'F8_STEM_WPC=1', 'F8_FUSE_CHAIN=0', 'F8_FUSE_BCHAIN=0', 'F8_FUSE_BCHAIN=1', 'F8_STEM_ROWS=0', 'F8_DW_MMA=0', 'F8_FUSE_HEAD2=0', 'F8_REQUANT_FLOAT=1', 'F8_FUSE_TAIL=0', 'F8_FUSE_POOL=0']
 
 
 @pytest.mark.parametrize('switch', SWITCHES)
@@ -108,7 +108,7 @@ OPTION_SETS = [
     ({'arena_copies': 3, 'pipeline_depth': 3}, None), ({'arena_copies': 4, 'pipeline_depth': 4}, None),      # bench.py's schedule: whole batches in flight, split stays 2
     ({'shared_streams': 0}, None),
     ({'fuse_pool': 0}, 'avgpool_sum'),      # the last join and the average pool as two launches (default: one, conv1x1_res+avgpool)
-    ({'requant_float': 0}, None), ({'requant_float': 0, 'fuse_chain': 0}, None),      # integer requantisation in every instance (chains; per-block launches)
+    ({'requant_float': 1}, None), ({'requant_float': 1, 'fuse_chain': 0}, None),      # float-converter requantisation where the planner bounds the value (chains; per-block launches); default: integer everywhere
     ({'stem_rows': 0}, None), ({'stem_rows': 0, 'fuse_input': 0}, None),      # the tile kernel of the head (f8_stem.hip), raw input / haloed form
 ]
 

@@ -90,16 +90,35 @@ def main():
             e['mfma_busy_frac'] = round(e.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / act, 5) if act else 0.0
             tb += e.get('SQ_VALU_MFMA_BUSY_CYCLES_sum', 0.0); ta += e.get('GRBM_GUI_ACTIVE_sum', 0.0) / 8.0 * 1024.0
             ti += e.get('SQ_INSTS_VALU_MFMA_I8_sum', 0.0)
-        passes = max((e['launches'] for k, e in mf.items() if 'input' in k), default=1)      # one input launch per forward pass
+        # forward passes the counter run covered = launches of a kernel that runs ONCE per forward: the classifier (every net has one), else the
+        # least-launched kernel.  (Round 4 looked for an `input` kernel: since the head reads the caller's buffer none is launched, `passes` fell to 1
+        # and the per-image figures below were 14x too large — VERDICT r4 #5a.)
+        once = [e['launches'] for k, e in mf.items() if 'fc_dense_kernel' in k or 'output_kernel' in k]
+        passes = min(once) if once else min((e['launches'] for e in mf.values()), default=1)
+        # algorithmic MFMA instructions per launch from the bench line of the same run (per_kernel: alg_ops per step / launches per step / 65536)
+        alg = {}
+        try:
+            bl = json.loads(open(os.path.join(src, 'bench_line.json')).read().strip())
+            for k, v in (bl.get('per_kernel') or {}).items():
+                if v.get('launches'):
+                    alg[k] = v['alg_ops'] / v['launches'] / 65536.0
+        except Exception:                                    # noqa: BLE001
+            pass
         with open(os.path.join(out, f'rocprof_{tag}_mfma.md'), 'w') as f:
             f.write(f'# rocprofv3 --pmc SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (own pass), same command ({tag}, {workload}, kernel sources {stamp[:16]})\n\n')
             f.write('Per-launch averages.  `busy` = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the share of the launch during which a '
                     'matrix pipe is busy, i.e. the achieved fraction of the INT8 MFMA peak (counter collection lengthens short kernels a little).\n\n')
             f.write(f'Whole net: busy {100 * tb / ta if ta else 0:.2f} % of the kernel time; {ti / passes / bs:.0f} v_mfma_i32_32x32x32_i8 per image '
                     f'(x 65536 op = {ti / passes / bs * 65536 / 1e9:.3f} Gop issued per image, halo recompute and tile padding included).\n\n')
-            f.write('| kernel | launches | MFMA_I8 insts | MFMA busy cycles | GUI_ACTIVE | busy |\n|---|---:|---:|---:|---:|---:|\n')
+            f.write('`issued / algorithmic` = MFMA instructions the counter saw per launch / (algorithmic ops of the launch / 65536, from the bench line of the same run): '
+                    'halo recompute, tile padding and K padding.\n\n')
+            f.write('| kernel | launches | MFMA_I8 insts | algorithmic MFMA | issued / algorithmic | MFMA busy cycles | GUI_ACTIVE | busy |\n|---|---:|---:|---:|---:|---:|---:|---:|\n')
             for k, e in sorted(mf.items(), key=lambda kv: -kv[1].get('GRBM_GUI_ACTIVE_sum', 0)):
-                f.write(f"| `{k}` | {e['launches']} | {e.get('SQ_INSTS_VALU_MFMA_I8', 0):.4g} | {e.get('SQ_VALU_MFMA_BUSY_CYCLES', 0):.4g} | "
+                a_ = alg.get(k)
+                e['alg_mfma_insts'] = None if not a_ else round(a_, 1)
+                e['issued_over_algorithmic'] = None if not a_ else round(e.get('SQ_INSTS_VALU_MFMA_I8', 0) / a_, 4)
+                f.write(f"| `{k}` | {e['launches']} | {e.get('SQ_INSTS_VALU_MFMA_I8', 0):.4g} | {'-' if not a_ else format(a_, '.4g')} | "
+                        f"{'-' if not a_ else format(e['issued_over_algorithmic'], '.3f')} | {e.get('SQ_VALU_MFMA_BUSY_CYCLES', 0):.4g} | "
                         f"{e.get('GRBM_GUI_ACTIVE', 0):.4g} | {100 * e['mfma_busy_frac']:.2f} % |\n")
         if True:                                             # one stamped file per workload (bench.py picks the one of its --arch / --bs)
             json.dump({'csrc_sha256': stamp, 'workload': workload, 'tag': tag, 'whole_net_mfma_busy_frac': round(tb / ta, 5) if ta else None,
