@@ -121,6 +121,9 @@ chain_kernel(const ChainArgs a) {
 #ifndef F8_CH_EARLY
 #define F8_CH_EARLY 1
 #endif
+#ifndef F8_CH_BREG
+#define F8_CH_BREG 1              // channel tiles per wave whose body.4 bias is register-resident in P3 (weights-stationary instances)
+#endif
     constexpr bool EARLY = F8_CH_EARLY != 0 && T > 1 && !ROT;
     // SPLIT (round 4, late): a wave's pixel tiles are CONSECUTIVE (pg * NPW + j instead of pg + PG * j), so a wave touches the tile's first row or its
     // last row, never both, and walks the taps of body.2 in the order that needs ITS halo row last: centre, bottom, top for the waves of the first
@@ -372,8 +375,13 @@ chain_kernel(const ChainArgs a) {
         // One block of the chain.  The stage-opening block is PEELED off the block loop below: inside the loop the stream registers are
         // loop-carried, i.e. allocated (though dead) throughout the opening block's P1 / P2 on top of its own live set — round 3's
         // opening-block instance spilled 144 bytes per lane that way (179 MB of scratch write-back per launch at the counters).
-        auto block = [&](const int b, auto dsc) {
+        // LASTC (round 5): 0 = not the chain's last block, 1 = the last block, 2 = decided at run time (the peeled first block).  As a run-time
+        // flag `last` put three branches, two exec-mask updates and three SGPR reloads (v_readlane of spilled scalars) around EVERY (pixel tile,
+        // channel tile) unit of P3 and kept the stage-output store code inside every block's instruction stream; P3 is bound by the number of
+        // instructions a wave issues (one per ~4.7 cycles at two waves per SIMD: DESIGN 4.1), so the identity blocks are now two straight-line copies.
+        auto block = [&](const int b, auto dsc, auto lastc) {
             {
+                constexpr int LASTC = decltype(lastc)::value;
                 constexpr bool TAILB = decltype(dsc)::value == 2;   // 0: identity block, 1: stage-opening block (same resolution), 2: only the join of one (TAIL)
                 if constexpr (!TAILB) ++seq;
                 int bnext[NBI];                                 // BROT: the next block's biases travel during P1 / P2 and land in the other slot before P3
@@ -385,7 +393,7 @@ chain_kernel(const ChainArgs a) {
                 constexpr int NK1B = DSB ? KS : NK1;
                 constexpr bool ROT1 = ROT && !DSB;
                 // the block's scalars, read once (FAST: formats are unsigned with a right shift, ReLUs present, the stream unshifted)
-                const bool last = b + 1 == a.nblk;
+                const bool last = LASTC == 2 ? (b + 1 == a.nblk) : (LASTC == 1);
                 const ChainBlk& BN = a.blk[last ? b : b + 1];
                 const int8_t* const pw0 = B.w0; const int8_t* const pw2 = B.w2; const int8_t* const pw4 = B.w4; const int8_t* const pwsc = B.wsc;
                 const int8_t* const pw0n = BN.w0;
@@ -747,6 +755,16 @@ chain_kernel(const ChainArgs a) {
                     } else if constexpr (WSTAT) {
                         // one pixel tile at a time; the wave's weights (CTW x KT fragments) stay in registers; B fragments one step ahead
                         constexpr int NST = NPT * CTW * KT;
+                        // BREG (round 5): body.4's bias of the wave's first BREG channel tiles stays in 16 registers each for the whole phase and is the C operand
+                        // of the unit's first body.4 MFMA (v_mfma D, A, B, C with C != D: no copy) — instead of four ds_read_b128 into the accumulator in
+                        // front of EVERY (pixel tile, channel tile) unit, whose latency the unit's MFMAs and all its vector work sat behind
+                        // (tools/ubench/ubench_p3.hip: 7.2 k -> 6.5 k cycles per phase at 56x56; profiles/ubench_p3_r05.txt)
+                        constexpr int BREG = F8_CH_BREG < CTW ? F8_CH_BREG : CTW;
+                        v16i breg[BREG > 0 ? BREG : 1];
+                        if constexpr (BREG > 0) {
+#pragma unroll
+                            for (int i = 0; i < BREG; ++i) bias_init(breg[i], wave * CTW + i);
+                        }
                         auto rd = [&](v4i& xf, auto gc) {
                             constexpr int G = decltype(gc)::value, PT = G / (CTW * KT), KI = G % KT;
                             if constexpr (KI >= K0) xf = *(const v4i*)(mid2 + mlane + PT * 32 * MS + (KI - K0) * 32);
@@ -759,7 +777,7 @@ chain_kernel(const ChainArgs a) {
                             constexpr int G = decltype(gc)::value, PT = G / (CTW * KT), I = (G / KT) % CTW, KI = G % KT;
                             const int ct = wave * CTW + I;
                             if constexpr (KI == 0) {
-                                bias_init(acc, ct);
+                                if constexpr (I >= BREG) bias_init(acc, ct);
                                 if constexpr (DSB) {    // the shortcut product accumulates straight into the stream registers (they are born here)
 #pragma unroll
                                     for (int g = 0; g < 4; ++g) {
@@ -773,7 +791,8 @@ chain_kernel(const ChainArgs a) {
                             v4i& nxt = (G & 1) ? xfa : xfb;
                             if constexpr (G + 1 < NST) rd(nxt, std::integral_constant<int, G + 1>{});
                             asm volatile("" : "+v"(cur));
-                            if constexpr (KI >= K0) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wst[I * KT + KI], cur, acc, 0, 0, 0);
+                            if constexpr (KI == K0 && I < BREG) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wst[I * KT + KI], cur, breg[I], 0, 0, 0);
+                            else if constexpr (KI >= K0) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wst[I * KT + KI], cur, acc, 0, 0, 0);
                             else res[PT][I] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wst[I * KT + KI], cur, res[PT][I], 0, 0, 0);
                             if constexpr (KI == KT - 1) {
                                 if constexpr (PT == NPT - 1 && I == CTW - 1) {   // the block's last weight use: the next block's body.0 starts to travel
@@ -817,9 +836,18 @@ chain_kernel(const ChainArgs a) {
                 __syncthreads();                                // x8 is complete (the next block's P1 reads it); mid2 may be rewritten
             }
         };
-        if constexpr (TAIL) block(0, std::integral_constant<int, 2>{});
-        else if constexpr (DS0) block(0, std::integral_constant<int, 1>{});
-        for (int b = DS0 ? 1 : 0; b < a.nblk; ++b) block(b, std::integral_constant<int, 0>{});
+#ifndef F8_CH_PEEL_LAST
+#define F8_CH_PEEL_LAST 0         // measured (round 5, same box): fewer instructions per unit of P3, 3 % SLOWER on the 56x56 launch (244 vs 236 us): the launch
+#endif                            // grows from 41 to 52 KB of code, and P3 is bound by vector THROUGHPUT, not by what a wave issues beside it
+        if constexpr (TAIL) block(0, std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+        else if constexpr (DS0) block(0, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+        if constexpr (F8_CH_PEEL_LAST) {
+            const int b0 = DS0 ? 1 : 0;
+            for (int b = b0; b + 1 < a.nblk; ++b) block(b, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            if (a.nblk > b0) block(a.nblk - 1, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        } else {
+            for (int b = DS0 ? 1 : 0; b < a.nblk; ++b) block(b, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+        }
 
         if (F8_CH_PREFETCH) in_issue(n + a.NG < a.N ? n + a.NG : n, n + a.NG < a.N);   // the next image's input tile: ahead of the output stores in the memory queue
         // ---- the int8 copy of the stage output: LDS rows -> whole NHWC rows in HBM
