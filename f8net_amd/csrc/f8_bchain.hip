@@ -560,6 +560,15 @@ static hipError_t launch_bchain_t(const BChainArgs& a, hipStream_t s) {
 #ifndef F8_BCH_S2
 #define F8_BCH_S2 2, (F8_BCH_NW == 16 ? 2 : 3)
 #endif
+// rows per tile of the three instances; the (NB, NBUF) pairs as VALUES (the macros may hold expressions)
+constexpr int bchain_rows(int C) { return C == 64 ? 8 : 7; }
+template <int NB, int NBUF> struct BChPair { static constexpr int nb = NB, nbuf = NBUF; };
+// The device symbol launch_bchain starts, as rocprofv3 prints it: built from the same tables the launcher below instantiates with (see chain_kernel_name)
+int bchain_kernel_name(char* buf, size_t cap, int C, int H, int W, bool ds, int fast) {
+    const int nb = C == 64 ? BChPair<F8_BCH_S0>::nb : (C == 128 ? BChPair<F8_BCH_S1>::nb : BChPair<F8_BCH_S2>::nb);
+    const int nbuf = C == 64 ? BChPair<F8_BCH_S0>::nbuf : (C == 128 ? BChPair<F8_BCH_S1>::nbuf : BChPair<F8_BCH_S2>::nbuf);
+    return snprintf(buf, cap, "f8::bchain_kernel<%d, %d, %d, %d, %d, %d, %d, %s, %d>", C, W, H, bchain_rows(C), nb, nbuf, fast, ds ? "true" : "false", F8_BCH_NW);
+}
 hipError_t launch_bchain(const BChainArgs& a, int C, int H, int W, hipStream_t s) {
     if (a.nblk < 1 || a.nblk > kBChainMaxBlocks) return hipErrorInvalidValue;
     const int fast = bchain_fast(a);
@@ -567,9 +576,9 @@ hipError_t launch_bchain(const BChainArgs& a, int C, int H, int W, hipStream_t s
     if (ds ? !(a.x8sc && a.wsc && a.bsc && bchain_ds_supported(C, H, W)) : !a.xr) return hipErrorInvalidValue;
 #define F8_BCH(...) (fast == 1 ? launch_bchain_t<__VA_ARGS__, 1, false>(a, s) : fast == 2 ? launch_bchain_t<__VA_ARGS__, 2, false>(a, s) : launch_bchain_t<__VA_ARGS__, 0, false>(a, s))
 #define F8_BCHD(...) (fast == 1 ? launch_bchain_t<__VA_ARGS__, 1, true>(a, s) : fast == 2 ? launch_bchain_t<__VA_ARGS__, 2, true>(a, s) : launch_bchain_t<__VA_ARGS__, 0, true>(a, s))
-    if (C == 64 && H == 56 && W == 56) return F8_BCH(64, 56, 56, 8, F8_BCH_S0);
-    if (C == 128 && H == 28 && W == 28) return ds ? F8_BCHD(128, 28, 28, 7, F8_BCH_S1) : F8_BCH(128, 28, 28, 7, F8_BCH_S1);
-    if (C == 256 && H == 14 && W == 14) return ds ? F8_BCHD(256, 14, 14, 7, F8_BCH_S2) : F8_BCH(256, 14, 14, 7, F8_BCH_S2);
+    if (C == 64 && H == 56 && W == 56) return F8_BCH(64, 56, 56, bchain_rows(64), F8_BCH_S0);
+    if (C == 128 && H == 28 && W == 28) return ds ? F8_BCHD(128, 28, 28, bchain_rows(128), F8_BCH_S1) : F8_BCH(128, 28, 28, bchain_rows(128), F8_BCH_S1);
+    if (C == 256 && H == 14 && W == 14) return ds ? F8_BCHD(256, 14, 14, bchain_rows(256), F8_BCH_S2) : F8_BCH(256, 14, 14, bchain_rows(256), F8_BCH_S2);
 #undef F8_BCH
 #undef F8_BCHD
     return hipErrorInvalidValue;

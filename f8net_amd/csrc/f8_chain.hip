@@ -121,6 +121,9 @@ chain_kernel(const ChainArgs a) {
 #ifndef F8_CH_EARLY
 #define F8_CH_EARLY 1
 #endif
+#ifndef F8_CH_PRIO
+#define F8_CH_PRIO 0              // 1: the second-dispatched half of the workgroup (waves 4-7: the arbitration losers on every SIMD) runs the second half of P3 at priority 1
+#endif
 #ifndef F8_CH_BREG
 #define F8_CH_BREG 1              // channel tiles per wave whose body.4 bias is register-resident in P3 (weights-stationary instances)
 #endif
@@ -776,6 +779,7 @@ chain_kernel(const ChainArgs a) {
                         static_for<NST>([&](auto gc) {
                             constexpr int G = decltype(gc)::value, PT = G / (CTW * KT), I = (G / KT) % CTW, KI = G % KT;
                             const int ct = wave * CTW + I;
+                            if constexpr (F8_CH_PRIO != 0 && G == (NPT / 2) * CTW * KT) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
                             if constexpr (KI == 0) {
                                 if constexpr (I >= BREG) bias_init(acc, ct);
                                 if constexpr (DSB) {    // the shortcut product accumulates straight into the stream registers (they are born here)
@@ -816,6 +820,7 @@ chain_kernel(const ChainArgs a) {
                         static_for<NST>([&](auto gc) {
                             constexpr int G = decltype(gc)::value, I = G / KK, KI = G % KK, Qi = G / NB, S = G % NB;
                             const int ct = wave * CTW + I;
+                            if constexpr (F8_CH_PRIO != 0 && G == (CTW / 2) * KK) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
                             if constexpr (S == 0 && Qi + NBUF - 1 < NQ) w3_load(wbuf[(Qi + NBUF - 1) % NBUF], Qi + NBUF - 1, wl16);
                             if constexpr (KI == 0) { bias_init(acc[0], ct); acc[1] = acc[0]; }
                             v4i (&cur)[2] = (G & 1) ? xfb : xfa;
@@ -832,6 +837,7 @@ chain_kernel(const ChainArgs a) {
                         });
                     }
                 }
+                if constexpr (F8_CH_PRIO != 0) __builtin_amdgcn_s_setprio(0);
                 F8_CT(4);
                 __syncthreads();                                // x8 is complete (the next block's P1 reads it); mid2 may be rewritten
             }
@@ -978,6 +984,18 @@ int chain_fast(const ChainArgs& a) {
         f16 = f16 && a.q[0].n <= kRequantU8MaxShift;
     }
     return (a.rq_int || !a.acc_ok || !a.stream_ok || !f16) ? 2 : 1;
+}
+
+// The device symbol launch_chain starts for this geometry, as rocprofv3 prints it — built HERE, from the (NB, NBUF) macros and chain_shape the launcher
+// below instantiates with, so that the planner's Step::kernel (bench.py joins its live timings with the counter files on that string) cannot drift
+// from the instance that runs (round 4 kept a second copy of these constants in f8_net.cpp).  fast: 0 / 1 / 2 as chain_fast returns it.
+#define F8_STR2(...) #__VA_ARGS__
+#define F8_STR(...) F8_STR2(__VA_ARGS__)
+int chain_kernel_name(char* buf, size_t cap, int C, int MID, int H, int W, int cin0, bool tail, int fast) {
+    int R = 4, wg = 1;
+    chain_shape(C, MID, H, W, cin0, tail, &R, &wg);
+    const char* nb = MID == 64 ? F8_STR(F8_CH_S0) : (MID == 128 ? F8_STR(F8_CH_S1) : F8_STR(F8_CH_S2));
+    return snprintf(buf, cap, "f8::chain_kernel<%d, %d, %d, %d, %d, %d, %s, %d, false, %s>", C, MID, W, H, R, cin0, nb, fast, tail ? "true" : "false");
 }
 
 hipError_t launch_chain(const ChainArgs& a, int C, int MID, int H, int W, int cin0, hipStream_t s) {

@@ -819,16 +819,36 @@ static void label_conv_step(f8_net* net, Step& st, const Node& nd) {
     st.kernel = buf;
 }
 
-int f8_net_finalize(f8_net* net, int max_batch) {
-    if (!net) return fail(F8_ERR_INVALID, "f8_net_finalize: null net");
-    if (net->finalized) return fail(F8_ERR_STATE, "f8_net_finalize: already finalized");
-    if (max_batch < 1) return fail(F8_ERR_INVALID, "f8_net_finalize: max_batch < 1");
-    if (net->out_t < 0) return fail(F8_ERR_STATE, "f8_net_finalize: no output marked");
-    if (net->nodes.empty() || net->nodes[0].kind != N_INPUT) return fail(F8_ERR_STATE, "f8_net_finalize: first node must be the input");
+// ================================================================================================================================
+// The planner: f8_net_finalize runs these passes in order.  Passes 1 .. 1i only MARK nodes (which launch hosts which conv);
+// pass 2 decides the forms each tensor needs in HBM, pass 3 emits the launches, pass 4 lays the arena out.  Round 5: one function per pass
+// (round 4: one 1100-line function).
+// ================================================================================================================================
+
+// position of a block (by its host conv) inside its stage chain / BasicBlock chain, -1: not chained
+static int chain_pos(const f8_net* net, int host) {
+    const auto& ND = net->nodes;
+    if (host < 0 || ND[host].chain_into < 0) return -1;
+    const std::vector<int>& ch = ND[ND[host].chain_into].chain;
+    for (size_t k = 0; k < ch.size(); ++k) if (ch[k] == host) return (int)k;
+    return -1;
+}
+static int bchain_pos(const f8_net* net, int host) {
+    const auto& ND = net->nodes;
+    if (host < 0 || ND[host].bchain_into < 0) return -1;
+    const std::vector<int>& ch = ND[ND[host].bchain_into].bchain;
+    for (size_t k = 0; k < ch.size(); ++k) if (ch[k] == host) return (int)k;
+    return -1;
+}
+
+// pass 1
+static void plan_residual_joins(f8_net* net, int max_batch) {
     auto& T = net->tensors;
     auto& ND = net->nodes;
     const int nn = (int)ND.size();
-
+    const Options& opt = net->opt;
+    const int fuse_blocks = opt.fuse_blocks;
+    (void)T; (void)nn; (void)opt; (void)fuse_blocks; (void)max_batch;
     // ---- 1. residual fusion: an add rides in the epilogue of the LATER of its two producers when
     //         that producer is an MFMA conv nobody else reads and the other operand is already there.
     for (int i = 0; i < nn; ++i) {
@@ -845,10 +865,18 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         }
     }
 
-    // ---- 1b. whole-block fusion: 1x1(ReLU) -> 3x3 pad 1 (ReLU) -> 1x1 + residual with the block input,
-    //          all stride 1, intermediates read by nobody else  ->  one launch (f8_fused.hip)
+}
+
+// pass 1b
+static void plan_bottleneck_blocks(f8_net* net, int max_batch) {
+    auto& T = net->tensors;
+    auto& ND = net->nodes;
+    const int nn = (int)ND.size();
     const Options& opt = net->opt;
     const int fuse_blocks = opt.fuse_blocks;
+    (void)T; (void)nn; (void)opt; (void)fuse_blocks; (void)max_batch;
+    // ---- 1b. whole-block fusion: 1x1(ReLU) -> 3x3 pad 1 (ReLU) -> 1x1 + residual with the block input,
+    //          all stride 1, intermediates read by nobody else  ->  one launch (f8_fused.hip)
     for (int i = 0; fuse_blocks && i < nn; ++i) {
         Node& c = ND[i];
         if (c.kind != N_CONV || c.fused_add < 0 || c.cd.groups != 1 || c.cd.kernel != 1 || c.cd.stride != 1 || c.cd.pad != 0 || c.cd.relu) continue;
@@ -879,10 +907,19 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         c.fb_a = ta.prod; c.fb_b = tb.prod; c.fb_R = R;
     }
 
+}
+
+// pass 1c
+static void plan_dual_gemm_joins(f8_net* net, int max_batch) {
+    auto& T = net->tensors;
+    auto& ND = net->nodes;
+    const int nn = (int)ND.size();
+    const Options& opt = net->opt;
+    const int fuse_blocks = opt.fuse_blocks;
+    (void)T; (void)nn; (void)opt; (void)fuse_blocks; (void)max_batch;
     // ---- 1c. downsample join: the add's two operands are both 1x1 / pad 0 convs (body.4 and the shortcut) and the
     //          earlier one feeds nothing else  ->  one dual-GEMM launch, its int32 result never touches HBM
-    const int fuse_dual = opt.fuse_dual;
-    for (int i = 0; fuse_dual && i < nn; ++i) {
+    for (int i = 0; opt.fuse_dual && i < nn; ++i) {
         Node& h = ND[i];
         if (h.kind != N_CONV || h.fused_add < 0 || h.fb_a >= 0 || h.cd.groups != 1 || h.cd.kernel != 1 || h.cd.pad != 0) continue;
         if (h.cd.cin % 64 != 0 || round_up(h.cd.cout, 32) <= 32) continue;          // kernel instances: BK = 64, BN = 64
@@ -896,6 +933,16 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         h.dual = T[other].prod; g.dual_host = i;
     }
 
+}
+
+// pass 1d
+static void plan_stage_opening_blocks(f8_net* net, int max_batch) {
+    auto& T = net->tensors;
+    auto& ND = net->nodes;
+    const int nn = (int)ND.size();
+    const Options& opt = net->opt;
+    const int fuse_blocks = opt.fuse_blocks;
+    (void)T; (void)nn; (void)opt; (void)fuse_blocks; (void)max_batch;
     // ---- 1d. stage-opening bottleneck at unchanged resolution: body.0 -> body.2 -> [body.4 + shortcut] in ONE launch
     for (int i = 0; fuse_blocks && i < nn; ++i) {
         Node& h = ND[i];
@@ -926,6 +973,16 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         h.fbd_a = ta.prod; h.fbd_b = tb.prod; h.fb_R = R; h.fbd_s2 = bs == 2;
     }
 
+}
+
+// pass 1f
+static void plan_stage_chains(f8_net* net, int max_batch) {
+    auto& T = net->tensors;
+    auto& ND = net->nodes;
+    const int nn = (int)ND.size();
+    const Options& opt = net->opt;
+    const int fuse_blocks = opt.fuse_blocks;
+    (void)T; (void)nn; (void)opt; (void)fuse_blocks; (void)max_batch;
     // ---- 1f. stage chains: consecutive bottleneck blocks at one resolution whose block-to-block tensors are read by nobody else
     //          -> ONE launch for all of them, the int32 residual stream stays in registers (f8_chain.hip).  A chain may start with
     //          the stage-opening block at unchanged resolution (1d) and continues through identity blocks (1b).
@@ -1013,14 +1070,16 @@ int f8_net_finalize(f8_net* net, int max_batch) {
             }
         }
     }
-    // position of a block (by its host conv) inside its chain, -1: not chained
-    auto chain_pos = [&](int host) -> int {
-        if (host < 0 || ND[host].chain_into < 0) return -1;
-        const std::vector<int>& ch = ND[ND[host].chain_into].chain;
-        for (size_t k = 0; k < ch.size(); ++k) if (ch[k] == host) return (int)k;
-        return -1;
-    };
+}
 
+// pass 1g
+static void plan_basic_block_chains(f8_net* net, int max_batch) {
+    auto& T = net->tensors;
+    auto& ND = net->nodes;
+    const int nn = (int)ND.size();
+    const Options& opt = net->opt;
+    const int fuse_blocks = opt.fuse_blocks;
+    (void)T; (void)nn; (void)opt; (void)fuse_blocks; (void)max_batch;
     // ---- 1g. BasicBlock identity blocks (3x3 ReLU -> 3x3 + residual with the block input, all stride 1) -> f8_bchain.hip: ONE launch for
     //          the consecutive ones of a stage, the int32 stream in registers (a single block is a chain of one: both convs in one
     //          launch, `mid` only in LDS)
@@ -1106,13 +1165,16 @@ int f8_net_finalize(f8_net* net, int max_batch) {
             ND[lastn].bchain = hosts;
         }
     }
-    auto bchain_pos = [&](int host) -> int {
-        if (host < 0 || ND[host].bchain_into < 0) return -1;
-        const std::vector<int>& ch = ND[ND[host].bchain_into].bchain;
-        for (size_t k = 0; k < ch.size(); ++k) if (ch[k] == host) return (int)k;
-        return -1;
-    };
+}
 
+// pass 1e
+static void plan_inverted_residuals(f8_net* net, int max_batch) {
+    auto& T = net->tensors;
+    auto& ND = net->nodes;
+    const int nn = (int)ND.size();
+    const Options& opt = net->opt;
+    const int fuse_blocks = opt.fuse_blocks;
+    (void)T; (void)nn; (void)opt; (void)fuse_blocks; (void)max_batch;
     // ---- 1e. MobileNet-V2 inverted residual: 1x1 expand (ReLU) -> depthwise 3x3 (ReLU) -> 1x1 project [+ residual with the
     //          block input], intermediates read by nobody else  ->  one launch (f8_ir.hip), the expanded tensors stay in LDS
     for (int i = 0; opt.fuse_ir && i < nn; ++i) {
@@ -1152,6 +1214,16 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         c.ir_a = ta.prod; c.ir_b = tb.prod; c.ir_R = R; c.ir_G = G;
     }
 
+}
+
+// pass 1h
+static void plan_mobilenet_v2_head(f8_net* net, int max_batch) {
+    auto& T = net->tensors;
+    auto& ND = net->nodes;
+    const int nn = (int)ND.size();
+    const Options& opt = net->opt;
+    const int fuse_blocks = opt.fuse_blocks;
+    (void)T; (void)nn; (void)opt; (void)fuse_blocks; (void)max_batch;
     // ---- 1h. MobileNet-V2 head: network input -> 3x3 / 2 conv (cin <= 4 -> 32, ReLU) -> depthwise 3x3 (ReLU) -> 1x1 (32 -> <= 32), each read
     //          by nobody else  ->  ONE row-walking launch (f8_stem.hip, stem_rows_kernel<KIND, true>): the three convs hand their rows to
     //          each other in registers, the launch reads the caller's buffer itself
@@ -1183,6 +1255,16 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         c.h2_head = ta.prod; c.h2_dw = tb.prod;
     }
 
+}
+
+// pass 1i
+static void plan_last_conv_and_pool(f8_net* net, int max_batch) {
+    auto& T = net->tensors;
+    auto& ND = net->nodes;
+    const int nn = (int)ND.size();
+    const Options& opt = net->opt;
+    const int fuse_blocks = opt.fuse_blocks;
+    (void)T; (void)nn; (void)opt; (void)fuse_blocks; (void)max_batch;
     // ---- 1i. the network's last 1x1 conv (hosting its residual join, or a plain conv + ReLU) and the average pool behind it: ONE launch that sums the map's
     //          pixels in the epilogue (f8_pool.hip); the conv's int32 result — read by nobody but the pool — never exists
     for (int i = 0; opt.fuse_pool && i < nn; ++i) {
@@ -1202,6 +1284,16 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         c.pool = i; p.pool_host = ci;
     }
 
+}
+
+// pass 2
+static void plan_tensor_forms(f8_net* net, int max_batch) {
+    auto& T = net->tensors;
+    auto& ND = net->nodes;
+    const int nn = (int)ND.size();
+    const Options& opt = net->opt;
+    const int fuse_blocks = opt.fuse_blocks;
+    (void)T; (void)nn; (void)opt; (void)fuse_blocks; (void)max_batch;
     // ---- 2. which forms does each tensor need?  (reverse order: consumers before producers)
     {
         Tensor& O = T[net->out_t];
@@ -1227,7 +1319,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 if (nd.absorbed_by >= 0 && ND[nd.absorbed_by].bds_b == i) break;   // second 3x3 of the opening block of a bchain launch: `mid` lives in LDS
                                                                  // (its 3x3 / 2 and its shortcut conv each ask for their int8 form of the block input below)
                 if (nd.bb_a >= 0) {                          // second conv of a chained BasicBlock: its source (`mid`) lives in LDS
-                    if (bchain_pos(i) == 0) {
+                    if (bchain_pos(net, i) == 0) {
                         const Node& ad = ND[nd.fused_add];
                         add_form(T[(ad.a == nd.out) ? ad.b : ad.a], FORM_I32, 0, 0);      // the stage's int32 stream: the chain's only input form
                     }
@@ -1237,7 +1329,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 {   // stage chain (f8_chain.hip): the tensors between its blocks exist in no form at all; an identity first block
                     // reads only the int32 form of the stage input (its int8 copy is made in the launch)
                     const int host = nd.absorbed_by >= 0 && ND[nd.absorbed_by].fb_a == i ? nd.absorbed_by : -1;   // nd = body.0 of an identity block
-                    const int pos = chain_pos(host);
+                    const int pos = chain_pos(net, host);
                     if (pos > 0) break;
                     if (pos == 0) { add_form(s, FORM_I32, 0, 0); break; }
                 }
@@ -1245,7 +1337,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                     (nd.absorbed_by >= 0 && ND[nd.absorbed_by].ir_b == i)) {
                     // source lives in LDS inside the fused launch: no HBM form.  (The block's first conv
                     // still reads the block input from HBM and falls through to the generic case.)
-                    if (nd.fused_add >= 0 && chain_pos(i) <= 0) {
+                    if (nd.fused_add >= 0 && chain_pos(net, i) <= 0) {
                         const Node& ad = ND[nd.fused_add];
                         const int other = (ad.a == nd.out) ? ad.b : ad.a;
                         add_form(T[other], FORM_I32, 0, 0);
@@ -1302,14 +1394,18 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         }
     }
 
+}
+
+// pass 3
+static int emit_steps(f8_net* net, int max_batch) {
+    auto& T = net->tensors;
+    auto& ND = net->nodes;
+    const int nn = (int)ND.size();
+    const Options& opt = net->opt;
+    const int fuse_blocks = opt.fuse_blocks;
+    (void)T; (void)nn; (void)opt; (void)fuse_blocks; (void)max_batch;
     // ---- 3. emit steps in node order
     net->steps.clear();
-    auto touch = [&](int t, int f, int step) {
-        if (t < 0 || f < 0) return;
-        Form& F = T[t].forms[f];
-        if (F.first < 0) F.first = step;
-        F.last = std::max(F.last, step);
-    };
     auto emit_requants = [&](int t, const std::vector<int>& extra) {
         for (int f : extra) {
             Step st; st.kind = S_REQUANT; st.node = T[t].prod;
@@ -1430,7 +1526,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                         const Node& c1 = ND[hk.bds_a >= 0 ? hk.bds_a : hk.bb_a];
                         bounded = bounded && conv_acc_bounded(c1) && stream_bounded(net, ND[hk.fused_add].out) && (k > 0 || hk.bds_a >= 0 || stream_bounded(net, c1.a));
                     }
-                    snprintf(kb, sizeof kb, "f8::bchain_kernel<%d, %d, %d, %d, 2, 3, %d, %s, 8>", o.C, o.W, o.H, o.C == 64 ? 8 : 7, (opt.requant_float && bounded) ? 1 : 2, ds ? "true" : "false");   // keep in sync with launch_bchain
+                    bchain_kernel_name(kb, sizeof kb, o.C, o.H, o.W, ds, (opt.requant_float && bounded) ? 1 : 2);   // the name comes from f8_bchain.hip, next to the launcher
                     st.kernel = kb;
                     break;
                 }
@@ -1489,7 +1585,7 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                         const Node& na = ND[hds ? hh.fbd_a : hh.fb_a]; const Node& nb = ND[hds ? hh.fbd_b : hh.fb_b];
                         bounded = bounded && conv_acc_bounded(na) && conv_acc_bounded(nb) && (k > 0 || hds || stream_bounded(net, na.a));
                     }
-                    snprintf(kb, sizeof kb, "f8::chain_kernel<%d, %d, %d, %d, %d, %d, %s, %d, false, %s>", C, MID, o.W, o.H, cR, tail ? hf.cd.cin : a0.cd.cin, MID == 256 ? "2, 4" : (MID == 64 ? "2, 2" : "2, 3"), (opt.requant_float && bounded) ? 1 : 2, tail ? "true" : "false");   // keep in sync with launch_chain (the FAST instance: real fraclen tables)
+                    chain_kernel_name(kb, sizeof kb, C, MID, o.H, o.W, tail ? hf.cd.cin : a0.cd.cin, tail, (opt.requant_float && bounded) ? 1 : 2);   // the name comes from f8_chain.hip, next to the launcher
                     st.kernel = kb;
                     break;
                 }
@@ -1828,7 +1924,24 @@ int f8_net_finalize(f8_net* net, int max_batch) {
                 }
             }
         }
+    return F8_OK;
+}
+
+// pass 4
+static int layout_arena(f8_net* net, int max_batch) {
+    auto& T = net->tensors;
+    auto& ND = net->nodes;
+    const int nn = (int)ND.size();
+    const Options& opt = net->opt;
+    const int fuse_blocks = opt.fuse_blocks;
+    (void)T; (void)nn; (void)opt; (void)fuse_blocks; (void)max_batch;
     // ---- 4. lifetimes and arena layout (first-fit over a free list; in-place residual update)
+    auto touch = [&](int t, int f, int step) {
+        if (t < 0 || f < 0) return;
+        Form& F = T[t].forms[f];
+        if (F.first < 0) F.first = step;
+        F.last = std::max(F.last, step);
+    };
     for (size_t si = 0; si < net->steps.size(); ++si) {
         Step& st = net->steps[si];
         touch(st.src_t, st.src_f, (int)si);
@@ -1934,6 +2047,28 @@ int f8_net_finalize(f8_net* net, int max_batch) {
         for (auto& F : t.forms)
             if (F.bytes_per_img * (size_t)max_batch >= (1ull << 31))
                 return fail(F8_ERR_UNSUPPORTED, "finalize: a tensor exceeds 2 GiB at max_batch %d (buffer addressing)", max_batch);
+    return F8_OK;
+}
+
+int f8_net_finalize(f8_net* net, int max_batch) {
+    if (!net) return fail(F8_ERR_INVALID, "f8_net_finalize: null net");
+    if (net->finalized) return fail(F8_ERR_STATE, "f8_net_finalize: already finalized");
+    if (max_batch < 1) return fail(F8_ERR_INVALID, "f8_net_finalize: max_batch < 1");
+    if (net->out_t < 0) return fail(F8_ERR_STATE, "f8_net_finalize: no output marked");
+    if (net->nodes.empty() || net->nodes[0].kind != N_INPUT) return fail(F8_ERR_STATE, "f8_net_finalize: first node must be the input");
+    plan_residual_joins(net, max_batch);            // 1:  a residual add rides in the epilogue of the later of its two producers
+    plan_bottleneck_blocks(net, max_batch);         // 1b: bottleneck identity blocks (one launch, or body.0 + body.2 on the 7x7 maps)
+    plan_dual_gemm_joins(net, max_batch);           // 1c: body.4 || shortcut of a stage-opening block as one dual GEMM
+    plan_stage_opening_blocks(net, max_batch);      // 1d: whole stage-opening blocks (same resolution / stride 2)
+    plan_stage_chains(net, max_batch);              // 1f: all consecutive bottleneck blocks of a stage in one launch
+    plan_basic_block_chains(net, max_batch);        // 1g: the same for BasicBlocks
+    plan_inverted_residuals(net, max_batch);        // 1e: MobileNet-V2 inverted residuals
+    plan_mobilenet_v2_head(net, max_batch);         // 1h: MobileNet-V2 head conv + depthwise + 1x1
+    plan_last_conv_and_pool(net, max_batch);        // 1i: the last 1x1 conv + the average pool
+    plan_tensor_forms(net, max_batch);              // 2:  which forms of each tensor exist in HBM
+    int rc = emit_steps(net, max_batch);            // 3:  the launches, packed weights, algorithmic bytes / ops
+    if (rc) return rc;
+    if ((rc = layout_arena(net, max_batch))) return rc;   // 4: lifetimes, first-fit arena
     net->max_batch = max_batch;
     net->finalized = true;
     return F8_OK;
