@@ -20,5 +20,12 @@ timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench_${TAG}_driverflag
 timeout 900 python bench.py --arch resnet18 --bs 128 --steps 200 --warmup 20 --per-layer > $OUT/bench_${TAG}_resnet18_bs128.json 2> $OUT/perlayer_${TAG}_resnet18_bs128.txt
 timeout 900 python bench.py --arch mobilenet_v2 --bs 128 --steps 200 --warmup 20 --per-layer > $OUT/bench_${TAG}_mobilenet_v2_bs128.json 2> $OUT/perlayer_${TAG}_mobilenet_v2_bs128.txt
 timeout 900 python bench.py --arch resnet50 --bs 256 --steps 200 --warmup 20 --per-layer > $OUT/bench_${TAG}_resnet50_bs256.json 2> $OUT/perlayer_${TAG}_resnet50_bs256.txt
+# round 5: what bounds the chain launches — the P3 microbenchmark (vector throughput; 8 / 12 / 16 waves; ablations) and the per-wave phase cycle counters
+# of a -DF8_TRACE build (tools/build_trace.sh) for the three ResNet-50 instances; rocprofv3 --att has no decoder library on this image (att_probe)
+if [ -x tools/ubench/ubench_p3.bin ]; then tools/ubench/ubench_p3.bin > $OUT/ubench_p3_$TAG.txt 2>&1; fi
+if [ -f f8net_amd/libf8net_trace.so ]; then
+  for k in 3 4 5; do F8NET_LIB=f8net_amd/libf8net_trace.so F8_TRACE_CHAIN=$k timeout 200 python tools/trace_run.py 2>&1 | grep -A12 "trace chain"; done > $OUT/chain_trace_$TAG.txt
+fi
+(cd /tmp && TMPDIR=/tmp timeout 120 rocprofv3 --att --kernel-trace -d /tmp/att_probe -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -3) > $OUT/att_probe_$TAG.log 2>&1
 rm -rf gpurun_out/prof_*
 ls -la $OUT
