@@ -26,7 +26,7 @@ timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES GRBM_
 # what the waves do when neither roof binds (round 4): SQ has 8 counter slots per pass; the SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* family counts quad-cycles
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o pmc -- $CMD > $OUT/pmc_sq.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_I8 GRBM_GUI_ACTIVE -d $OUT/pmc_sq2 -o pmc -- $CMD > $OUT/pmc_sq2.log 2>&1
-tail -1 $OUT/trace.log > $OUT/bench_line.json
+grep "^{\"metric\"" $OUT/trace.log | tail -1 > $OUT/bench_line.json      # (rocprofv3 prints after the program: the JSON line is not the last one)
 # summarise on the box and drop the databases (gpurun merges at most 64 MiB back)
 python $REPO/tools/summarize_prof.py $OUT $TAG --out $OUT/summary ${MAIN:+--main} > $OUT/summarize.log 2>&1 || tail -5 $OUT/summarize.log
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma $OUT/pmc_sq $OUT/pmc_sq2
