@@ -167,7 +167,11 @@ size_t f8_net_output_elems(const f8_net* net);
 int f8_net_upload(f8_net* net);
 
 /* Runs the net on `N` images (1 <= N <= max_batch).  input_dev: int32 NCHW [N,C,H,W];
- * output_dev: float32 or int32 [N, output_elems].  Asynchronous on `stream`. */
+ * output_dev: float32 or int32 [N, output_elems].  Asynchronous on `stream`.
+ * F8_ERR_HIP without issuing anything when a stage-chain launch of an EARLIER run of this handle gave up a halo wait (see f8_net_check): the
+ * failing launch also writes its code to a host-visible word that this call reads without synchronising; runs are refused until f8_net_check
+ * has collected the error (round 5).  The logits of the failed run itself are poisoned (NaN / INT32_MIN); runs issued before the failure
+ * became visible are unaffected — the error word carries the failed run's tag and only that run's waits / outputs react to it. */
 int f8_net_run(f8_net* net, const int32_t* input_dev, void* output_dev, int N, void* stream);
 
 /* Same net, fed with the fp32 images forward_loss receives (fix_train.py:676-692): the input quantisation
@@ -217,10 +221,11 @@ int f8_net_set_input_ready(f8_net* net, void* event);
 
 /* Blocks until the device is idle and reports failures that happened INSIDE kernels of earlier runs of this handle: the
  * stage-chain launches (option fuse_chain) exchange halo rows between workgroups and bound every wait (chain_timeout_ms); a
- * workgroup whose neighbour never arrives sets a sticky error word, the launch runs on without waiting, and the run's outputs are then
- * invalid — they are POISONED where they leave the library (the classifier / output kernel writes NaN, or INT32_MIN for int32 outputs,
- * while the word is set), so a caller that never calls this function cannot mistake them for results.  F8_OK, or
- * F8_ERR_HIP with the code in f8_last_error (the word is cleared).  It also reports (F8_ERR_INVALID) an int32 network input that held
+ * workgroup whose neighbour never arrives stores (run tag << 8 | code) in an error word, the launch runs on without waiting, and THAT run's
+ * outputs are invalid — they are POISONED where they leave the library (the classifier / output kernel writes NaN, or INT32_MIN for int32
+ * outputs, when the word carries its run's tag), so a caller that never calls this function cannot mistake them for results; later runs are
+ * refused by f8_net_run until this function has been called.  F8_OK, or F8_ERR_HIP with the code in f8_last_error — the words of EVERY
+ * arena copy are then cleared and the launches' ticket / flag words re-armed from the host (the device is idle).  It also reports (F8_ERR_INVALID) an int32 network input that held
  * values outside the head's 8-bit format in a run since the last check: f8_net_run NARROWS such an input to 8 bits where the reference
  * would feed the full int32 to the head conv (fix_train.py:689 only asserts >= 0), so out-of-format values cannot be honoured; the range
  * is checked inside the input / stem kernel (option check_input_range, default 1).  Never needed for correctness of a healthy run. */
