@@ -412,8 +412,8 @@ def main():
             if lk:
                 limiter = {'limiter': lk.get('limiter'),
                            'evidence': 'rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT '
-                                       '(own pass; profiles/rocprof_*_valu.md): a pipe busy >= half of the launch names the limiter, else latency (waves parked at s_waitcnt / s_barrier) or issue-stall',
-                           **{k: lk.get(k) for k in ('wave_parked_frac', 'wave_issue_stall_frac', 'wave_issuing_frac', 'wave_issuing_valu_frac', 'valu_pipe_busy_frac', 'lds_busy_frac',
+                                       '(own pass; profiles/rocprof_*_valu.md): a pipe busy >= half of the launch names the limiter; "a+b in turn" when matrix pipe and vector issue together cover half of it in alternating phases; else latency (waves parked at s_waitcnt / s_barrier) or issue-stall',
+                           **{k: lk.get(k) for k in ('wave_parked_frac', 'wave_issue_stall_frac', 'wave_issuing_frac', 'wave_issuing_valu_frac', 'valu_pipe_busy_frac', 'valu_issue_busy_frac', 'lds_busy_frac',
                                                      'mfma_busy_frac', 'hbm_frac_measured_bytes', 'lds_bank_conflict_per_lds_active')}}
         elif why:
             notes.append(why)

@@ -161,14 +161,25 @@ def main():
             hbm_frac = (hbm / (dur * 1e-6) / 8.0e12) if (hbm and dur) else None
             # VALU pipe busy: wave64 VALU instructions x 2 cycles (32 lanes per SIMD and cycle) over the SIMD-cycles of the launch
             valu_busy = (e.get('SQ_INSTS_VALU', 0.0) * 2.0 / act_simd) if act_simd else None
+            # round 5: the share of the launch's SIMD-cycles during which a wave of the SIMD is ISSUING a vector instruction, straight from the counter
+            # (SQ_ACTIVE_INST_VALU: quad-cycles summed over waves) — no assumption about what an instruction costs.  In the chain launches a wave64 integer
+            # instruction occupies its SIMD for ~4.4 cycles, not 2 (profiles/chain_limiter_r05.md), so the "VALU pipe" column above reads low by that factor.
+            valu_issue = (e.get('SQ_ACTIVE_INST_VALU', 0.0) * 4.0 / act_simd) if act_simd else None
             lds_busy = (e.get('SQ_LDS_IDX_ACTIVE', 0.0) / (e.get('GRBM_GUI_ACTIVE_2', 0.0) / 8.0 * 256.0)) if e.get('GRBM_GUI_ACTIVE_2') else None
-            cand = {'hbm': hbm_frac or 0.0, 'mfma': mfma_busy or 0.0, 'valu': valu_busy or 0.0, 'lds': lds_busy or 0.0}
+            cand = {'hbm': hbm_frac or 0.0, 'mfma': mfma_busy or 0.0, 'valu': max(valu_busy or 0.0, valu_issue or 0.0), 'lds': lds_busy or 0.0}
             top = max(cand, key=cand.get)
-            # a pipe that is busy more than half of the launch names the limiter; otherwise the waves are waiting: parked at s_waitcnt / s_barrier
-            # (memory / exchange latency, barrier skew) or stalled at issue (dependent instructions, a busy pipe)
-            limiter = top if cand[top] >= 0.5 else ('latency' if parked >= stall else 'issue-stall')
+            # a pipe that is busy more than half of the launch names the limiter; a launch whose phases saturate the matrix pipe and the vector issue IN TURN
+            # (each is busy while the other idles: the chain launches) is named by both when together they cover half of it; otherwise the waves are
+            # waiting: parked at s_waitcnt / s_barrier (memory / exchange latency, barrier skew) or stalled at issue (dependent instructions, a busy pipe)
+            if cand[top] >= 0.5:
+                limiter = top
+            elif cand['mfma'] + cand['valu'] >= 0.5 and min(cand['mfma'], cand['valu']) >= 0.1:
+                limiter = 'mfma+valu in turn' if cand['mfma'] >= cand['valu'] else 'valu+mfma in turn'
+            else:
+                limiter = 'latency' if parked >= stall else 'issue-stall'
             lim[k] = {'limiter': limiter, 'wave_parked_frac': round(parked, 4), 'wave_issue_stall_frac': round(stall, 4), 'wave_issuing_frac': round(active, 4),
                       'wave_issuing_valu_frac': round(valu, 4), 'valu_pipe_busy_frac': None if valu_busy is None else round(valu_busy, 4),
+                      'valu_issue_busy_frac': None if valu_issue is None else round(valu_issue, 4),
                       'lds_busy_frac': None if lds_busy is None else round(lds_busy, 4), 'mfma_busy_frac': mfma_busy, 'hbm_frac_measured_bytes': None if hbm_frac is None else round(hbm_frac, 4),
                       'valu_insts_per_launch': e.get('SQ_INSTS_VALU'), 'lds_insts_per_launch': e.get('SQ_INSTS_LDS'), 'lds_bank_conflict_cycles': e.get('SQ_LDS_BANK_CONFLICT'),
                       'lds_bank_conflict_per_lds_active': (round(e.get('SQ_LDS_BANK_CONFLICT', 0.0) / e['SQ_LDS_IDX_ACTIVE'], 4) if e.get('SQ_LDS_IDX_ACTIVE') else None),
@@ -177,13 +188,13 @@ def main():
             f.write(f'# rocprofv3 --pmc, two SQ passes of their own (tools/profile.sh), same command ({tag}, {workload}, kernel sources {stamp[:16]})\n\n')
             f.write('What the waves of each kernel do.  `parked` = SQ_WAIT_ANY / SQ_WAVE_CYCLES (waiting at s_waitcnt / s_barrier: memory and halo-exchange latency, barrier skew), '
                     '`issue stall` = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (a dependent instruction or a busy pipe), `issuing` = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES (of which VALU: '
-                    'SQ_ACTIVE_INST_VALU).  `VALU pipe` = SQ_INSTS_VALU x 2 cycles / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); `MFMA` from the MFMA pass; `HBM` = measured bytes / duration / 8 TB/s; '
-                    '`LDS` = SQ_LDS_IDX_ACTIVE / (GUI_ACTIVE / 8 x 256 CUs).  **limiter** = the pipe that is busy at least half of the launch, else `latency` (parked > stalled) or `issue-stall`.\n\n')
-            f.write('| kernel | share % | avg us | limiter | parked | issue stall | issuing (VALU) | VALU pipe | MFMA | LDS | HBM | bank-conflict / LDS-active | VALU insts | LDS insts |\n|---|---:|---:|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|\n')
+                    'SQ_ACTIVE_INST_VALU).  `VALU pipe` = SQ_INSTS_VALU x 2 cycles / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), `VALU issue` = SQ_ACTIVE_INST_VALU x 4 / the same SIMD-cycles (the share of the launch a SIMD spends issuing vector instructions, whatever one costs); `MFMA` from the MFMA pass; `HBM` = measured bytes / duration / 8 TB/s; '
+                    '`LDS` = SQ_LDS_IDX_ACTIVE / (GUI_ACTIVE / 8 x 256 CUs).  **limiter** = the pipe that is busy at least half of the launch; `a+b in turn` when matrix pipe and vector issue together cover half of it (phases that saturate one while the other idles); else `latency` (parked > stalled) or `issue-stall`.\n\n')
+            f.write('| kernel | share % | avg us | limiter | parked | issue stall | issuing (VALU) | VALU pipe | VALU issue | MFMA | LDS | HBM | bank-conflict / LDS-active | VALU insts | LDS insts |\n|---|---:|---:|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|\n')
             pc = lambda v: '-' if v is None else f'{100 * v:.1f} %'
             for k, e in sorted(lim.items(), key=lambda kv: -(kv[1]['share_pct'] or 0)):
                 f.write(f"| `{k}` | {e['share_pct'] or 0:.2f} | {e['avg_us'] or 0:.1f} | **{e['limiter']}** | {pc(e['wave_parked_frac'])} | {pc(e['wave_issue_stall_frac'])} | "
-                        f"{pc(e['wave_issuing_frac'])} ({pc(e['wave_issuing_valu_frac'])}) | {pc(e['valu_pipe_busy_frac'])} | {pc(e['mfma_busy_frac'])} | {pc(e['lds_busy_frac'])} | {pc(e['hbm_frac_measured_bytes'])} | "
+                        f"{pc(e['wave_issuing_frac'])} ({pc(e['wave_issuing_valu_frac'])}) | {pc(e['valu_pipe_busy_frac'])} | {pc(e['valu_issue_busy_frac'])} | {pc(e['mfma_busy_frac'])} | {pc(e['lds_busy_frac'])} | {pc(e['hbm_frac_measured_bytes'])} | "
                         f"{'-' if e['lds_bank_conflict_per_lds_active'] is None else e['lds_bank_conflict_per_lds_active']} | {e['valu_insts_per_launch'] or 0:.4g} | {e['lds_insts_per_launch'] or 0:.4g} |\n")
         json.dump({'csrc_sha256': stamp, 'workload': workload, 'tag': tag, 'kernels': lim}, open(os.path.join(out, f'pmc_limiter_{arch}_bs{bs}.json'), 'w'), indent=1, sort_keys=True)
     line = os.path.join(src, 'bench_line.json')
