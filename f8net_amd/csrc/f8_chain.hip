@@ -730,7 +730,7 @@ chain_kernel(const ChainArgs a) {
                             const int ct = wave * CTW + I;
                             if constexpr (S == 0 && Bi + NBUF - 1 < NBT) wt_load(pwsc, pw4, wbuf[(Bi + NBUF - 1) % NBUF], std::integral_constant<int, Bi + NBUF - 1>{}, wl16);
                             if constexpr (K == 0) {
-                                bias_init(acc[0], ct); acc[1] = acc[0];
+                                bias_init(acc[0], ct);
 #pragma unroll
                                 for (int g = 0; g < 4; ++g) {
                                     const v4i bs = *(const v4i*)(bias_lds + BSLOTS * BIAS_INTS + ct * 32 + 8 * g + 4 * lh);
@@ -746,8 +746,9 @@ chain_kernel(const ChainArgs a) {
                                 res[2 * H2][I] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Bi % NBUF][S], cur[0], res[2 * H2][I], 0, 0, 0);
                                 res[2 * H2 + 1][I] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Bi % NBUF][S], cur[1], res[2 * H2 + 1][I], 0, 0, 0);
                             } else {
+                                if constexpr (K == KS) acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Bi % NBUF][S], cur[1], acc[0], 0, 0, 0);   // C = the bias still in acc[0]
                                 acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Bi % NBUF][S], cur[0], acc[0], 0, 0, 0);
-                                acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Bi % NBUF][S], cur[1], acc[1], 0, 0, 0);
+                                if constexpr (K != KS) acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Bi % NBUF][S], cur[1], acc[1], 0, 0, 0);
                             }
                             if constexpr (K == KT2 - 1) {
                                 if constexpr (G == NFRT - 1) { if (!last) w1_prime(pw0n, std::integral_constant<int, NK1>{}, wl16); }
@@ -822,13 +823,16 @@ chain_kernel(const ChainArgs a) {
                             const int ct = wave * CTW + I;
                             if constexpr (F8_CH_PRIO != 0 && G == (CTW / 2) * KK) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
                             if constexpr (S == 0 && Qi + NBUF - 1 < NQ) w3_load(wbuf[(Qi + NBUF - 1) % NBUF], Qi + NBUF - 1, wl16);
-                            if constexpr (KI == 0) { bias_init(acc[0], ct); acc[1] = acc[0]; }
+                            if constexpr (KI == 0) bias_init(acc[0], ct);
                             v4i (&cur)[2] = (G & 1) ? xfb : xfa;
                             v4i (&nxt)[2] = (G & 1) ? xfa : xfb;
                             if constexpr (G + 1 < NST) rd(nxt, std::integral_constant<int, G + 1>{});
                             pin(cur);
+                            // a unit's first step: the SECOND tile's MFMA goes first and takes its C operand from acc[0], which still holds the bias — instead of a
+                            // 16-register copy acc[1] = acc[0] per unit (round 5: vector instructions are what P3 is short of)
+                            if constexpr (KI == 0) acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Qi % NBUF][S], cur[1], acc[0], 0, 0, 0);
                             acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Qi % NBUF][S], cur[0], acc[0], 0, 0, 0);
-                            acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Qi % NBUF][S], cur[1], acc[1], 0, 0, 0);
+                            if constexpr (KI != 0) acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wbuf[Qi % NBUF][S], cur[1], acc[1], 0, 0, 0);
                             if constexpr (KI == KK - 1) {
                                 if constexpr (I == CTW - 1) { if (!last) w1_prime(pw0n, std::integral_constant<int, NK1>{}, wl16); }
                                 finish(std::integral_constant<int, 0>{}, std::integral_constant<int, I>{}, acc[0]);
@@ -843,8 +847,8 @@ chain_kernel(const ChainArgs a) {
             }
         };
 #ifndef F8_CH_PEEL_LAST
-#define F8_CH_PEEL_LAST 0         // measured (round 5, same box): fewer instructions per unit of P3, 3 % SLOWER on the 56x56 launch (244 vs 236 us): the launch
-#endif                            // grows from 41 to 52 KB of code, and P3 is bound by vector THROUGHPUT, not by what a wave issues beside it
+#define F8_CH_PEEL_LAST 1         // measured (round 5, same box, interleaved): alone — before BREG — 3 % SLOWER on the 56x56 launch (the launch grows from 41 to 52 KB of
+#endif                            // code and P3 is bound by vector THROUGHPUT, not by what a wave issues beside it: DESIGN 4.1); together with BREG +1.0 % img/s in four of four pairs
         if constexpr (TAIL) block(0, std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
         else if constexpr (DS0) block(0, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
         if constexpr (F8_CH_PEEL_LAST) {
