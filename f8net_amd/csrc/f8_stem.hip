@@ -283,6 +283,11 @@ __device__ __forceinline__ v4i stem_quant16(const Y& y, int n, int lo, int hi, u
         const float sc = requant_u8_scale(n);
 #pragma unroll
         for (int g = 0; g < 4; ++g) d[g] = requant_u8x4(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], sc) ^ x_or;
+    } else if (n > 0 && n <= 30 && lo == 0 && hi == 255) {   // the same case on INTEGER instructions (option requant_float = 0 — the default since round 5 — or an
+                                                     // accumulator the planner cannot bound): v_bfe_u32, v_add3_u32, v_ashr_pk_u8_i32: 2 3/4 per value, exact for every int32.
+                                                     // (Round 5: the integer default used to fall through to the general form below, 4 3/4 per value.)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) d[g] = requant_u8x4_int(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], n) ^ x_or;
     } else if (n > 0) {                              // another right shift: four
         const unsigned hf = 1u << (n - 1);
 #pragma unroll
