@@ -569,10 +569,11 @@ int bchain_kernel_name(char* buf, size_t cap, int C, int H, int W, bool ds, int 
     const int nbuf = C == 64 ? BChPair<F8_BCH_S0>::nbuf : (C == 128 ? BChPair<F8_BCH_S1>::nbuf : BChPair<F8_BCH_S2>::nbuf);
     return snprintf(buf, cap, "f8::bchain_kernel<%d, %d, %d, %d, %d, %d, %d, %s, %d>", C, W, H, bchain_rows(C), nb, nbuf, fast, ds ? "true" : "false", F8_BCH_NW);
 }
-hipError_t launch_bchain(const BChainArgs& a, int C, int H, int W, hipStream_t s) {
+hipError_t launch_bchain(const BChainArgs& a, int C, int H, int W, hipStream_t s, char* launched, size_t cap) {
     if (a.nblk < 1 || a.nblk > kBChainMaxBlocks) return hipErrorInvalidValue;
     const int fast = bchain_fast(a);
     const bool ds = a.x8in != nullptr;
+    if (launched) bchain_kernel_name(launched, cap, C, H, W, ds, fast);      // the instance that runs (see launch_chain)
     if (ds ? !(a.x8sc && a.wsc && a.bsc && bchain_ds_supported(C, H, W)) : !a.xr) return hipErrorInvalidValue;
 #define F8_BCH(...) (fast == 1 ? launch_bchain_t<__VA_ARGS__, 1, false>(a, s) : fast == 2 ? launch_bchain_t<__VA_ARGS__, 2, false>(a, s) : launch_bchain_t<__VA_ARGS__, 0, false>(a, s))
 #define F8_BCHD(...) (fast == 1 ? launch_bchain_t<__VA_ARGS__, 1, true>(a, s) : fast == 2 ? launch_bchain_t<__VA_ARGS__, 2, true>(a, s) : launch_bchain_t<__VA_ARGS__, 0, true>(a, s))

@@ -997,16 +997,27 @@ int chain_fast(const ChainArgs& a) {
 // from the instance that runs (round 4 kept a second copy of these constants in f8_net.cpp).  fast: 0 / 1 / 2 as chain_fast returns it.
 #define F8_STR2(...) #__VA_ARGS__
 #define F8_STR(...) F8_STR2(__VA_ARGS__)
+// ROT of the instance launch_chain starts for a geometry (a -DF8_CH_ROT tuning build rotates the K order of the identity-first 14x14 instance only)
+static bool chain_rot(int H, bool tail) {
+#ifdef F8_CH_ROT
+    return H == 14 && !tail;
+#else
+    (void)H; (void)tail; return false;
+#endif
+}
 int chain_kernel_name(char* buf, size_t cap, int C, int MID, int H, int W, int cin0, bool tail, int fast) {
     int R = 4, wg = 1;
     chain_shape(C, MID, H, W, cin0, tail, &R, &wg);
     const char* nb = MID == 64 ? F8_STR(F8_CH_S0) : (MID == 128 ? F8_STR(F8_CH_S1) : F8_STR(F8_CH_S2));
-    return snprintf(buf, cap, "f8::chain_kernel<%d, %d, %d, %d, %d, %d, %s, %d, false, %s>", C, MID, W, H, R, cin0, nb, fast, tail ? "true" : "false");
+    return snprintf(buf, cap, "f8::chain_kernel<%d, %d, %d, %d, %d, %d, %s, %d, %s, %s>", C, MID, W, H, R, cin0, nb, fast, chain_rot(H, tail) ? "true" : "false", tail ? "true" : "false");
 }
 
-hipError_t launch_chain(const ChainArgs& a, int C, int MID, int H, int W, int cin0, hipStream_t s) {
+// `launched` (optional): receives the symbol of the instance that was started — the planner names a step before the run's arguments exist and
+// guesses `fast` from its bounds (1 or 2); chain_fast may still pick the generic instance (0): the executor corrects Step::kernel from here
+hipError_t launch_chain(const ChainArgs& a, int C, int MID, int H, int W, int cin0, hipStream_t s, char* launched, size_t cap) {
     if (a.nblk < 1 || a.nblk > kChainMaxBlocks) return hipErrorInvalidValue;
     const int fast = chain_fast(a);
+    if (launched) chain_kernel_name(launched, cap, C, MID, H, W, cin0, a.tail != 0, fast);
 #define F8_CHAIN_INST(...) (fast == 1 ? launch_chain_t<__VA_ARGS__, 1, F8_CHAIN_ROT>(a, s) : fast == 2 ? launch_chain_t<__VA_ARGS__, 2, F8_CHAIN_ROT>(a, s) : launch_chain_t<__VA_ARGS__, 0, F8_CHAIN_ROT>(a, s))
 #define F8_CHAIN_ROT false
 #if F8_CH_R2_S0

@@ -333,13 +333,13 @@ bool chain_tail_supported(int C, int MID, int H, int W, int cin0);   // ... a st
 int chain_max_blocks(int C, int MID, int H, int W, int cin0, bool tail);
 // rows per tile (4, or 2: the two-workgroups-per-CU instance of tuning builds, -DF8_CH_R2_S0=1) and resident workgroups per CU of the instance that runs the shape
 void chain_shape(int C, int MID, int H, int W, int cin0, bool tail, int* R, int* wg_per_cu);
-hipError_t launch_chain(const ChainArgs& a, int C, int MID, int H, int W, int cin0, hipStream_t s);
+hipError_t launch_chain(const ChainArgs& a, int C, int MID, int H, int W, int cin0, hipStream_t s, char* launched = nullptr, size_t cap = 0);   // launched: the symbol it started
 int chain_kernel_name(char* buf, size_t cap, int C, int MID, int H, int W, int cin0, bool tail, int fast);   // the symbol launch_chain starts (f8_chain.hip)
 // consecutive BasicBlock identity blocks of a stage in one launch (f8_bchain.hip)
 bool bchain_supported(int C, int H, int W);
 bool bchain_ds_supported(int C, int H, int W);
 int bchain_tiles_per_img(int C, int H, int W);
-hipError_t launch_bchain(const BChainArgs& a, int C, int H, int W, hipStream_t s);
+hipError_t launch_bchain(const BChainArgs& a, int C, int H, int W, hipStream_t s, char* launched = nullptr, size_t cap = 0);
 int bchain_kernel_name(char* buf, size_t cap, int C, int H, int W, bool ds, int fast);                         // the symbol launch_bchain starts (f8_bchain.hip)
 // 1x1 -> 3x3 of a 7x7 bottleneck block in one launch (f8_p12.hip); FusedArgs: x8, w0 / b0, w2 / b2, requant 1, q[] = the int8 outputs
 bool fused_p12_supported(int C, int MID, int H, int W);

@@ -119,7 +119,8 @@ struct Step {
     int acc_shl = 0, res_shl = 0, relu0 = 0, relu1 = 0;
     bool dense = false;
     bool raw_input = false;            // S_INPUT: its work is done by the stem launch (S_STEMPOOL with the same flag) unless the run's input is uint8 NHWC
-    std::string name, kernel;          // kernel = device symbol as rocprofv3 prints it
+    std::string name;
+    mutable std::string kernel;        // device symbol as rocprofv3 prints it; chain steps: corrected by the first run from the instance the launcher really started
     double bytes_per_img = 0, bytes_const = 0, ops_per_img = 0;
 };
 
@@ -428,6 +429,9 @@ int f8_net_set_option(f8_net* net, const char* key, int value) {
 }
 int f8_net_get_option(const f8_net* net, const char* key, int* value) {
     if (!net || !value) return fail(F8_ERR_INVALID, "f8_net_get_option: null argument");
+    // read-only state key: 1 = the host-visible mirror of the chain error words is active (f8_net_run then refuses further runs after a time-out
+    // without a synchronisation); 0 = the page-locked allocation failed at upload / not uploaded yet: only f8_net_check reports a time-out
+    if (key && !strcmp(key, "err_mirror")) { *value = (net->uploaded && net->h_err) ? 1 : 0; return F8_OK; }
     const OptKey* k = find_opt(key);
     if (!k) return fail(F8_ERR_INVALID, "f8_net_get_option: unknown key '%s'", key ? key : "(null)");
     *value = net->opt.*(k->slot);
@@ -2423,7 +2427,9 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             a.err = a.sync + kChainErrWord; a.err_host = net->h_err_dev; a.epoch = net->epoch;
             a.xchg = (int8_t*)(net->d_chain + (size_t)part * net->chain_stride + 4096);
             a.timeout_ticks = (uint32_t)std::min<long long>((long long)net->opt.chain_timeout_ms * 100000ll, 0x7fffffffll);
-            e = launch_chain(a, C, MID, oT.H, oT.W, tail ? hf.cd.cin : a0.cd.cin, s);
+            char kb[160] = "";
+            e = launch_chain(a, C, MID, oT.H, oT.W, tail ? hf.cd.cin : a0.cd.cin, s, kb, sizeof kb);
+            if (kb[0] && st.kernel != kb) st.kernel = kb;
             break;
         }
         case S_BCHAIN: {
@@ -2470,7 +2476,9 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             a.err = a.sync + kChainErrWord; a.err_host = net->h_err_dev; a.epoch = net->epoch;
             a.xchg = (int8_t*)(net->d_chain + (size_t)part * net->chain_stride + 4096);
             a.timeout_ticks = (uint32_t)std::min<long long>((long long)net->opt.chain_timeout_ms * 100000ll, 0x7fffffffll);
-            e = launch_bchain(a, x.C, x.H, x.W, s);
+            char kb[160] = "";
+            e = launch_bchain(a, x.C, x.H, x.W, s, kb, sizeof kb);
+            if (kb[0] && st.kernel != kb) st.kernel = kb;
             break;
         }
         case S_P12: {

@@ -99,6 +99,7 @@ class PipelinedShardedForward(ShardedForward):
             if (world > 1 or self.force_collective) else self.local
         self.work = [None] * depth
         self.i = 0
+        self.error = None           # first exception a forward raised on this rank while collectives were outstanding (re-raised by finish())
 
     def __call__(self, x_local, n_total=None):
         k = self.i % self.depth
@@ -108,7 +109,17 @@ class PipelinedShardedForward(ShardedForward):
             if self.work[j] is not None:
                 self.work[j].wait()        # a pair's previous collective is done before its buffers are rewritten
                 self.work[j] = None
-        self.forward_local(x_local, self.local[k])
+        try:
+            self.forward_local(x_local, self.local[k])
+        except Exception as e:                                      # noqa: BLE001
+            # a rank whose forward refuses (f8_net_run returns an error once the host mirror shows a chain time-out) must still take part in this
+            # step's collective: its peers are already in it and would block until the backend's time-out.  It contributes a POISONED block
+            # (NaN: what the classifier writes while the error word is set) and the error is raised by finish(), after the outstanding collectives.
+            if self.world == 1 and not self.force_collective:
+                raise
+            self.local[k].fill_(float('nan'))
+            if self.error is None:
+                self.error = e
         if self.world > 1 or self.force_collective:
             self.work[k] = dist.all_gather_into_tensor(self.full[k], self.local[k], group=self.group, async_op=True)
         return self.full[k]
@@ -118,6 +129,9 @@ class PipelinedShardedForward(ShardedForward):
             if self.work[k] is not None:
                 self.work[k].wait()
                 self.work[k] = None
+        if self.error is not None:
+            e, self.error = self.error, None
+            raise e
 
 
 def verify_gather(local_logits, gathered_logits, n_local: int, steps: int, dt_own: float, group=None):
@@ -126,7 +140,9 @@ def verify_gather(local_logits, gathered_logits, n_local: int, steps: int, dt_ow
     * `rccl_ranks`: the number of distinct rank ids an actual all-gather returned (= the ranks the backend really connected);
     * `per_rank_img_s`: each rank's OWN rate over its own clock (the headline takes the slowest rank's time);
     * `logits_gathered_ok`: every rank compares each block of ITS gathered logits with a checksum the owning rank computed from its local
-      logits (an int64 sum and an order-sensitive weighted int64 sum, both exact), then the verdicts are AND-reduced.
+      logits (an int64 sum and an order-sensitive weighted int64 sum, both exact), then the verdicts are AND-reduced.  A block that holds a
+      non-finite value — the poison a timed-out chain launch leaves in its logits — fails the check even when it matches its owner's;
+    * `nonfinite_per_rank`: non-finite values in each rank's local block.
 
     Replaces what the reference's DataParallel gather / metric all-reduce would silently assume (fix_train.py:269, myutils/distributed.py:79-87)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -151,11 +167,13 @@ def verify_gather(local_logits, gathered_logits, n_local: int, steps: int, dt_ow
     ok = 1
     for r in range(world):
         blk = gathered_logits[r * n_local:(r + 1) * n_local] if world > 1 else local_logits[:n_local]
-        if blk.shape[0] != n_local or not torch.equal(checksum(blk), table[r, 2:]):
+        cs = checksum(blk)
+        if blk.shape[0] != n_local or not torch.equal(cs, table[r, 2:]) or float(cs[2]) > 0 or float(table[r, 4]) > 0:
             ok = 0
     flag = torch.tensor([ok], dtype=torch.int32, device=dev)
     if world > 1:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
     ids = sorted({int(v) for v in table[:, 0].tolist()})
     return {'rccl_ranks': len(ids), 'rank_ids': ids, 'backend': dist.get_backend(group) if dist.is_initialized() else None,
-            'per_rank_img_s': [round(float(v), 1) for v in table[:, 1].tolist()], 'logits_gathered_ok': bool(int(flag.item()) == 1)}
+            'per_rank_img_s': [round(float(v), 1) for v in table[:, 1].tolist()], 'nonfinite_per_rank': [int(v) for v in table[:, 4].tolist()],
+            'logits_gathered_ok': bool(int(flag.item()) == 1)}

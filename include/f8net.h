@@ -254,6 +254,10 @@ int f8_net_check(f8_net* net);
  *               batch), chunk_budget_mb (memory-side cache a chunk's int32 stream may occupy), chunk_ds, chunk_opener,
  *               split_streams, graph, stagger, stagger_pipelined, stem_wpc, stem_grid_div (row-walking head on 1 / n of the CUs; 0 = by output form), check_device, check_input_range, pipeline_depth (2..4 runs in flight),
  *               chain_timeout_ms (bound of a stage-chain launch's halo waits)
+ *   read-only (f8_net_get_option): err_mirror (1 = after upload a page-locked host mirror of the chain error words exists: f8_net_run returns
+ *               F8_ERR_HIP without issuing anything once a chain launch of an EARLIER run gave up waiting, until f8_net_check collects the error;
+ *               0 = the mirror could not be allocated: time-outs surface only through f8_net_check / poisoned logits.  Multi-rank callers: a rank
+ *               that is refused must still enter the step's collective — INTEGRATION.md "rank divergence")
  * F8_ERR_INVALID for an unknown key or a value outside the key's range. */
 int f8_net_set_option(f8_net* net, const char* key, int value);
 int f8_net_get_option(const f8_net* net, const char* key, int* value);

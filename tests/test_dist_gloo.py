@@ -173,10 +173,22 @@ def test_bench_dry_run_dist_world2():
     mg = d['multi_gpu']
     assert mg['rccl_ranks'] == 2 and mg['rank_ids'] == [0, 1] and mg['backend'] == 'gloo' and mg['logits_gathered_ok'] is True
     assert len(mg['per_rank_img_s']) == 2 and all(v > 0 for v in mg['per_rank_img_s'])
-    # --gpus must match the world size of the launch
-    r1 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run-dist', '--bs', '2', '--hw', '32', '--arch', 'resnet18'],
-                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
-    assert r1.returncode != 0 and 'WORLD_SIZE' in (r1.stderr + r1.stdout)
+    # the plain form, no launcher: `python bench.py --gpus 2` starts its own ranks under torch.distributed.run on a free port
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--dry-run-dist', '--bs', '2', '--hw', '32',
+                         '--arch', 'resnet18'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    lines = [l for l in r1.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r1.stdout
+    d1 = json.loads(lines[0])
+    assert d1['n_gpus'] == 2 and d1['multi_gpu']['rccl_ranks'] == 2 and d1['multi_gpu']['logits_gathered_ok'] is True and d1['steps'] == 3
+    # a failing rank's exit code comes back through the self-launch (here: an unknown architecture)
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run-dist', '--bs', '2', '--hw', '32', '--arch', 'no_such_net'],
+                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r2.returncode != 0 and not [l for l in r2.stdout.splitlines() if l.startswith('{')]
+    # under a launcher --gpus must match its world size
+    r3 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run-dist', '--bs', '2', '--hw', '32', '--arch', 'resnet18'],
+                        env=dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'), cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r3.returncode != 0 and 'WORLD_SIZE' in (r3.stderr + r3.stdout)
 
 
 def _verify_worker(rank, world, port, corrupt, q):
@@ -214,3 +226,53 @@ def test_verify_gather_flags_a_block_that_differs_from_its_owners_checksum(corru
     for r in (0, 1):
         assert got[r]['rccl_ranks'] == 2 and got[r]['logits_gathered_ok'] is (not corrupt), got
         assert got[r]['per_rank_img_s'] == [60.0, 60.0]
+
+
+def _refusing_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch
+    import torch.distributed as dist
+    from f8net_amd import dist as f8dist
+    f8dist.init_from_env(backend='gloo')
+    n, classes = 2, 4
+    calls = [0]
+
+    def local(t, o):
+        calls[0] += 1
+        if rank == 1 and calls[0] >= 2:       # f8_net_run refusing once the host mirror shows an earlier run's chain time-out
+            raise RuntimeError('f8_net_run: a stage-chain launch of an earlier run gave up waiting')
+        o.copy_(t.reshape(n, -1)[:, :classes].to(torch.float32) + 100 * rank)
+
+    pf = f8dist.PipelinedShardedForward(local, classes, n, torch.device('cpu'))
+    outs = [pf(torch.full((n, 8), float(step))) for step in range(4)]   # every rank issues 4 collectives
+    err = None
+    try:
+        pf.finish()
+    except RuntimeError as e:
+        err = str(e)
+    last = outs[-1]
+    sc = f8dist.verify_gather(pf.local[(pf.i - 1) % pf.depth], last, n, 4, 1.0)
+    q.put((rank, err, bool(torch.isnan(last[n:]).all()), bool(torch.isfinite(last[:n]).all()), sc))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_rank_whose_forward_refuses_still_enters_the_collective():
+    """f8_net_run returns an error on ONE rank (host mirror of a chain time-out) while its peers are already in the all-gather.
+    PipelinedShardedForward keeps that rank in every collective with a NaN block and raises from finish(); verify_gather rejects the poisoned
+    block although it equals its owner's checksum."""
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_refusing_worker, args=(r, 2, 29697, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = {r: rest for r, *rest in (q.get(timeout=120) for _ in ps)}
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][0] is None and 'gave up waiting' in got[1][0]          # only the refusing rank raises, and only from finish()
+    for r in (0, 1):
+        err, peer_nan, own_ok, sc = got[r]
+        assert peer_nan and own_ok                                        # rank 1's block arrived on both ranks, poisoned; rank 0's block is intact
+        assert sc['logits_gathered_ok'] is False and sc['nonfinite_per_rank'] == [0, 8] and sc['rccl_ranks'] == 2

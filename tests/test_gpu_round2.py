@@ -477,8 +477,11 @@ def test_chain_halo_timeout_poisons_one_run_is_reported_and_the_handle_recovers(
     n = 8
     x, fl = synth.make_input(spec, params, n, 224, seed=2)
     want = oracle.net_forward(spec, params, x, fl)
-    net = build_net(spec, params, max_batch=n, hw=224)
+    # one sub-batch per run: a chain error word (and the poison the classifier derives from it) is per arena copy, i.e. per sub-batch — with the
+    # default split of 2 only the half whose launch gave up would be poisoned
+    net = build_net(spec, params, max_batch=n, hw=224, options={'split': 1})
     assert 'stage_chain' in net.describe()
+    assert net.get_option('err_mirror') in (0, 1)
     xd = torch.from_numpy(x).cuda()
     assert np.array_equal(net.run(xd).cpu().numpy(), want)
     net.set_option('chain_timeout_ms', 0)
