@@ -136,6 +136,12 @@ chain_kernel(const ChainArgs a) {
 #ifndef F8_CH_SPLIT
 #define F8_CH_SPLIT 1
 #endif
+    // cache-policy bits of the halo rows' stores and loads: 17 = sc0 sc1 (agent scope: write-through / L2 bypass — what a neighbour on another XCD needs).
+    // Tuning builds (results INVALID when neighbours sit on different XCDs): 1 = sc0 only, 0 = none: the rows stay in the producer's L2 — what the
+    // write-through and the fabric round trip cost (profiles/chain_limiter_r06.md)
+#ifndef F8_CH_HALO_AUX
+#define F8_CH_HALO_AUX 17
+#endif
     constexpr int PG_ = 8 / (MID / 32), NPW_ = ((R * W + 31) / 32 + PG_ - 1) / PG_;
     constexpr bool SPLIT = F8_CH_SPLIT != 0 && EARLY && PG_ >= 2 && T * R == H && W <= NPW_ * 32 && (R - 1) * W >= NPW_ * 32;
     static_assert(NB <= CM && CM % NB == 0 && NK1 % NB == 0, "a batch of K steps stays inside one 3x3 tap / one weight tile");
@@ -508,8 +514,8 @@ chain_kernel(const ChainArgs a) {
                         const v4i o = quant_tile16<FAST, true>(acc[j], n1, lo1, hi1, xor1);   // FAST: lo1 == 0 is the ReLU
                         if (pix < npx) *(v4i*)(patch + ent * MS + mt * 32 + lh * 16) = o;
                         if constexpr (EARLY) {                  // my first / last row -> the neighbours, write-through (sc0 sc1), 16 bytes per lane
-                            if (pix < npx && pr == 0 && has_up) __builtin_amdgcn_raw_buffer_store_b128(o, rxp, pub0 + (unsigned)(pc * MID), 0, 17);
-                            if (pix < npx && pr == rows - 1 && has_dn) __builtin_amdgcn_raw_buffer_store_b128(o, rxp, pub0 + (unsigned)(ROWB + pc * MID), 0, 17);
+                            if (pix < npx && pr == 0 && has_up) __builtin_amdgcn_raw_buffer_store_b128(o, rxp, pub0 + (unsigned)(pc * MID), 0, F8_CH_HALO_AUX);
+                            if (pix < npx && pr == rows - 1 && has_dn) __builtin_amdgcn_raw_buffer_store_b128(o, rxp, pub0 + (unsigned)(ROWB + pc * MID), 0, F8_CH_HALO_AUX);
                         }
                     }
                     if constexpr (EARLY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains (the first body.2 weight batches land too)
@@ -531,7 +537,7 @@ chain_kernel(const ChainArgs a) {
                     if (mine) {
                         const int ent = (side == 0 ? 1 : rows) * PW + col + 1;
                         const v4i v = *(const v4i*)(patch + ent * MS + c16 * 16);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rxc, (unsigned)(((L * 2 + (int)par) * 2 + side) * ROWB + idx * 16), 0, 17);   // sc0 sc1: write-through
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rxc, (unsigned)(((L * 2 + (int)par) * 2 + side) * ROWB + idx * 16), 0, F8_CH_HALO_AUX);   // sc0 sc1: write-through
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains
                     F8_CT(10);
@@ -576,7 +582,7 @@ chain_kernel(const ChainArgs a) {
                     __syncthreads();
                     if (mine) {
                         const int nb_wg = side == 0 ? L - 1 : L + 1;            // upper neighbour's BOTTOM row / lower neighbour's TOP row
-                        const v4i v = __builtin_amdgcn_raw_buffer_load_b128(rxc, (unsigned)(((nb_wg * 2 + (int)par) * 2 + (1 - side)) * ROWB + idx * 16), 0, 17);
+                        const v4i v = __builtin_amdgcn_raw_buffer_load_b128(rxc, (unsigned)(((nb_wg * 2 + (int)par) * 2 + (1 - side)) * ROWB + idx * 16), 0, F8_CH_HALO_AUX);
                         const int ent = (side == 0 ? 0 : rows + 1) * PW + col + 1;
                         *(v4i*)(patch + ent * MS + c16 * 16) = v;
                     }

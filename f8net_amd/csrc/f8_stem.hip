@@ -267,6 +267,11 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemPoolArgs a) {
 #ifndef F8_STEM_DB
 #define F8_STEM_DB 3                                  // B fragments in flight per compute wave (tuning builds override)
 #endif
+// tuning builds (results INVALID): what the ResNet head is bound by — 1: the B fragments are not read from LDS, 2: no horizontal-pool vector work
+// per conv row, 3: the loader waves load nothing after the first band, 4: no output stores (profiles/stem_limiter_r06.md)
+#ifndef F8_STEM_ABL
+#define F8_STEM_ABL 0
+#endif
 namespace {
 constexpr int RB = 7;                               // pooled rows per band
 constexpr int SW = 28;                              // pooled columns per strip (lane 28 of a strip only provides O for lane 27)
@@ -432,7 +437,7 @@ __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))
     if (wave >= 8) {
         // =================================================== loader waves: band it + 1 -> the other patch while band it is multiplied
         for (int it = 0; d < ntiles; d += G, ++it) {
-            if (d + G < ntiles) load_band(band_of(d + G), lds + ((it & 1) ^ 1) * PBUF, tid - 512, 256);
+            if (F8_STEM_ABL != 3 && d + G < ntiles) load_band(band_of(d + G), lds + ((it & 1) ^ 1) * PBUF, tid - 512, 256);
             __syncthreads();
         }
         if constexpr (KIND == 0) { if (a.err && bad) atomicOr(a.err, 1u); }
@@ -591,6 +596,7 @@ __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))
             constexpr int DB = F8_STEM_DB;
             v4i xo[DB], xe[DB];
             auto rd = [&](int r, v4i& o_, v4i& e_) {
+                if constexpr (F8_STEM_ABL == 1) { o_ = v4i{cr + r, (int)offO, r, cr}; e_ = v4i{r, cr, (int)offE, cr ^ r}; (void)base; return; }
                 o_ = *(const v4i*)(base + r * ROWB + offO);
                 const v2i x0 = *(const v2i*)(base + r * ROWB + offE), x1 = *(const v2i*)(base + r * ROWB + offE + 8);
                 e_ = v4i{x0.x, x0.y, x1.x, x1.y};
@@ -605,7 +611,48 @@ __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))
                 o = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[r], xo[r % DB], o, 0, 0, 0);
             }
 #pragma unroll
-            for (int q = 0; q < 16; ++q) sink(q, max(max(e[q], o[q]), dpp_next_lane(o[q])));
+            for (int q = 0; q < 16; ++q) {
+                if constexpr (F8_STEM_ABL == 2) sink(q, e[q] ^ o[q]);
+                else sink(q, max(max(e[q], o[q]), dpp_next_lane(o[q])));
+            }
+        };
+
+        // PAIR (round 6): the two conv rows of a pooled row (2P, 2P + 1) are multiplied TOGETHER — four accumulators (E / O of both rows) instead of
+        // two.  A wave's MFMAs on one accumulator are a dependent chain (v_mfma_i32_32x32x32_i8: 16 passes), and with two chains per wave and two
+        // compute waves per SIMD the matrix pipe sat idle between them: ablations of the LDS reads, of the pool's vector work, of the loaders and of
+        // the stores each left the launch where it was (profiles/stem_limiter_r06.md).  The rows' input windows overlap (input rows 4P - 3 .. 4P + 3
+        // and 4P - 1 .. 4P + 5): nine B-fragment reads feed 28 MFMAs instead of fourteen; the bias is the first MFMA's C operand (16 registers for
+        // the wave's life instead of four LDS reads and 32 moves per conv row).
+#ifndef F8_STEM_PAIR
+#define F8_STEM_PAIR 1
+#endif
+        auto conv_pair = [&](int crA, const v16i& bz, auto&& sinkA, auto&& sinkB) {    // crA = 2P >= 0
+            v16i eA, oA, eB, oB;
+            const char* const base = patch + (2 * (crA - 2 * p0) + 2) * ROWB;
+            constexpr int DB = F8_STEM_DB < 3 ? F8_STEM_DB : 3;
+            v4i xo[DB], xe[DB];
+            auto rd = [&](int r, v4i& o_, v4i& e_) {
+                if constexpr (F8_STEM_ABL == 1) { o_ = v4i{crA + r, (int)offO, r, crA}; e_ = v4i{r, crA, (int)offE, crA ^ r}; (void)base; return; }
+                o_ = *(const v4i*)(base + r * ROWB + offO);
+                const v2i x0 = *(const v2i*)(base + r * ROWB + offE), x1 = *(const v2i*)(base + r * ROWB + offE + 8);
+                e_ = v4i{x0.x, x0.y, x1.x, x1.y};
+            };
+#pragma unroll
+            for (int r = 0; r < DB - 1; ++r) rd(r, xo[r], xe[r]);
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {                           // input row r of the pair's window: kernel row r of conv row A, r - 2 of conv row B
+                if (r + DB - 1 < 9) rd(r + DB - 1, xo[(r + DB - 1) % DB], xe[(r + DB - 1) % DB]);
+                asm volatile("" : "+v"(xo[r % DB]), "+v"(xe[r % DB]));
+                if (r == 0) { eA = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[0], xe[0], bz, 0, 0, 0); oA = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[0], xo[0], bz, 0, 0, 0); }
+                else if (r < 7) { eA = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[r], xe[r % DB], eA, 0, 0, 0); oA = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[r], xo[r % DB], oA, 0, 0, 0); }
+                if (r == 2) { eB = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[0], xe[r % DB], bz, 0, 0, 0); oB = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[0], xo[r % DB], bz, 0, 0, 0); }
+                else if (r > 2) { eB = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[r - 2], xe[r % DB], eB, 0, 0, 0); oB = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[r - 2], xo[r % DB], oB, 0, 0, 0); }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if constexpr (F8_STEM_ABL == 2) { sinkA(q, eA[q] ^ oA[q]); sinkB(q, eB[q] ^ oB[q]); }
+                else { sinkA(q, max(max(eA[q], oA[q]), dpp_next_lane(oA[q]))); sinkB(q, max(max(eB[q], oB[q]), dpp_next_lane(oB[q]))); }
+            }
         };
 
         const int rps = (B.rp + nsb - 1) / nsb;
@@ -613,11 +660,24 @@ __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))
         if (pb < pe) {
             v16i carry;
             conv_row(2 * (p0 + pb) - 1, [&](int q, int v) { carry[q] = v; });
+            v16i bz;                                                // this half's biases in accumulator layout (PAIR)
+            if constexpr (F8_STEM_PAIR) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const v4i b = *(const v4i*)(bias_l + 8 * g * 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bz[4 * g + q] = b[q];
+                }
+            }
             for (int p = pb; p < pe; ++p) {
                 const int P = p0 + p;
                 v16i pm;
-                conv_row(2 * P, [&](int q, int v) { pm[q] = max(carry[q], v); });
-                conv_row(2 * P + 1, [&](int q, int v) { carry[q] = v; pm[q] = max(max(pm[q], v), floor0); });
+                if constexpr (F8_STEM_PAIR) {
+                    conv_pair(2 * P, bz, [&](int q, int v) { pm[q] = max(carry[q], v); }, [&](int q, int v) { carry[q] = v; pm[q] = max(max(pm[q], v), floor0); });
+                } else {
+                    conv_row(2 * P, [&](int q, int v) { pm[q] = max(carry[q], v); });
+                    conv_row(2 * P + 1, [&](int q, int v) { carry[q] = v; pm[q] = max(max(pm[q], v), floor0); });
+                }
                 // ---- pooled row P: outputs
                 const int m = (B.n * a.P + P) * a.Q + (lane_out ? col : 0);
                 if (lane_out && a.out32) {
@@ -631,7 +691,7 @@ __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))
                 for (int k = 0; k < 2; ++k)
                     if (a.q[k].ptr) {
                         const v4i v = stem_quant16(pm, a.q[k].n, a.q[k].lo, a.q[k].hi, a.q[k].bias_xor, a.acc_ok != 0 && a.rq_int == 0);
-                        if (lane_out) *(v4i*)(a.q[k].ptr + (size_t)m * 64 + half * 32 + lh * 16) = v;
+                        if (lane_out && (F8_STEM_ABL != 4 || v[0] == 0x12345678)) *(v4i*)(a.q[k].ptr + (size_t)m * 64 + half * 32 + lh * 16) = v;
                     }
             }
         }

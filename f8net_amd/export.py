@@ -45,6 +45,11 @@ class ExportConfig:
     quant_avgpool: bool = True
     pool_fusing: bool = True
     bn_eps: float = 1e-5
+    # The FLOAT model's own `int_infer` evaluation (fix_quant_ops.py:418-431) instead of `int_model()`'s export: ResNets and
+    # MobileNet-V1 store the pool's 64 / 49 on the last BLOCK module (fix_resnet.py:472-477, fix_mobilenet_v1.py:218-223), where no conv reads it —
+    # a conv's own `avgpool_scale` stays 1.0 until `int_conv(avgpool_scale=...)` runs — so in that mode the last conv is quantised WITHOUT the
+    # scale (other integers, other weight fraclen) and the pool is sum / 64.  MobileNet-V2 stores it on `tail[0]` itself: no difference there.
+    int_infer_eval: bool = False
 
 
 def float_key(int_key: str) -> str:
@@ -280,7 +285,7 @@ def export_int_state(spec: topology.NetSpec, float_state: dict, cfg: ExportConfi
     layers[spec.fc_key] = fc
     for L in prev_tail:
         L.following = fc
-    if cfg.quant_avgpool:
+    if cfg.quant_avgpool and not (cfg.int_infer_eval and (resnet or mbv1)):
         # FXQAvgPool2d(7).scale = 2^round(log2(49)) / 49 goes to the last conv before the pool
         # (fix_resnet.py:536-539, fix_mobilenet_v1.py:271-275, fix_mobilenet_v2.py:419-420)
         shiftnum = torch.round(torch.log2(torch.tensor(7 ** 2))).int().item()
@@ -305,6 +310,16 @@ def load_float_checkpoint(path_or_dict) -> dict:
             continue
         out[k] = v
     return out
+
+
+def int_infer_model_from_float(arch: str, float_state, cfg: ExportConfig, num_classes: int = 1000):
+    """The reference's `int_infer` evaluation mode of the FLOAT model (`int_infer: True` in every shipped test yml; fix_quant_ops.py:418-431,
+    916-929; fix_resnet.py:158-187, 489-505) as a GPU module: every conv / linear of that mode is `conv(int weights, int(input * 2^fl)) / 2^fl` with
+    float ReLU / residual adds / pool in between, i.e. the integer network evaluated on values float32 carries exactly — so it runs as the planned
+    integer network on the integers THAT mode uses (`ExportConfig.int_infer_eval`: see there for where they differ from `int_model()`'s), and
+    `IntModel.forward_int_infer(x)` quantises the float batch as the float head does and returns real-valued logits."""
+    import dataclasses
+    return int_model_from_float(arch, float_state, dataclasses.replace(cfg, int_infer_eval=True), num_classes)
 
 
 def int_model_from_float(arch: str, float_state, cfg: ExportConfig, num_classes: int = 1000):

@@ -209,6 +209,21 @@ class IntModel(nn.Module):
         setattr(xi, 'output_fraclen', fl)
         return self.forward(xi)
 
+    def forward_int_infer(self, x):
+        """The FLOAT model's `int_infer` evaluation (fix_quant_ops.py:418-431; build the module with `export.int_infer_model_from_float`): `x` is the
+        real-valued float batch.  The head of that mode sees `int(relu(x) * 2^fl)` (a `weight_only` head: fix_quant_ops.py:218-226, truncation) or,
+        with FLAGS.normalize, `int(fix_quant(x, 8, fl, signed) * 2^fl)` (round, clamp to +-127); every later layer re-quantises real values that
+        float32 holds exactly, so the integers never have to be left; the classifier's accumulators are divided by 2^(weight + input fraclen)
+        (`:929`): REAL-valued logits, unlike `forward_integize`."""
+        head, fc = self.head[0], self.classifier[0]
+        fl = int(head.input_fraclen.item())
+        if self.spec.normalize:
+            xi = torch.clamp(torch.round(x * float(2 ** fl)), -127, 127).to(torch.int32)
+        else:
+            xi = (torch.relu(x) * float(2 ** fl)).to(torch.int32)
+        setattr(xi, 'output_fraclen', fl)
+        return self.forward(xi) / float(2 ** (int(fc.weight_fraclen.item()) + int(fc.input_fraclen.item())))
+
     def _load_from_state_dict(self, *a, **k):
         super()._load_from_state_dict(*a, **k)
         self._plans = {}

@@ -67,9 +67,10 @@ EXPORT_CASES = {
 }
 
 
-def build_reference_int_model(arch, yml=None, float_state=None):
+def build_reference_float_model(arch, yml=None, float_state=None):
+    """The reference's FLOAT (fake-quant) model in eval mode with the flag broadcast of fix_train.py:270-295 — what `int_model()` converts, and what
+    the `int_infer` evaluation mode (fix_quant_ops.py:418-431) runs on."""
     import torch
-    import torch.nn as nn
     sys.dont_write_bytecode = True
     sys.path.insert(0, REF)
     sys.argv = ['gen_golden', f'app:{os.path.join(REF, yml or YMLS[arch])}', 'bs:1']
@@ -113,6 +114,15 @@ def build_reference_int_model(arch, yml=None, float_state=None):
         with torch.no_grad():
             for k, v in float_state.items():
                 sd[k].copy_(torch.from_numpy(np.asarray(v)).reshape(sd[k].shape))
+    return model, FLAGS
+
+
+def build_reference_int_model(arch, yml=None, float_state=None, keep_float=False):
+    import torch
+    import torch.nn as nn
+    model, FLAGS = build_reference_float_model(arch, yml, float_state)
+    if keep_float:      # int_infer golden: the float model's own forward, taken BEFORE the conversion flags the modules int_op_only
+        keep_float(model, FLAGS)
     # -- fix_train.py:930-934 with the requires_grad shim
     orig_conv, orig_lin = nn.Conv2d.__init__, nn.Linear.__init__
 
@@ -249,6 +259,35 @@ def child_export(case):
     np.savez_compressed(os.path.join(GOLD, f'export_{case}.npz'), **out)
     wfl = [int(sd[k]) for k in sorted(sd) if k.endswith('weight_fraclen')]
     print(f'[gen_golden] export {case}: {len(names)} layers, weight fraclens {sorted(set(wfl))}, wrote export_{case}.npz')
+
+
+def child_intinfer(case):
+    """`int_infer` evaluation mode (fix_quant_ops.py:418-431): the reference's FLOAT model — eval mode, `int_infer: True` as every
+    shipped test yml sets it — on a real-valued float batch, BEFORE `int_model()` touches it.  The fixture keeps its logits; the batch is
+    `synth.rand_uniform_int(9, 'intinfer', ...) / 2^(head input fraclen)` (regenerated by the tests)."""
+    import torch
+    sys.path.insert(0, REPO)
+    from f8net_amd import synth, topology
+    arch, yml = EXPORT_CASES[case]
+    fstate = synth.make_float_state(topology.get(arch), seed=77)
+    got = {}
+
+    def run_float(model, FLAGS):
+        assert getattr(FLAGS, 'int_infer', False), 'the yml must evaluate in int_infer mode'
+        norm = bool(getattr(FLAGS, 'normalize', False))
+        hfl = int(torch.round(model.head[0].get_input_fraclen()).item())
+        xi = synth.rand_uniform_int(9, 'intinfer', (2, 3, 64, 64), -127 if norm else 0, 127 if norm else 255).astype(np.float32)
+        with torch.no_grad():
+            got['logits'] = model(torch.from_numpy(xi / float(2 ** hfl))).numpy().copy()
+        got['meta'] = np.array([hfl, int(norm)], dtype=np.int32)
+
+    _, FLAGS = build_reference_int_model(arch, yml=yml, float_state=fstate, keep_float=run_float)
+    out = {'logits': got['logits'], 'meta': got['meta'],
+           'flags': np.array([int(bool(getattr(FLAGS, k, False))) for k in
+                              ('normalize', 'format_from_metric', 'format_grid_search', 'no_clipping', 'input_fraclen_sharing',
+                               'quant_avgpool', 'pool_fusing', 'rescale_forward', 'rescale_forward_conv')], dtype=np.int32)}
+    np.savez_compressed(os.path.join(GOLD, f'intinfer_{case}.npz'), **out)
+    print(f'[gen_golden] int_infer {case}: head fraclen {got["meta"][0]}, logits {got["logits"].shape} max |.| {np.abs(got["logits"]).max():.4f}, wrote intinfer_{case}.npz')
 
 
 ONNX_LSHIFT = {'stage_0_layer_0.body.0': (6, 0), 'stage_0_layer_0.body.2': (8, 5),      # n = 6 - 8 = -2
@@ -471,12 +510,14 @@ def main():
         child_onnx(args.child.split(':', 1)[1])
     elif args.child and args.child.startswith('export:'):
         child_export(args.child.split(':', 1)[1])
+    elif args.child and args.child.startswith('intinfer:'):
+        child_intinfer(args.child.split(':', 1)[1])
     elif args.child:
         child_model(args.child)
     else:
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
         base = [a for a in YMLS if a not in DEEP]
-        for c in ['ops'] + list(YMLS) + [f'export:{c}' for c in EXPORT_CASES] + [f'onnx:{a}' for a in base + ['resnet18+lshift']]:
+        for c in ['ops'] + list(YMLS) + [f'export:{c}' for c in EXPORT_CASES] + [f'intinfer:{c}' for c in EXPORT_CASES] + [f'onnx:{a}' for a in base + ['resnet18+lshift']]:
             subprocess.check_call([sys.executable, os.path.abspath(__file__), '--child', c], env=env)
 
 

@@ -28,7 +28,10 @@ __device__ __forceinline__ void group_barrier(unsigned* ctr, unsigned target) {
     while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < (int)target) __builtin_amdgcn_s_sleep(1);
 }
 
-template <int MODE>      // 0: lockstep, 1: pingpong, 2: pingpong without the initial offset (both groups start in M)
+// Round 6 (VERDICT r5 #1a): modes 1 / 2 run a FIXED iteration count per group, so the figure printed for the slower group mixes the time it shares the CU
+// with the time it runs alone after the first-dispatched group has finished; "aggregate" cannot be read off it.  Mode 3 measures it: the two groups PULL
+// iterations from one LDS counter until 2 x iters group-iterations are done (the work of `iters` lockstep iterations); mode 4 = one group alone on the CU.
+template <int MODE>      // 0: lockstep, 1: pingpong, 2: pingpong without the initial offset (both groups start in M), 3: two groups pulling work, 4: one group alone
 __global__ void __launch_bounds__(512) pp_kernel(int iters, int n, int sh, int* out, unsigned long long* cyc) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -82,37 +85,62 @@ __global__ void __launch_bounds__(512) pp_kernel(int iters, int n, int sh, int* 
     unsigned gen = 0;
     auto bar = [&]() {
         if constexpr (MODE == 0) __syncthreads();
-        else { gen += 4; group_barrier(ctr, gen); }
+        else { gen += 4; group_barrier(ctr, gen); }      // (mode 4: the idle group never arrives at group 0's counter — groups have counters of their own)
     };
     const unsigned long long t0 = __builtin_readcyclecounter();
-    if (MODE == 1 && grp == 1) { phase_m(); bar(); }        // group B: half a period behind
-    for (int it = 0; it < iters; ++it) {
-        phase_m(); bar();
-        phase_v(); bar();
+    int done = 0;
+    if constexpr (MODE == 3) {
+        unsigned* const taken = (unsigned*)(lds + 140 * 1024) + 96;        // shared ticket counter; slot[grp][parity] = the group's current ticket
+        unsigned* const slot = (unsigned*)(lds + 140 * 1024) + 128 + grp * 2;
+        unsigned par = 0;
+        for (;;) {
+            if ((wave & 3) == 0 && lane == 0) slot[par] = __hip_atomic_fetch_add(taken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            bar();
+            const unsigned tk = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(slot + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            par ^= 1u;
+            if (tk >= (unsigned)(2 * iters)) break;
+            phase_m(); bar();
+            phase_v();
+            ++done;
+        }
+    } else if constexpr (MODE == 4) {
+        if (grp == 0) for (int it = 0; it < iters; ++it) { phase_m(); bar(); phase_v(); bar(); ++done; }
+    } else {
+        if (MODE == 1 && grp == 1) { phase_m(); bar(); }        // group B: half a period behind
+        for (int it = 0; it < iters; ++it) {
+            phase_m(); bar();
+            phase_v(); bar();
+            ++done;
+        }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     int s = 0; for (int t = 0; t < 7; ++t) for (int r = 0; r < 16; ++r) s += res[t][r];
     for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r];
     if (s == 0x7fffffff) out[0] = s;
-    if (lane == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
+    if (lane == 0) { cyc[blockIdx.x * 8 + wave] = t1 - t0; cyc[2048 + blockIdx.x * 8 + wave] = (unsigned long long)done; }
 }
 
 template <int MODE> static void run(const char* name, int iters) {
     int* out; unsigned long long* cyc;
-    CK(hipMalloc((void**)&out, 64)); CK(hipMalloc((void**)&cyc, 256 * 8 * 8)); CK(hipMemset(cyc, 0, 256 * 8 * 8));
+    CK(hipMalloc((void**)&out, 64)); CK(hipMalloc((void**)&cyc, 2 * 256 * 8 * 8)); CK(hipMemset(cyc, 0, 2 * 256 * 8 * 8));
     auto k = pp_kernel<MODE>;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     hipLaunchKernelGGL(k, dim3(256), dim3(512), 150 * 1024, 0, 4, 8, 0, out, cyc); CK(hipDeviceSynchronize());
     hipLaunchKernelGGL(k, dim3(256), dim3(512), 150 * 1024, 0, iters, 8, 0, out, cyc); CK(hipDeviceSynchronize());
-    static unsigned long long h[256 * 8]; CK(hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost));
-    double mx = 0, a = 0, b = 0;
-    for (int i = 0; i < 256; ++i) { double m = 0; for (int w = 0; w < 8; ++w) m = h[i * 8 + w] > m ? h[i * 8 + w] : m; mx += m; a += h[i * 8]; b += h[i * 8 + 7]; }
-    printf("%-44s %8.0f cycles per (M + V) iteration (slowest wave; wave 0 %6.0f, wave 7 %6.0f)\n", name, mx / 256 / iters, a / 256 / iters, b / 256 / iters);
+    static unsigned long long h[2 * 256 * 8]; CK(hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost));
+    double mx = 0, a = 0, b = 0, da = 0, db = 0;
+    for (int i = 0; i < 256; ++i) { double m = 0; for (int w = 0; w < 8; ++w) m = h[i * 8 + w] > m ? h[i * 8 + w] : m; mx += m; a += h[i * 8]; b += h[i * 8 + 7]; da += h[2048 + i * 8]; db += h[2048 + i * 8 + 7]; }
+    // group-iterations per workgroup and their aggregate rate: lockstep = 2 groups x iters
+    const double gi = (da + db) / 256;
+    printf("%-52s %8.0f cycles per (M + V) iteration of BOTH groups (slowest wave / (group-iterations / 2)); wave 0: %6.0f cycles total / %5.1f iterations, wave 7: %6.0f / %5.1f; aggregate %.4f group-iterations per k-cycle\n",
+           name, mx / 256 / (gi / 2), a / 256, da / 256, b / 256, db / 256, 1e3 * gi / (mx / 256));
     CK(hipFree(out)); CK(hipFree(cyc));
 }
 int main() {
     run<0>("lockstep: 8 waves, s_barrier per phase", 200);
     run<1>("pingpong: two 4-wave groups, half a period apart", 200);
     run<2>("two groups, own barriers, same start", 200);
+    run<3>("two groups PULLING iterations from one counter", 200);
+    run<4>("one 4-wave group alone on the CU", 200);
     return 0;
 }
