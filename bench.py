@@ -406,8 +406,8 @@ def main():
         for i in range(n_l):
             name, nbytes, nops = net.launch_info(i, BS)
             k = net.launch_kernel(i)
-            e = by_kernel.setdefault(k, {'ms': 0.0, 'bytes': 0.0, 'ops': 0.0, 'launches': 0})
-            e['ms'] += ms[i]; e['bytes'] += nbytes; e['ops'] += nops; e['launches'] += net.step_launches(i, BS)
+            e = by_kernel.setdefault(k, {'ms': 0.0, 'bytes': 0.0, 'ops': 0.0, 'valu': 0.0, 'launches': 0})
+            e['ms'] += ms[i]; e['bytes'] += nbytes; e['ops'] += nops; e['valu'] += net.launch_valu(i, BS); e['launches'] += net.step_launches(i, BS)
             rows.append((i, name, ms[i], nbytes, nops))
         parts = net.num_parts(BS)       # each planned launch is issued once per sub-batch
         dom = max(by_kernel, key=lambda k: by_kernel[k]['ms'])
@@ -493,9 +493,9 @@ def main():
                           'hbm_frac_structural_bytes': round(value / world * STRUCT_BYTES_PER_IMG.get(args.arch, 0.0) / 1e9 / HBM_PEAK_GBS, 4),
                           'hbm_frac_algorithmic_bytes': round(value / world * sum(r[3] for r in rows) / BS / 1e9 / HBM_PEAK_GBS, 4),
                           'alg_bytes_per_img': round(sum(r[3] for r in rows) / BS, 0)},
-            # per kernel symbol: launches per step, live duration (HIP events), algorithmic ops / bytes per step — tools/summarize_prof.py divides the
-            # MFMA instructions the counters saw by the algorithmic ones (issued / algorithmic: halo recompute, tile padding)
-            'per_kernel': {k: {'launches': e['launches'], 'us': round(1e3 * e['ms'], 2), 'alg_ops': round(e['ops'], 0), 'alg_bytes': round(e['bytes'], 0)}
+            # per kernel symbol: launches per step, live duration (HIP events), algorithmic ops / bytes / essential vector lane-operations per step — tools/summarize_prof.py
+            # divides the MFMA and vector instructions the counters saw by them (issued / algorithmic: halo recompute, tile padding; issued / essential: addressing, swaps ...)
+            'per_kernel': {k: {'launches': e['launches'], 'us': round(1e3 * e['ms'], 2), 'alg_ops': round(e['ops'], 0), 'alg_bytes': round(e['bytes'], 0), 'alg_valu': round(e['valu'], 0)}
                            for k, e in by_kernel.items() if e['ms'] > 0},
             'build': {'csrc_sha256': stamp[:16]},
         }

@@ -122,6 +122,7 @@ struct Step {
     std::string name;
     mutable std::string kernel;        // device symbol as rocprofv3 prints it; chain steps: corrected by the first run from the instance the launcher really started
     double bytes_per_img = 0, bytes_const = 0, ops_per_img = 0;
+    double valu_per_img = 0;           // ESSENTIAL vector lane-operations per image (f8_net_launch_valu): what the reference's semantics need once the MFMAs are done
 };
 
 }  // namespace
@@ -785,6 +786,12 @@ static void select_outputs(f8_net* net, int t, OutSel* o, std::vector<int>* extr
 }
 
 // Name (layer key + kernel variant) and device symbol (as rocprofv3 prints it) of a conv step; depends on the tile.
+// Essential vector work of a launch (VERDICT r5 #1b: the counters' SQ_INSTS_VALU x 64 divided by this = issued / essential): per value of the
+// reference's semantics, with the cheapest exact integer forms of f8_device.h —
+//   an int8 value produced (in HBM or only in LDS): round-half-even shift + clamp + pack = 3 (v_bfe_u32, v_add3_u32, 1/2 v_ashr_pk_u8_i32, 1/4 v_perm_b32,
+//   1/4 v_xor_b32; the ReLU in front of it is the clamp's lower bound); a joined int32 value: align-add + clamp / ReLU = 2; a max-pooled conv value: 1.
+// Addressing, lane swaps, exec masks, halo code, tile padding and recompute are NOT in it: they are what the ratio shows.
+static double out_forms8(const Step& st) { return (double)((st.out.f8[0] >= 0) + (st.out.f8[1] >= 0)); }
 static void label_conv_step(f8_net* net, Step& st, const Node& nd) {
     auto& ND = net->nodes;
     const f8_conv_desc& d = nd.cd;
@@ -1463,6 +1470,7 @@ static int emit_steps(f8_net* net, int max_batch) {
                     Tensor& o = T[out_t];
                     const double cpx = (double)o.H * o.W;
                     st.ops_per_img = 2.0 * cpx * (32.0 * hh.cd.cin * 9 + 32.0 * 9 + 32.0 * nd.cd.cout);
+                    st.valu_per_img = 3.0 * cpx * (32.0 + 32.0 + o.Cs * out_forms8(st));
                     st.bytes_per_img = (double)s.H * s.W * 4 + cpx * o.Cs * ((st.out.f8[0] >= 0) + (st.out.f8[1] >= 0));
                     st.bytes_const = 32.0 * 100 + 32.0 * 13 + 32.0 * 36;
                     st.name = "head3x3s2+dw3x3+1x1:" + tname(net, hh.out) + "+" + tname(net, hb.out) + "+" + tname(net, nd.out);
@@ -1482,6 +1490,7 @@ static int emit_steps(f8_net* net, int max_batch) {
                     const f8_conv_desc& d = nd.cd;
                     const double cpx = (double)T[nd.out].H * T[nd.out].W;
                     st.ops_per_img = 2.0 * cpx * d.cout * d.cin * d.kernel * d.kernel;
+                    st.valu_per_img = cpx * d.cout + 3.0 * (double)o.H * o.W * o.Cs * out_forms8(st);      // one max per conv value; the requantisation runs on the pooled ones
                     st.bytes_per_img = (double)s.H * s.W * 4 + (double)o.H * o.W * o.Cs * ((st.out.f32 >= 0 ? 4 : 0) + (st.out.f8[0] >= 0) + (st.out.f8[1] >= 0));
                     st.bytes_const = (double)nd.coutP * (nd.ktot + 4);
                     st.name = "stem7x7s2+maxpool3x3s2:" + tname(net, nd.out) + "+" + tname(net, pl.out);
@@ -1521,6 +1530,7 @@ static int emit_steps(f8_net* net, int max_batch) {
                     if (st.out.f32 >= 0) b += px * o.Cs * 4;
                     for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += px * o.Cs;
                     st.ops_per_img = ops; st.bytes_per_img = b; st.bytes_const = wbytes;
+                    st.valu_per_img = (double)ch.size() * px * o.C * (3.0 + 2.0 + 3.0) - 3.0 * px * o.C + 3.0 * px * o.Cs * out_forms8(st);   // per block: first conv's int8, join, the next block's int8 input; the last block's are the output forms
                     st.name = "basic_chain_x" + std::to_string(ch.size()) + (ds ? "_ds:" : ":") + tname(net, f1.out) + ".." + tname(net, nd.out);
                     char kb[160];
                     // the instance's arithmetic as launch_bchain picks it (bchain_fast): the float converter only for values the planner bounds
@@ -1573,6 +1583,10 @@ static int emit_steps(f8_net* net, int max_batch) {
                     if (st.out.f32 >= 0) b += px * o.Cs * 4;
                     for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += px * o.Cs;
                     st.ops_per_img = ops; st.bytes_per_img = b; st.bytes_const = wbytes;
+                    {   // per block: body.0's and body.2's int8 outputs (the TAIL join has none), the join, the next block's int8 input (last block: the output forms)
+                        const double mid = (double)(tail ? ND[hf.dual].cd.cin : ND[ds ? hf.fbd_a : hf.fb_a].cd.cout);
+                        st.valu_per_img = px * ((double)(ch.size() - (tail ? 1 : 0)) * 2.0 * mid * 3.0 + (double)ch.size() * o.C * 2.0 + (double)(ch.size() - 1) * o.C * 3.0 + 3.0 * o.Cs * out_forms8(st));
+                    }
                     const Node& a0 = tail ? ND[hf.dual] : ND[ds ? hf.fbd_a : hf.fb_a];
                     st.name = "stage_chain_x" + std::to_string(ch.size()) + (tail ? "_tail:" : (ds ? "_ds:" : ":")) + tname(net, a0.out) + ".." + tname(net, nd.out);
                     char kb[160];
@@ -1615,6 +1629,7 @@ static int emit_steps(f8_net* net, int max_batch) {
                     const double px = (double)x.H * x.W, pxo = (double)o.H * o.W;   // stride-2 opener: body.0 runs on the input map
                     st.ops_per_img = 2.0 * (px * (double)na.cd.cin * na.cd.cout + pxo * (9.0 * nb.cd.cin * nb.cd.cout + (double)ng.cd.cin * ng.cd.cout +
                                                                                          (double)nd.cd.cin * nd.cd.cout));
+                    st.valu_per_img = 3.0 * (px * na.cd.cout + pxo * nb.cd.cout) + pxo * o.C * 2.0 + 3.0 * pxo * o.Cs * out_forms8(st);
                     double b = px * x.Cs;                                           // int8 input once
                     if (st.out.f32 >= 0) b += pxo * o.Cs * 4;
                     for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += pxo * o.Cs;
@@ -1648,6 +1663,7 @@ static int emit_steps(f8_net* net, int max_batch) {
                     Tensor& o = T[out_t];
                     const double px = (double)x.H * x.W, pxo = (double)o.H * o.W;
                     st.ops_per_img = 2.0 * (px * (double)na.cd.cin * na.cd.cout + pxo * 9.0 * nd.cd.cin * nd.cd.cout);
+                    st.valu_per_img = 3.0 * (px * na.cd.cout + pxo * o.Cs * out_forms8(st));
                     double b = px * x.Cs;
                     for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += pxo * o.Cs;
                     st.bytes_per_img = b;
@@ -1684,6 +1700,7 @@ static int emit_steps(f8_net* net, int max_batch) {
                     Tensor& o = T[out_t];
                     const double px = (double)x.H * x.W, pxo = (double)o.H * o.W;
                     st.ops_per_img = 2.0 * (px * na.cd.cin * na.cd.cout + pxo * 9.0 * nb.cd.cout + pxo * (double)nd.cd.cin * nd.cd.cout);
+                    st.valu_per_img = 3.0 * (px * na.cd.cout + pxo * nb.cd.cout) + (st.res_t >= 0 ? 2.0 * pxo * o.C : 0.0) + 3.0 * pxo * o.Cs * out_forms8(st);
                     double b = px * x.Cs + (st.res_t >= 0 ? px * x.Cs * 4 : 0);
                     if (st.out.f32 >= 0) b += pxo * o.Cs * 4;
                     for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += pxo * o.Cs;
@@ -1723,6 +1740,7 @@ static int emit_steps(f8_net* net, int max_batch) {
                     Tensor& o = T[out_t];
                     const double px = (double)x.H * x.W;
                     st.ops_per_img = 2.0 * px * ((double)na.cd.cin * na.cd.cout + 9.0 * nb.cd.cin * nb.cd.cout + (double)nd.cd.cin * nd.cd.cout);
+                    st.valu_per_img = px * (3.0 * (na.cd.cout + nb.cd.cout) + 2.0 * o.C + 3.0 * o.Cs * out_forms8(st));
                     double b = px * x.Cs * (1 + 4);                                 // int8 input + int32 residual, once each
                     if (st.out.f32 >= 0) b += px * o.Cs * 4;
                     for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += px * o.Cs;
@@ -1793,6 +1811,7 @@ static int emit_steps(f8_net* net, int max_batch) {
                 if (st.out.f32 >= 0) b += outpix * o.Cs * 4;
                 for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += outpix * o.Cs;
                 st.bytes_per_img = b;
+                st.valu_per_img = ((st.res_t >= 0 || nd.dual >= 0) ? 2.0 * opix * o.C : 0.0) + (nd.pool >= 0 ? opix * o.C : 0.0) + 3.0 * outpix * o.Cs * out_forms8(st) + (nd.depthwise ? 9.0 * opix * d.cout / 4.0 : 0.0);   // (a VALU depthwise conv: one v_dot4 per four taps)
                 st.bytes_const = nd.depthwise ? (double)s.Cs * 13 : (double)nd.coutP * (nd.ktot + 4);
                 if (nd.dual >= 0) st.bytes_const += (double)ND[nd.dual].coutP * (ND[nd.dual].ktot + 4);
                 label_conv_step(net, st, nd);
@@ -2113,6 +2132,13 @@ int f8_net_launch_info(const f8_net* net, int i, int N, char* name, size_t name_
     if (name && name_cap) { snprintf(name, name_cap, "%s", st.name.c_str()); }
     if (alg_bytes) *alg_bytes = st.bytes_per_img * N + st.bytes_const;
     if (alg_ops) *alg_ops = st.ops_per_img * N;
+    return F8_OK;
+}
+
+int f8_net_launch_valu(const f8_net* net, int i, int N, double* essential_lane_ops) {
+    if (!net || !net->finalized) return fail(F8_ERR_STATE, "f8_net_launch_valu: not finalized");
+    if (i < 0 || i >= (int)net->steps.size() || !essential_lane_ops) return fail(F8_ERR_INVALID, "f8_net_launch_valu: index / null pointer");
+    *essential_lane_ops = net->steps[i].valu_per_img * N;
     return F8_OK;
 }
 

@@ -629,7 +629,7 @@ __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))
         auto conv_pair = [&](int crA, const v16i& bz, auto&& sinkA, auto&& sinkB) {    // crA = 2P >= 0
             v16i eA, oA, eB, oB;
             const char* const base = patch + (2 * (crA - 2 * p0) + 2) * ROWB;
-            constexpr int DB = F8_STEM_DB < 3 ? F8_STEM_DB : 3;
+            constexpr int DB = 2;                                   // B fragments one input row ahead (three deep: 168 registers and 20 bytes of scratch; measured equal)
             v4i xo[DB], xe[DB];
             auto rd = [&](int r, v4i& o_, v4i& e_) {
                 if constexpr (F8_STEM_ABL == 1) { o_ = v4i{crA + r, (int)offO, r, crA}; e_ = v4i{r, crA, (int)offE, crA ^ r}; (void)base; return; }

@@ -133,6 +133,12 @@ class F8Net:
         """Kernel launches planned launch i issues per run of N images (sub-batches / chunks), f8_net_step_launches."""
         return check(self._L.f8_net_step_launches(self._h, i, int(N)))
 
+    def launch_valu(self, i, N):
+        """Essential vector lane-operations of planned launch i for N images (f8_net_launch_valu)."""
+        v = ctypes.c_double(0.0)
+        check(self._L.f8_net_launch_valu(self._h, i, int(N), ctypes.byref(v)))
+        return v.value
+
     def launch_kernel(self, i):
         buf = ctypes.create_string_buffer(256)
         check(self._L.f8_net_launch_kernel(self._h, i, buf, 256))

@@ -283,6 +283,11 @@ int f8_net_launch_info(const f8_net* net, int i, int N, char* name, size_t name_
                        double* alg_bytes, double* alg_ops);
 
 /* Device kernel symbol of launch i as rocprofv3 --kernel-trace prints it (without the argument list). */
+/* ESSENTIAL vector lane-operations of planned launch i for N images: what the reference's element-wise semantics between the matrix products need in
+ * their cheapest exact integer form — 3 per int8 value produced (int_op_only_fix_quant, fix_quant_ops.py:99-112: tie bit, rounding add, 1/2 shift-
+ * saturate-pack, 1/4 merge, 1/4 bias flip), 2 per joined int32 value (fix_resnet.py:40-54: align-add + clamp / ReLU), 1 per max-pooled value.
+ * The profile tooling divides the counters' vector instructions x 64 lanes by it (profiles/rocprof_*_valu.md: issued / essential). */
+int f8_net_launch_valu(const f8_net* net, int i, int N, double* essential_lane_ops);
 int f8_net_launch_kernel(const f8_net* net, int i, char* buf, size_t cap);
 
 /* Attach a label (e.g. the state_dict key) to the node that produced tensor `t`. */

@@ -184,18 +184,40 @@ def main():
                       'valu_insts_per_launch': e.get('SQ_INSTS_VALU'), 'lds_insts_per_launch': e.get('SQ_INSTS_LDS'), 'lds_bank_conflict_cycles': e.get('SQ_LDS_BANK_CONFLICT'),
                       'lds_bank_conflict_per_lds_active': (round(e.get('SQ_LDS_BANK_CONFLICT', 0.0) / e['SQ_LDS_IDX_ACTIVE'], 4) if e.get('SQ_LDS_IDX_ACTIVE') else None),
                       'waves_per_launch': e.get('SQ_WAVES'), 'avg_us': dur, 'share_pct': durs.get(k, (None, None))[1]}
+        # issued / essential vector work (VERDICT r5 #1b): SQ_INSTS_VALU counts wave instructions — x 64 lanes — against the essential lane-operations of the
+        # kernel's launches (f8_net_launch_valu: 3 per int8 value produced, 2 per joined int32 value, 1 per pooled value; the bench line of the same run)
+        ess = {}
+        try:
+            bl = json.loads(open(os.path.join(src, 'bench_line.json')).read().strip())
+            for k, v in (bl.get('per_kernel') or {}).items():
+                if v.get('launches') and v.get('alg_valu'):
+                    ess[k] = v['alg_valu'] / v['launches']
+        except Exception:                                    # noqa: BLE001
+            pass
+        ti_, te_ = 0.0, 0.0
+        for k, e in lim.items():
+            a_ = ess.get(k)
+            e['essential_valu_lane_ops_per_launch'] = a_
+            e['valu_issued_over_essential'] = None if not a_ or not e.get('valu_insts_per_launch') else round(e['valu_insts_per_launch'] * 64.0 / a_, 3)
+            if a_ and e.get('valu_insts_per_launch'):
+                n_ = sq[k].get('launches', 1) if k in sq else 1
+                ti_ += e['valu_insts_per_launch'] * 64.0 * n_; te_ += a_ * n_
         with open(os.path.join(out, f'rocprof_{tag}_valu.md'), 'w') as f:
             f.write(f'# rocprofv3 --pmc, two SQ passes of their own (tools/profile.sh), same command ({tag}, {workload}, kernel sources {stamp[:16]})\n\n')
             f.write('What the waves of each kernel do.  `parked` = SQ_WAIT_ANY / SQ_WAVE_CYCLES (waiting at s_waitcnt / s_barrier: memory and halo-exchange latency, barrier skew), '
                     '`issue stall` = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (a dependent instruction or a busy pipe), `issuing` = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES (of which VALU: '
                     'SQ_ACTIVE_INST_VALU).  `VALU pipe` = SQ_INSTS_VALU x 2 cycles / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), `VALU issue` = SQ_ACTIVE_INST_VALU x 4 / the same SIMD-cycles (the share of the launch a SIMD spends issuing vector instructions, whatever one costs); `MFMA` from the MFMA pass; `HBM` = measured bytes / duration / 8 TB/s; '
-                    '`LDS` = SQ_LDS_IDX_ACTIVE / (GUI_ACTIVE / 8 x 256 CUs).  **limiter** = the pipe that is busy at least half of the launch; `a+b in turn` when matrix pipe and vector issue together cover half of it (phases that saturate one while the other idles); else `latency` (parked > stalled) or `issue-stall`.\n\n')
-            f.write('| kernel | share % | avg us | limiter | parked | issue stall | issuing (VALU) | VALU pipe | VALU issue | MFMA | LDS | HBM | bank-conflict / LDS-active | VALU insts | LDS insts |\n|---|---:|---:|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|\n')
+                    '`LDS` = SQ_LDS_IDX_ACTIVE / (GUI_ACTIVE / 8 x 256 CUs); `issued / essential` = SQ_INSTS_VALU x 64 lanes / the essential vector lane-operations of the launch '
+                    '(f8_net_launch_valu: 3 per int8 value the reference requantises, 2 per joined int32 value, 1 per pooled value — addressing, lane swaps, exec-mask traffic, halo code, '
+                    'tile padding and recompute are what pushes it above 1).  **limiter** = the pipe that is busy at least half of the launch; `a+b in turn` when matrix pipe and vector issue together cover half of it (phases that saturate one while the other idles); else `latency` (parked > stalled) or `issue-stall`.\n\n')
+            if te_:
+                f.write(f'Whole net (kernels with an essential count): issued / essential = {ti_ / te_:.2f}.\n\n')
+            f.write('| kernel | share % | avg us | limiter | parked | issue stall | issuing (VALU) | VALU pipe | VALU issue | MFMA | LDS | HBM | bank-conflict / LDS-active | VALU insts | issued / essential | LDS insts |\n|---|---:|---:|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|\n')
             pc = lambda v: '-' if v is None else f'{100 * v:.1f} %'
             for k, e in sorted(lim.items(), key=lambda kv: -(kv[1]['share_pct'] or 0)):
                 f.write(f"| `{k}` | {e['share_pct'] or 0:.2f} | {e['avg_us'] or 0:.1f} | **{e['limiter']}** | {pc(e['wave_parked_frac'])} | {pc(e['wave_issue_stall_frac'])} | "
                         f"{pc(e['wave_issuing_frac'])} ({pc(e['wave_issuing_valu_frac'])}) | {pc(e['valu_pipe_busy_frac'])} | {pc(e['valu_issue_busy_frac'])} | {pc(e['mfma_busy_frac'])} | {pc(e['lds_busy_frac'])} | {pc(e['hbm_frac_measured_bytes'])} | "
-                        f"{'-' if e['lds_bank_conflict_per_lds_active'] is None else e['lds_bank_conflict_per_lds_active']} | {e['valu_insts_per_launch'] or 0:.4g} | {e['lds_insts_per_launch'] or 0:.4g} |\n")
+                        f"{'-' if e['lds_bank_conflict_per_lds_active'] is None else e['lds_bank_conflict_per_lds_active']} | {e['valu_insts_per_launch'] or 0:.4g} | {'-' if e.get('valu_issued_over_essential') is None else e['valu_issued_over_essential']} | {e['lds_insts_per_launch'] or 0:.4g} |\n")
         json.dump({'csrc_sha256': stamp, 'workload': workload, 'tag': tag, 'kernels': lim}, open(os.path.join(out, f'pmc_limiter_{arch}_bs{bs}.json'), 'w'), indent=1, sort_keys=True)
     line = os.path.join(src, 'bench_line.json')
     if os.path.exists(line):
