@@ -54,7 +54,17 @@ __global__ void __launch_bounds__(512) conv3x3s2_wreg_kernel(const ConvArgs a, c
     const int rh = Cfg::RSPLIT == 2 ? h : 0, ch = Cfg::CSPLIT == 2 ? h : 0;
     const int ct = ch * 8 + wave;                        // this wave's output-channel tile
     const int r0 = rh * RO;                              // first output row of the workgroup
-    const int rot = (wave * 2 + (blockIdx.x >> 3) * 3 + (blockIdx.x & 7)) & (SPT - 1);
+    // K-order rotation (integer sums are exact in any order): so that the workgroups do not all ask the L2 for the same kilobyte of the weight
+    // stream at the same moment.  Round 6: by whole TAPS (`trot`, wave-uniform: scalar arithmetic once per tap) instead of by K32 steps inside a
+    // tap — with a run-time step every B-fragment read paid five to six vector instructions of swizzled-address arithmetic (rocprof_r06_valu.md:
+    // 13 - 21 x the essential vector work, 47 - 49 % issue stall); with the step a compile-time constant a read's address is ONE v_xor_b32 of a
+    // per-tap base: entry * CIN | ((lh ^ entry % 16) << 4), whose low bits the step's (2 s << 4) never meets with a carry.
+#ifndef F8_S2_TAPROT
+#define F8_S2_TAPROT 1
+#endif
+    const int rot = F8_S2_TAPROT ? 0 : ((wave * 2 + (blockIdx.x >> 3) * 3 + (blockIdx.x & 7)) & (SPT - 1));
+    const int trot = F8_S2_TAPROT ? __builtin_amdgcn_readfirstlane((int)((unsigned)(wave * 4 + (blockIdx.x >> 3) * 5 + (blockIdx.x & 7) * 2) % 9u)) : 0;
+    auto tap_of = [&](int T) { const int t = T + trot; return t >= 9 ? t - 9 : t; };      // the tap multiplied T-th
 
     // ---- this lane's pixels: accumulators start at the (border-class) bias
     v16i acc[PT];
@@ -93,11 +103,18 @@ __global__ void __launch_bounds__(512) conv3x3s2_wreg_kernel(const ConvArgs a, c
     __builtin_amdgcn_sched_barrier(0);
 
     const v4i* const wp = (const v4i*)a.w + (size_t)ct * NK * 64 + lane;      // fragment order: [tile][K32 step][lane][16 B]
+    // TAPROT: BUFFER loads (resource = this wave's channel tile, the step in the scalar offset, the lane in the one vector offset) — as flat loads every
+    // fragment cost a 64-bit vector add (138 v_lshl_add_u64 per wave in the K loop)
+    const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc((void*)((const v4i*)a.w + (size_t)ct * NK * 64), 0, (unsigned)(NK * 1024), 0x00020000);
+    const unsigned wl16 = (unsigned)lane * 16u;
     v4i wbuf[NBUF][NB];
-    auto load_batch = [&](v4i (&dst)[NB], int s0) {      // a batch stays inside a tap; the rotation is inside the tap's SPT steps
-        const int tb = s0 & ~(SPT - 1);
+    auto load_batch = [&](v4i (&dst)[NB], int s0) {      // a batch stays inside a tap
+        const int tb = F8_S2_TAPROT ? tap_of(s0 / SPT) * SPT : (s0 & ~(SPT - 1));
 #pragma unroll
-        for (int s = 0; s < NB; ++s) dst[s] = wp[(size_t)(tb + ((s0 + s + rot) & (SPT - 1))) * 64];
+        for (int s = 0; s < NB; ++s) {
+            if constexpr (F8_S2_TAPROT) dst[s] = __builtin_amdgcn_raw_buffer_load_b128(rwt, wl16, (tb + ((s0 + s) & (SPT - 1))) * 1024, 0);
+            else dst[s] = wp[(size_t)(tb + ((s0 + s + rot) & (SPT - 1))) * 64];
+        }
     };
     constexpr int PRE = NBUF - 1 < NBAT ? NBUF - 1 : NBAT;
     static_for<PRE>([&](auto bc) { constexpr int B = decltype(bc)::value; load_batch(wbuf[B], B * NB); });
@@ -113,15 +130,22 @@ __global__ void __launch_bounds__(512) conv3x3s2_wreg_kernel(const ConvArgs a, c
     auto rdx = [&](auto gc, v4i (&xf)[PT]) {
         constexpr int G = decltype(gc)::value, T = G / SPT;
         if constexpr (G % SPT == 0) {                    // a new tap: its patch entries (the fragments of the previous tap are in registers)
+            const int t = tap_of(T), dy = (t * 11) >> 5, dx = t - 3 * dy;          // scalar
 #pragma unroll
             for (int j = 0; j < PT; ++j) {
-                const int ent = ent0[j] + (T / 3) * PC + T % 3;
-                eoff[j] = (unsigned)(ent * CIN); esw[j] = (unsigned)(ent & 15);
+                const int ent = ent0[j] + dy * PC + dx;
+                eoff[j] = F8_S2_TAPROT ? (unsigned)(ent * CIN) | (((unsigned)lh ^ (unsigned)(ent & 15)) << 4) : (unsigned)(ent * CIN);
+                esw[j] = (unsigned)(ent & 15);
             }
         }
-        const unsigned c2 = (unsigned)((((G % SPT) + rot) & (SPT - 1)) * 2 + lh);
+        if constexpr (F8_S2_TAPROT) {
 #pragma unroll
-        for (int j = 0; j < PT; ++j) xf[j] = *(const v4i*)(patch + eoff[j] + ((c2 ^ esw[j]) << 4));
+            for (int j = 0; j < PT; ++j) xf[j] = *(const v4i*)(patch + (eoff[j] ^ (unsigned)((G % SPT) * 32)));
+        } else {
+            const unsigned c2 = (unsigned)((((G % SPT) + rot) & (SPT - 1)) * 2 + lh);
+#pragma unroll
+            for (int j = 0; j < PT; ++j) xf[j] = *(const v4i*)(patch + eoff[j] + ((c2 ^ esw[j]) << 4));
+        }
     };
     v4i xa[PT], xb[PT];
     rdx(std::integral_constant<int, 0>{}, xa);
