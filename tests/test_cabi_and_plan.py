@@ -316,3 +316,24 @@ def test_planner_bounds_the_residual_stream_before_it_plans_the_float_requantisa
     r18 = topology.get('resnet18')
     ks = chains(build_net(r18, synth.reference_params(r18), max_batch=8, hw=224, options=fl))
     assert len(ks) == 3 and all(re.search(r', 1, (false|true), 8>$', k) for k in ks), ks       # stage 0 reads the max-pooled head output: bounded through the pool node
+
+
+def test_essential_vector_work_per_launch_follows_the_reference_semantics():
+    """f8_net_launch_valu (VERDICT r5 #1b): 3 lane-operations per int8 value a launch produces (in HBM or only in LDS), 2 per joined int32 value, 1 per
+    max-pooled conv value — checked by hand for the stage-0 chain and the head of ResNet-50 and as a whole-net total; scales with N."""
+    from f8net_amd import synth, topology
+    from f8net_amd.net import build_net
+    spec = topology.get('resnet50', normalize=True)
+    net = build_net(spec, synth.reference_params(spec, seed=1234), max_batch=128, hw=224, options={'whole_batch_launches': 1})
+    by = {net.launch_info(i, 1)[0].split(':')[0]: net.launch_valu(i, 1) for i in range(net.num_launches)}
+    px = 56 * 56
+    # opening block + 2 identity blocks at 56x56: per block body.0 / body.2 int8 outputs (64 + 64), the join (256 x 2), the next block's int8 input (256 x 3; last block: one int8 output form)
+    assert by['stage_chain_x3_ds'] == px * (3 * 2 * 64 * 3 + 3 * 256 * 2 + 2 * 256 * 3 + 3 * 256)
+    # head: one max per conv value (112 x 112 x 64), the requantisation on the pooled values
+    assert by['stem7x7s2+maxpool3x3s2'] == 112 * 112 * 64 + 3 * px * 64
+    total = sum(net.launch_valu(i, 1) for i in range(net.num_launches))
+    assert 30e6 < total < 45e6                                   # ~ 37 M per image (5 1/4 per stream value + 3 per inner value)
+    assert net.launch_valu(3, 128) == 128 * net.launch_valu(3, 1)
+    assert net.get_option('err_mirror') == 0                     # read-only state key: no mirror before the upload
+    with pytest.raises(Exception):
+        net.set_option('err_mirror', 1)
