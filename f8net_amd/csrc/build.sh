@@ -18,15 +18,16 @@ $HIPCC $FLAGS -c f8_wstat.hip -o ../../build/f8_wstat.o 2> ../../build/f8_wstat.
 $HIPCC $FLAGS -c f8_s2conv.hip -o ../../build/f8_s2conv.o 2> ../../build/f8_s2conv.log &
 $HIPCC $FLAGS -c f8_fc.hip -o ../../build/f8_fc.o 2> ../../build/f8_fc.log &
 $HIPCC $FLAGS -c f8_chain.hip -o ../../build/f8_chain.o 2> ../../build/f8_chain.log &
+$HIPCC $FLAGS -c f8_cchain.hip -o ../../build/f8_cchain.o 2> ../../build/f8_cchain.log &
 $HIPCC $FLAGS -c f8_bchain.hip -o ../../build/f8_bchain.o 2> ../../build/f8_bchain.log &
 $HIPCC $FLAGS -c f8_dwmma.hip -o ../../build/f8_dwmma.o 2> ../../build/f8_dwmma.log &
 $HIPCC $FLAGS -c f8_pool.hip -o ../../build/f8_pool.o 2> ../../build/f8_pool.log &
 $HIPCC $FLAGS -x hip -c f8_net.cpp -o ../../build/f8_net.o 2> ../../build/f8_net.log &
 wait
-for f in f8_kernels f8_fused f8_conv3x3 f8_stem f8_opener f8_ir f8_p12 f8_wreg f8_wstat f8_s2conv f8_fc f8_chain f8_bchain f8_dwmma f8_pool f8_net; do grep -E "error|warning:" ../../build/$f.log | grep -v Rpass || true; done
+for f in f8_kernels f8_fused f8_conv3x3 f8_stem f8_opener f8_ir f8_p12 f8_wreg f8_wstat f8_s2conv f8_fc f8_chain f8_cchain f8_bchain f8_dwmma f8_pool f8_net; do grep -E "error|warning:" ../../build/$f.log | grep -v Rpass || true; done
 # a failed compile leaves the previous object in place: the link below would silently ship stale code
 if grep -lE "(^|[^a-z])error( generated|:)" ../../build/f8_*.log; then echo "ERROR: compile errors (logs above)"; exit 1; fi
-$HIPCC --offload-arch=gfx950 -shared -fPIC ../../build/f8_kernels.o ../../build/f8_fused.o ../../build/f8_conv3x3.o ../../build/f8_stem.o ../../build/f8_opener.o ../../build/f8_ir.o ../../build/f8_p12.o ../../build/f8_wreg.o ../../build/f8_wstat.o ../../build/f8_s2conv.o ../../build/f8_fc.o ../../build/f8_chain.o ../../build/f8_bchain.o ../../build/f8_dwmma.o ../../build/f8_pool.o ../../build/f8_net.o -o $OUT
+$HIPCC --offload-arch=gfx950 -shared -fPIC ../../build/f8_kernels.o ../../build/f8_fused.o ../../build/f8_conv3x3.o ../../build/f8_stem.o ../../build/f8_opener.o ../../build/f8_ir.o ../../build/f8_p12.o ../../build/f8_wreg.o ../../build/f8_wstat.o ../../build/f8_s2conv.o ../../build/f8_fc.o ../../build/f8_chain.o ../../build/f8_cchain.o ../../build/f8_bchain.o ../../build/f8_dwmma.o ../../build/f8_pool.o ../../build/f8_net.o -o $OUT
 echo "built $(readlink -f $OUT)"
 # device probe of the float requantisation (f8_device.h requant_u8x4): a stand-alone binary, run by tests/test_gpu_requant_probe.py
 $HIPCC --offload-arch=gfx950 -O2 ../../tools/ubench/cvt_u8_probe.hip -o ../../tools/ubench/cvt_u8_probe.bin 2> ../../build/cvt_u8_probe.log || { echo "ERROR: cvt_u8_probe"; exit 1; }

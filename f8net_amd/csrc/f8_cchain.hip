@@ -1,0 +1,578 @@
+// f8_cchain.hip — the bottleneck identity blocks of a 7x7 stage (ResNet-50 stage 3: C = 2048, MID = 512) in ONE launch over CLUSTERS of
+// eight workgroups; the int32 residual stream stays in registers from block to block (gfx950).
+//
+// IntBlock.forward of /root/reference/models/fix_resnet.py:26-77 applied to consecutive blocks as IntModel.forward does (fix_resnet.py:361-366),
+// every int_op_only_fix_quant (fix_quant_ops.py:90-114) in place.  Same arguments, same planner entry and the same tests as f8_chain.hip
+// (ChainArgs, launch_chain); what differs is how the work is cut.
+//
+// Why a different cut.  A 7x7 map has 49 pixels and a block 4.4 MB of weights: a tile of rows (f8_chain.hip) would stream megabytes of weights
+// per 49 pixels, and the launches this replaces (fused_p12 + the residual-carrying 1x1: 65 us per block and 128 images) do exactly that — every
+// workgroup PAIR reads W0 twice and W2 once for ONE image at the L1's 32-64 B/clk, then the join launch moves the int32 stream (51 MB in, 51 MB
+// out) through HBM.  Here a cluster of G = 8 workgroups (8 CUs) owns IMG = 4 images (196 pixels = 7 pixel tiles of 32) and cuts every
+// convolution by OUTPUT CHANNEL:
+//   * stream: workgroup c keeps channels [256 c, 256 c + 256) of all 196 pixels in registers — wave w one 32-channel tile x 7 pixel tiles
+//     = 112 registers per lane, as in f8_chain.hip;
+//   * P1 (1x1, K = 2048): workgroup c computes mid channels [64 c, 64 c + 64) for all pixels — it streams 128 KB of W0, not 1 MB;
+//   * P2 (3x3, K = 4608): mid2 channels [64 c, 64 c + 64) — 288 KB of W2, not 1.18 MB;
+//   * P3 (1x1, K = 512) + join: its 256 stream channels — 128 KB of W4, register-resident per wave.
+// A cluster reads each block's weights ONCE for four images (the pair design: twice per image), and the stream never touches memory.
+// The price: every phase needs ALL channels of its input, so the cluster exchanges its int8 activations three times per block through
+// memory — x8 (448 KB), mid1 and mid2 (112 KB each), written by their producers in MFMA-B-FRAGMENT order ([pixel tile][K32 step][lane][16 B]:
+// what a lane holds after the epilogue's two permlane swaps IS its 16 bytes of the consumer's B fragment), so every exchange store and load is a
+// contiguous 1 KB per wave instruction and the consumers' LDS images are straight LDS-DMA copies.  Protocol: f8_chain.hip's (write-through
+// stores, drain, barrier, one flag per workgroup and exchange number; consumers poll the seven others' flags, bounded; agent-scope loads) —
+// placement-independent: a workgroup's place is a ticket, the eight members of a cluster are consecutive tickets, so the set of started
+// workgroups is a prefix of the logical grid and only the cluster whose last member has not started yet waits.
+//
+// Phases of a block on one workgroup (512 threads = 8 waves, 2 per SIMD, 256 registers each):
+//   P1: operands through an LDS ring of D1 = 3 chunks (a chunk = 4 K32 steps: 7 x8 fragments + 2 weight fragments each, LDS-DMA, no registers
+//       in flight — the stream holds 112 of them); wave (pp, kh) multiplies pixel tiles 2 pp, 2 pp + 1 by both channel tiles over K half kh
+//       (2 x 2 register block), the halves are added through LDS, epilogue -> mid1 -> exchange;
+//   P2: mid1 of the whole cluster in LDS (112 KB, fragment order; a tap of a lane's pixel is another lane's slot of another fragment: one per-lane
+//       base per (pixel tile, tap), out-of-image taps point at 8 KB of biased zeros), W2 through a ring of D2 = 4 chunks of 8 fragments; same
+//       wave roles, K cut by half a tap's channels; epilogue -> mid2 -> exchange;
+//   P3: mid2 of the whole cluster in LDS, the wave's 16 W4 fragments and its bias in registers; per pixel tile 16 MFMAs, then the join with the
+//       stream registers, ReLU, requantisation -> x8' -> exchange (or, after the last block, the stage's output forms).
+#include "f8_device.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+namespace f8 {
+
+struct CCfg {
+    static constexpr int C = 2048, MID = 512, PXI = 49, IMG = 4, NPX = PXI * IMG, NPT = 7, G = 8;
+    static constexpr int CT = C / 32, CM = MID / 32, CTC = CT / G, CMC = CM / G;      // channel tiles: stream 64, mid 16; per workgroup 8 / 2
+    static constexpr int NK1 = C / 32, KK = MID / 32;                                   // K32 steps of body.0 / body.4 (body.2: 9 taps x KK)
+    // exchange buffers of one cluster (fragment order)
+    static constexpr int X8_BYTES = NPT * NK1 * 1024, M_BYTES = NPT * KK * 1024;
+    static constexpr int OFF_M1 = X8_BYTES, OFF_M2 = X8_BYTES + M_BYTES, XCL_BYTES = X8_BYTES + 2 * M_BYTES;
+    // LDS
+    static constexpr int PATCH_BYTES = M_BYTES;                                         // mid1 (P2) / mid2 (P3) of the whole cluster
+    static constexpr int ZERO_BYTES = 8192;                                             // biased zeros: what out-of-image taps read (8 K32 steps deep)
+    static constexpr int D1 = 3, CH1_FR = 40, CH1_BYTES = CH1_FR * 1024;                 // P1 ring: 32 x8 fragments (tile 7 = dummy) + 8 weight fragments per chunk
+    static constexpr int D2 = 4, CH2_BYTES = 8 * 1024;                                  // P2 ring: 8 weight fragments per chunk
+    static constexpr int OFF_ZERO = PATCH_BYTES, OFF_RING2 = PATCH_BYTES + ZERO_BYTES;
+    static constexpr int OFF_BIAS = OFF_RING2 + D2 * CH2_BYTES, BIAS_INTS = 32 * (2 * CMC + CTC);
+    static constexpr int OFF_MISC = OFF_BIAS + BIAS_INTS * 4, LDS_BYTES = OFF_MISC + 256;
+    static_assert(D1 * CH1_BYTES <= OFF_RING2, "the P1 ring lives in the patch's bytes (dead during P1)");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+constexpr size_t kCChainXchgBytes = (size_t)32 * CCfg::XCL_BYTES;                        // 32 clusters = 256 workgroups
+
+// 16 accumulator values of one 32x32 tile (this lane: one pixel, channels 8g + 4 lh + e) -> this lane's 16 bytes of the consumer's fragment
+// (f8_chain.hip quant_tile16: FAST 0 = any format, 1 = float converter, 2 = integer v_ashr_pk_u8_i32)
+template <int FAST>
+__device__ __forceinline__ v4i cq_tile16(const v16i& y, int n, int lo, int hi, unsigned x_or) {
+    unsigned d[4];
+    const float sc = FAST == 1 ? requant_u8_scale(n) : 0.0f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if constexpr (FAST == 1) d[g] = requant_u8x4(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], sc) ^ x_or;
+        else if constexpr (FAST == 2) d[g] = requant_u8x4_int(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3], n) ^ x_or;
+        else d[g] = pack4(requant1(y[4 * g], n, lo, hi), requant1(y[4 * g + 1], n, lo, hi), requant1(y[4 * g + 2], n, lo, hi), requant1(y[4 * g + 3], n, lo, hi)) ^ x_or;
+    }
+    auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+    auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+    const v4i o = {(int)s0[0], (int)s0[1], (int)s1[0], (int)s1[1]};
+    return o;
+}
+
+#define F8_LDS3(p) ((__attribute__((address_space(3))) void*)(p))
+
+// barrier that leaves vector-memory operations (the LDS-DMA ring) in flight: __syncthreads() drains them (s_waitcnt vmcnt(0) in front of every s_barrier —
+// each ring stage then exposes its whole latency); LDS accesses are complete, and no memory access moves across it
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// FAST as in chain_kernel: 0 = generic formats, 1 / 2 = ReLU everywhere, unsigned 8-bit formats with right shifts, the stream unshifted;
+// requantisation through the float converter (1: bounded values, shifts <= 16) or in integer operations (2: the default plan)
+template <int FAST>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+cchain_kernel(const ChainArgs a) {
+    using Cfg = CCfg;
+    constexpr int C = Cfg::C, NPT = Cfg::NPT, NK1 = Cfg::NK1, KK = Cfg::KK;
+    if constexpr (FAST == 1) set_fp_round_nearest_even();
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* const ring2 = lds + Cfg::OFF_RING2;
+    int* const bias_lds = (int*)(lds + Cfg::OFF_BIAS);         // b0 (64: this workgroup's two mid tiles) | b2 (64) | b4 (256: its eight stream tiles)
+    int* const misc = (int*)(lds + Cfg::OFF_MISC);
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;
+    const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+    const unsigned l16 = (unsigned)(lane * 16);
+    const int pp = wave & 3, kh = wave >> 2;                   // P1 / P2 role: pixel-tile pair, K half
+
+    if (tid == 0) misc[0] = (int)__hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int L = __builtin_amdgcn_readfirstlane(misc[0]);
+    const int cl = L >> 3, c = L & 7;                          // cluster, member
+    const int ncl = (int)(gridDim.x >> 3);
+    const int ngroups = (a.N + Cfg::IMG - 1) / Cfg::IMG;
+    const int npix = a.N * Cfg::PXI;
+    unsigned* const flags = a.sync + 16;
+    const unsigned long long t_limit = (unsigned long long)a.timeout_ticks;
+    unsigned seq = 0;
+#ifdef F8_TRACE
+    unsigned tt[12] = {}; unsigned t_prev = (unsigned)__builtin_readcyclecounter();
+#define F8_CT(i) do { const unsigned now_ = (unsigned)__builtin_readcyclecounter(); tt[i] += now_ - t_prev; t_prev = now_; } while (0)
+#else
+#define F8_CT(i)
+#endif
+
+    const __amdgpu_buffer_rsrc_t rxc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xchg + (size_t)cl * Cfg::XCL_BYTES), 0, (unsigned)Cfg::XCL_BYTES, 0x00020000);
+    auto wrsrc = [](const int8_t* p) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7ffffff0, 0x00020000); };
+
+    // ---- exchange: every storing wave drains, barrier, one flag store; then the seven others' flags (bounded), barrier
+    auto publish = [&]() {
+        ++seq;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flags + L, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto wait_all = [&]() {
+        if (tid < Cfg::G && tid != c) {
+            unsigned* const f = flags + cl * Cfg::G + tid;
+            const unsigned long long t0 = wall_clock64();
+            bool ok = true;
+            while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > t_limit) { ok = false; break; }
+                if ((__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 8) == a.epoch) break;   // another workgroup of THIS run gave up
+            }
+            if (!ok) {       // a member that never arrives: sticky error word, the launch runs on without waiting (f8_chain.hip)
+                __hip_atomic_store(a.err, (a.epoch << 8) | 0x80u | ((unsigned)seq & 0x3fu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.err_host) __hip_atomic_store(a.err_host, (a.epoch << 8) | 0x80u | ((unsigned)seq & 0x3fu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        __syncthreads();
+    };
+    // the whole cluster's mid1 / mid2 (112 fragments) -> LDS [0, 112 KB): 14 LDS-DMA instructions per wave
+    auto load_patch = [&](int off) {
+#pragma unroll
+        for (int k = 0; k < 14; ++k) {
+            const int e = wave * 14 + k;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxc, F8_LDS3(lds + e * 1024), 16, l16, off + e * 1024, 0, 17);
+        }
+    };
+
+    v16i res[NPT];                                             // the stream: this wave's channel tile (8 c + wave) x 7 pixel tiles
+    const int ct = c * Cfg::CTC + wave;
+
+    for (int grp = cl; grp < ngroups; grp += ncl) {
+        const int m0 = grp * Cfg::NPX;                         // first global pixel of the group
+        // =============================== stage input: the stream (I32T) -> registers; its int8 form -> exchange
+        {
+            const ChainBlk& B0 = a.blk[0];
+            const __amdgpu_buffer_rsrc_t rxr = __builtin_amdgcn_make_buffer_rsrc((void*)a.xr, 0, (unsigned)(((npix + 31) & ~31) * C * 4), 0x00020000);
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) {
+                const int p = j * 32 + l31, m = m0 + p;
+                const unsigned vo = (p < Cfg::NPX && m < npix) ? (unsigned)((m >> 5) * (C * 128) + lh * 512 + (m & 31) * 16) : kOOB;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const v4i v = __builtin_amdgcn_raw_buffer_load_b128(rxr, vo + g * 1024, ct * 4096, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) res[j][4 * g + e] = v[e];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) {
+                const v4i o = cq_tile16<FAST>(res[j], B0.nq, FAST ? 0 : B0.loq, FAST ? 255 : B0.hiq, FAST ? 0x80808080u : B0.xorq);
+                __builtin_amdgcn_raw_buffer_store_b128(o, rxc, l16, (j * NK1 + ct) * 1024, 17);
+            }
+            publish();
+            F8_CT(0);
+        }
+
+        for (int b = 0; b < a.nblk; ++b) {
+            const ChainBlk& B = a.blk[b];
+            const bool last = b + 1 == a.nblk;
+            const ChainBlk& BN = a.blk[last ? b : b + 1];
+            const int n1 = B.n1, n2 = B.n2, acc_shl = B.acc_shl, res_shl = B.res_shl;
+            const int lo1 = FAST ? 0 : B.lo1, hi1 = FAST ? 255 : B.hi1, lo2 = FAST ? 0 : B.lo2, hi2 = FAST ? 255 : B.hi2;
+            const unsigned xor1 = FAST ? 0x80808080u : B.xor1, xor2 = FAST ? 0x80808080u : B.xor2;
+            const int relu_a = FAST ? 1 : B.relu_a, relu_b = FAST ? 1 : B.relu_b, relu1 = FAST ? 1 : B.relu1;
+            const int nq = BN.nq, loq = FAST ? 0 : BN.loq, hiq = FAST ? 255 : BN.hiq;
+            const unsigned xorq = FAST ? 0x80808080u : BN.xorq;
+
+            // ---- this block's biases -> LDS (read from P1's epilogue on; the previous block's were last read at the top of its P3)
+            {
+                int bv = 0;
+                if (tid < 64) bv = B.b0[c * 64 + tid];
+                else if (tid < 128) bv = B.b2[c * 64 + tid - 64];
+                else if (tid < Cfg::BIAS_INTS) bv = B.b4[c * 256 + tid - 128];
+                if (tid < Cfg::BIAS_INTS) bias_lds[tid] = bv;
+            }
+            wait_all();                                         // x8 of the whole cluster is in memory
+            F8_CT(1);
+
+            // =============================== P1: mid1[64 c ..] = requant(relu(W0 . x8 + b0))
+            {
+                const __amdgpu_buffer_rsrc_t rw0 = wrsrc(B.w0);
+                v16i acc[2][2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[jj][i][r] = 0;
+                constexpr int NCH = NK1 / 4, D = Cfg::D1, NI = 5;
+                // chunk q: K32 steps 2q, 2q + 1 (K half 0) and 32 + 2q, 33 + 2q (K half 1); LDS image: fragment e = 4 j + t (x8, j = 0 .. 7) / 32 + 4 i + t (W0)
+                auto issue = [&](int q) {
+                    char* const slot = lds + (q % D) * Cfg::CH1_BYTES;
+#pragma unroll
+                    for (int k = 0; k < NI; ++k) {
+                        const int e = wave * NI + k, t = e & 3;
+                        const int step = t < 2 ? 2 * q + t : 32 + 2 * q + (t - 2);
+                        if (e < 32) {
+                            const int j = e >> 2;
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxc, F8_LDS3(slot + e * 1024), 16, j < NPT ? l16 : kOOB, (j * NK1 + step) * 1024, 0, 17);
+                        } else {
+                            const int i = (e - 32) >> 2;
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw0, F8_LDS3(slot + e * 1024), 16, l16, ((c * 2 + i) * NK1 + step) * 1024, 0, 0);
+                        }
+                    }
+                };
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                issue(0); issue(1);
+                const unsigned bb = (unsigned)((pp * 8 + kh * 2) * 1024) + l16, ab = (unsigned)((32 + kh * 2) * 1024) + l16;
+                static_for<NCH>([&](auto qc) {
+                    constexpr int Q = decltype(qc)::value;
+                    constexpr int younger = (Q + D - 2 < NCH - 1 ? Q + D - 2 : NCH - 1) - Q;
+                    wait_vmcnt<younger * NI>();
+                    lds_barrier();
+                    if constexpr (Q + D - 1 < NCH) issue(Q + D - 1);
+                    const char* const slot = lds + (Q % D) * Cfg::CH1_BYTES;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const v4i a0 = *(const v4i*)(slot + ab + s * 1024), a1 = *(const v4i*)(slot + ab + (4 + s) * 1024);
+                        const v4i b0 = *(const v4i*)(slot + bb + s * 1024), b1 = *(const v4i*)(slot + bb + (4 + s) * 1024);
+                        acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc[0][0], 0, 0, 0);
+                        acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc[0][1], 0, 0, 0);
+                        acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[1][0], 0, 0, 0);
+                        acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
+                    }
+                });
+                F8_CT(2);
+                __syncthreads();                                // the ring is dead: its bytes carry the K halves' exchange
+                // wave (pp, kh) finishes channel tile kh of its two pixel tiles: it gives away its sums for tile 1 - kh and takes the partner's for tile kh
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        v4i o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = kh ? acc[jj][0][4 * g + e] : acc[jj][1][4 * g + e];
+                        *(v4i*)(lds + (wave * 8 + jj * 4 + g) * 1024 + l16) = o;
+                    }
+                __syncthreads();
+                const int floor0 = relu_a ? 0 : INT32_MIN;
+                const int ctm = c * 2 + kh;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    v16i y;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const v4i o = *(const v4i*)(lds + ((wave ^ 4) * 8 + jj * 4 + g) * 1024 + l16);
+                        const v4i bv = *(const v4i*)(bias_lds + kh * 32 + 8 * g + 4 * lh);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned mine = (unsigned)(kh ? acc[jj][1][4 * g + e] : acc[jj][0][4 * g + e]);
+                            y[4 * g + e] = (int)(mine + (unsigned)o[e] + (unsigned)bv[e]);
+                            if constexpr (!FAST) y[4 * g + e] = max(y[4 * g + e], floor0);
+                        }
+                    }
+                    const int j = pp * 2 + jj;
+                    const v4i o = cq_tile16<FAST>(y, n1, lo1, hi1, xor1);
+                    if (j < NPT) __builtin_amdgcn_raw_buffer_store_b128(o, rxc, l16, Cfg::OFF_M1 + (j * KK + ctm) * 1024, 17);
+                }
+                publish();
+                F8_CT(3);
+            }
+            {   // zeros for the out-of-image taps: [112 KB, 120 KB) — the barrier inside publish() is behind every read of the K-half exchange
+                const v4i zv = {(int)xor1, (int)xor1, (int)xor1, (int)xor1};
+                *(v4i*)(lds + Cfg::OFF_ZERO + tid * 16) = zv;
+            }
+            wait_all();                                         // mid1 of the whole cluster is in memory
+            F8_CT(4);
+
+            // =============================== P2: mid2[64 c ..] = requant(relu(conv3x3(mid1) + b2))
+            {
+                const __amdgpu_buffer_rsrc_t rw2 = wrsrc(B.w2);
+                load_patch(Cfg::OFF_M1);
+                constexpr int NCH = 36, D = Cfg::D2;
+                // chunk q: tap q / 4, channel steps 2 (q % 4) + {0, 1} of each half-tap; LDS image: fragment e = 4 i + t
+                auto issue = [&](int q) {
+                    const int e = wave, i = e >> 2, t = e & 3;
+                    const int step = (q >> 2) * KK + (t < 2 ? 0 : 8) + 2 * (q & 3) + (t & 1);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw2, F8_LDS3(ring2 + (q % D) * Cfg::CH2_BYTES + e * 1024), 16, l16, ((c * 2 + i) * (9 * KK) + step) * 1024, 0, 0);
+                };
+                issue(0); issue(1); issue(2);
+                // LDS offset of tap (ty, tx) of this lane's pixel in the fragment-order patch, K half included; out-of-image: the zeros.  Derived per TAP from
+                // the lane's row / column (kept: two registers per pixel tile; all 18 offsets at once were what the allocator spilled)
+                int prow[2], pcol[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int p = (pp * 2 + jj) * 32 + l31;
+                    const int rem = p % Cfg::PXI, r = rem / 7;
+                    prow[jj] = p < Cfg::NPX ? r : 64; pcol[jj] = rem - r * 7;             // row 64: every tap of a padding lane is out of the image
+                }
+                unsigned tb[2] = {0u, 0u};
+                auto tap_base = [&](auto tc) {
+                    constexpr int T = decltype(tc)::value, TY = T / 3 - 1, TX = T % 3 - 1;
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int q = (pp * 2 + jj) * 32 + l31 + TY * 7 + TX;
+                        const bool ok = (unsigned)(prow[jj] + TY) < 7u && (unsigned)(pcol[jj] + TX) < 7u;
+                        tb[jj] = ok ? (unsigned)((q >> 5) * (KK * 1024) + kh * 8192 + lh * 512 + (q & 31) * 16) : (unsigned)Cfg::OFF_ZERO + l16;
+                    }
+                };
+                v16i acc[2][2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[jj][i][r] = 0;
+                const unsigned ab = (unsigned)(kh * 2 * 1024) + l16;
+                static_for<NCH>([&](auto qc) {
+                    constexpr int Q = decltype(qc)::value, T = Q / 4;
+                    constexpr int younger = (Q + D - 2 < NCH - 1 ? Q + D - 2 : NCH - 1) - Q;
+                    wait_vmcnt<younger>();
+                    lds_barrier();
+                    if constexpr (Q + D - 1 < NCH) issue(Q + D - 1);
+                    if constexpr (Q % 4 == 0) tap_base(std::integral_constant<int, T>{});
+                    const char* const slot = ring2 + (Q % D) * Cfg::CH2_BYTES;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const v4i a0 = *(const v4i*)(slot + ab + s * 1024), a1 = *(const v4i*)(slot + ab + (4 + s) * 1024);
+                        const v4i b0 = *(const v4i*)(lds + tb[0] + (2 * (Q % 4) + s) * 1024), b1 = *(const v4i*)(lds + tb[1] + (2 * (Q % 4) + s) * 1024);
+                        acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc[0][0], 0, 0, 0);
+                        acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc[0][1], 0, 0, 0);
+                        acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[1][0], 0, 0, 0);
+                        acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
+                    }
+                });
+                F8_CT(5);
+                __syncthreads();                                // nobody reads the patch any more: its bytes carry the K halves' exchange
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        v4i o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = kh ? acc[jj][0][4 * g + e] : acc[jj][1][4 * g + e];
+                        *(v4i*)(lds + (wave * 8 + jj * 4 + g) * 1024 + l16) = o;
+                    }
+                __syncthreads();
+                const int floor0 = relu_b ? 0 : INT32_MIN;
+                const int ctm = c * 2 + kh;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    v16i y;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const v4i o = *(const v4i*)(lds + ((wave ^ 4) * 8 + jj * 4 + g) * 1024 + l16);
+                        const v4i bv = *(const v4i*)(bias_lds + 64 + kh * 32 + 8 * g + 4 * lh);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned mine = (unsigned)(kh ? acc[jj][1][4 * g + e] : acc[jj][0][4 * g + e]);
+                            y[4 * g + e] = (int)(mine + (unsigned)o[e] + (unsigned)bv[e]);
+                            if constexpr (!FAST) y[4 * g + e] = max(y[4 * g + e], floor0);
+                        }
+                    }
+                    const int j = pp * 2 + jj;
+                    const v4i o = cq_tile16<FAST>(y, n2, lo2, hi2, xor2);
+                    if (j < NPT) __builtin_amdgcn_raw_buffer_store_b128(o, rxc, l16, Cfg::OFF_M2 + (j * KK + ctm) * 1024, 17);
+                }
+                publish();
+                F8_CT(6);
+            }
+
+            // =============================== P3: stream' = clamp((W4 . mid2 + b4) << sa + (stream << sr)) [ReLU]; x8' = requant(stream')
+            {
+                const __amdgpu_buffer_rsrc_t rw4 = wrsrc(B.w4);
+                v4i wst[KK];                                    // this wave's weights: channel tile ct, all 16 K32 steps (requested before the wait)
+#pragma unroll
+                for (int k = 0; k < KK; ++k) wst[k] = __builtin_amdgcn_raw_buffer_load_b128(rw4, l16, (ct * KK + k) * 1024, 0);
+                v16i breg;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const v4i bv = *(const v4i*)(bias_lds + 128 + wave * 32 + 8 * g + 4 * lh);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) breg[4 * g + e] = bv[e];
+                }
+                wait_all();                                     // mid2 of the whole cluster is in memory
+                F8_CT(7);
+                load_patch(Cfg::OFF_M2);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                F8_CT(8);
+                const int floor1 = relu1 ? 0 : -2147483647;     // the join's clamp_(min=-(2^31-1)) and the ReLU floor are one max
+                static_for<NPT>([&](auto jc) {
+                    constexpr int J = decltype(jc)::value;
+                    v16i acc;
+#pragma unroll
+                    for (int k = 0; k < KK; ++k) {
+                        const v4i xf = *(const v4i*)(lds + (J * KK + k) * 1024 + l16);
+                        if (k == 0) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wst[k], xf, breg, 0, 0, 0);
+                        else acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wst[k], xf, acc, 0, 0, 0);
+                    }
+                    v16i& rr = res[J];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if constexpr (FAST) rr[r] = max((int)(((unsigned)acc[r] << acc_shl) + (unsigned)rr[r]), 0);
+                        else rr[r] = max((int)(((unsigned)acc[r] << acc_shl) + ((unsigned)rr[r] << res_shl)), floor1);
+                    }
+                    if (!last) {
+                        const v4i o = cq_tile16<FAST>(rr, nq, loq, hiq, xorq);
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rxc, l16, (J * NK1 + ct) * 1024, 17);
+                    } else if (!a.pool) {
+                        const int p = J * 32 + l31, m = m0 + p;
+                        if (p < Cfg::NPX && m < npix) {
+                            const unsigned tot = (unsigned)(((npix + 31) & ~31) * C);
+                            if (a.out32) {
+                                const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)a.out32, 0, tot * 4u, 0x00020000);
+                                const unsigned vo = (unsigned)((m >> 5) * (C * 128) + lh * 512 + (m & 31) * 16);
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) {
+                                    const v4i o = {rr[4 * g], rr[4 * g + 1], rr[4 * g + 2], rr[4 * g + 3]};
+                                    __builtin_amdgcn_raw_buffer_store_b128(o, ro, vo + g * 1024, ct * 4096, 0);
+                                }
+                            }
+#pragma unroll
+                            for (int k = 0; k < 2; ++k)
+                                if (a.q[k].ptr) {
+                                    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)a.q[k].ptr, 0, tot, 0x00020000);
+                                    __builtin_amdgcn_raw_buffer_store_b128(cq_tile16<0>(rr, a.q[k].n, a.q[k].lo, a.q[k].hi, a.q[k].bias_xor), rq, (unsigned)(m * C + 16 * lh), ct * 32, 0);
+                                }
+                        }
+                    }
+                });
+                if (last && a.pool) {
+                    // FXQAvgPool2d (fix_quant_ops.py:126-134, int branch): the wrapping int32 sum over each image's 49 pixels, from the stream registers.  A lane holds
+                    // pixel 32 j + l31 of the group's four images in tile j; per channel: the lane's share of each image (compile-time lane ranges), then a
+                    // butterfly whose first two steps hand two / one of the four sums to the partner lane — every lane ends with the total of image (lane & 3)
+                    const bool b0 = lane & 1, b1 = lane & 2;
+                    const int n_img = grp * Cfg::IMG + (lane & 3);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        unsigned tot[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            unsigned sm[Cfg::IMG];
+                            static_for<Cfg::IMG>([&](auto ic) {
+                                constexpr int I = decltype(ic)::value, LO = I * Cfg::PXI, HI = LO + Cfg::PXI;
+                                unsigned acc_i = 0;
+                                static_for<NPT>([&](auto jc) {
+                                    constexpr int J = decltype(jc)::value;
+                                    if constexpr (J * 32 < HI && J * 32 + 32 > LO) {
+                                        constexpr int L0 = LO - J * 32, L1 = HI - J * 32;      // this image's lanes of tile J: [L0, L1)
+                                        acc_i += (l31 >= L0 && l31 < L1) ? (unsigned)res[J][4 * g + e] : 0u;
+                                    }
+                                });
+                                sm[I] = acc_i;
+                            });
+                            const unsigned u0 = (b0 ? sm[1] : sm[0]) + (unsigned)__shfl_xor((int)(b0 ? sm[0] : sm[1]), 1);
+                            const unsigned u1 = (b0 ? sm[3] : sm[2]) + (unsigned)__shfl_xor((int)(b0 ? sm[2] : sm[3]), 1);
+                            unsigned v = (b1 ? u1 : u0) + (unsigned)__shfl_xor((int)(b1 ? u0 : u1), 2);
+                            v += (unsigned)__shfl_xor((int)v, 4); v += (unsigned)__shfl_xor((int)v, 8); v += (unsigned)__shfl_xor((int)v, 16);
+                            tot[e] = v;
+                        }
+                        if (l31 < Cfg::IMG && n_img < a.N) {
+                            const int ch = ct * 32 + 8 * g + 4 * lh;
+                            if (a.out32) { const v4i o = {(int)tot[0], (int)tot[1], (int)tot[2], (int)tot[3]}; *(v4i*)(a.out32 + i32t_index(n_img, ch, C)) = o; }
+#pragma unroll
+                            for (int k = 0; k < 2; ++k)
+                                if (a.q[k].ptr)
+                                    *(unsigned*)(a.q[k].ptr + (size_t)n_img * C + ch) =
+                                        pack4(requant1((int)tot[0], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1((int)tot[1], a.q[k].n, a.q[k].lo, a.q[k].hi),
+                                              requant1((int)tot[2], a.q[k].n, a.q[k].lo, a.q[k].hi), requant1((int)tot[3], a.q[k].n, a.q[k].lo, a.q[k].hi)) ^ a.q[k].bias_xor;
+                        }
+                    }
+                }
+                F8_CT(9);
+                if (!last) publish();
+                else __syncthreads();                           // the next group's P1 ring overwrites mid2
+                F8_CT(10);
+            }
+        }
+    }
+    // ---- re-arm ticket and flags for the next launch on this scratch (f8_chain.hip): the last workgroup out zeroes them
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        misc[2] = (__hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) ? 1 : 0;
+    }
+    __syncthreads();
+    if (misc[2]) {
+        for (int i = tid; i < (int)gridDim.x; i += 512) __hip_atomic_store(flags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) { __hip_atomic_store(a.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(a.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    }
+#ifdef F8_TRACE
+    if (a.trace && lane == 0) {
+        unsigned* tp = (unsigned*)a.trace + ((size_t)blockIdx.x * 8 + wave) * 16;
+        for (int i = 0; i < 12; ++i) tp[i] = tt[i];
+        tp[12] = (unsigned)L;
+    }
+#endif
+}
+
+bool cchain_supported(int C, int MID, int H, int W, int cin0) { return C == 2048 && MID == 512 && H == 7 && W == 7 && cin0 == 2048; }
+size_t cchain_xchg_bytes() { return kCChainXchgBytes; }
+// clusters (of 8 workgroups, 4 images per round) a launch over N images starts on a device with `slots` free compute units
+int cchain_clusters(int N, int slots) {
+    const int groups = (N + CCfg::IMG - 1) / CCfg::IMG, cap = std::min(slots / CCfg::G, 32);
+    if (cap < 1) return 0;
+    const int rounds = (groups + cap - 1) / cap;
+    return (groups + rounds - 1) / rounds;                      // the fewest clusters that need no more rounds
+}
+int cchain_kernel_name(char* buf, size_t cap, int fast) { return snprintf(buf, cap, "f8::cchain_kernel<%d>", fast); }
+
+template <int FAST>
+static hipError_t launch_cchain_t(const ChainArgs& a, hipStream_t s) {
+    static unsigned long long attr_done = 0; int attr_dev = -1;
+    if (!dyn_lds_opted_in(&attr_done, &attr_dev)) {
+        hipError_t e = hipFuncSetAttribute((const void*)cchain_kernel<FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, CCfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        if (attr_dev >= 0) attr_done |= 1ull << attr_dev;
+    }
+    const int grid = a.NG * CCfg::G;
+    if (a.NG < 1 || grid > 256 || !a.xr || a.tail) return hipErrorInvalidValue;
+#ifdef F8_TRACE
+    static unsigned* tbuf = nullptr; static int count = 0;
+    static const int want = [] { const char* e = getenv("F8_TRACE_CHAIN7"); return e ? atoi(e) : -1; }();
+    ChainArgs b = a;
+    const bool tracing = (count++ == want);
+    if (tracing) { if (!tbuf) (void)hipMalloc((void**)&tbuf, (size_t)256 * 8 * 64); (void)hipMemsetAsync(tbuf, 0, (size_t)grid * 8 * 64, s); b.trace = tbuf; }
+    hipLaunchKernelGGL((cchain_kernel<FAST>), dim3(grid), dim3(512), CCfg::LDS_BYTES, s, b);
+    if (tracing) {
+        (void)hipStreamSynchronize(s);
+        static unsigned hb[256 * 8 * 16];
+        (void)hipMemcpy(hb, tbuf, (size_t)grid * 8 * 64, hipMemcpyDeviceToHost);
+        static const char* nm[11] = {"stage-in+publish", "wait x8", "P1 loop", "P1 epilogue+publish", "wait mid1", "P2 loop", "P2 epilogue+publish", "wait mid2", "P3 patch load", "P3 compute", "P3 publish"};
+        for (int w : {0, 3, 4, 7}) {
+            double ph[12] = {};
+            for (int i = 0; i < grid; ++i) for (int k = 0; k < 12; ++k) ph[k] += (double)hb[((size_t)i * 8 + w) * 16 + k];
+            fprintf(stderr, "[trace cchain<%d>] grid %d, %d blocks, N %d, wave %d: avg cycles per WG (whole launch):", FAST, grid, a.nblk, a.N, w);
+            double tot = 0;
+            for (int k = 0; k < 11; ++k) { fprintf(stderr, " %s %.0f |", nm[k], ph[k] / grid); tot += ph[k] / grid; }
+            fprintf(stderr, " total %.0f\n", tot);
+        }
+    }
+#else
+    hipLaunchKernelGGL((cchain_kernel<FAST>), dim3(grid), dim3(512), CCfg::LDS_BYTES, s, a);
+#endif
+    return hipGetLastError();
+}
+
+// fast: chain_fast(a) (f8_chain.hip)
+hipError_t launch_cchain(const ChainArgs& a, int fast, hipStream_t s) {
+    return fast == 1 ? launch_cchain_t<1>(a, s) : fast == 2 ? launch_cchain_t<2>(a, s) : launch_cchain_t<0>(a, s);
+}
+
+}  // namespace f8

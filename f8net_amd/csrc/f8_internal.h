@@ -27,6 +27,7 @@ struct Options {
     int fuse_bchain = 2;         // consecutive BasicBlock identity blocks of a stage in ONE launch (f8_bchain.hip); 2: with the stage-opening block in front of them
     int fuse_chain = 1;          // all consecutive bottleneck blocks of a stage in ONE launch, int32 residual stream in registers (f8_chain.hip)
                                  // with the same number of rounds (224): groups that finish a round early free their CUs for the next batch's launches
+    int fuse_chain7 = 1;         // ... and the identity blocks of a 7x7 bottleneck stage over clusters of eight workgroups (f8_cchain.hip); 0: fused_p12 + the residual-carrying 1x1
     int fuse_pool = 1;           // the network's last 1x1 conv (+ residual join) and the average pool behind it in one launch (f8_pool.hip)
     int fuse_tail = 1;           // ... and the JOIN of a stride-2 stage-opening block as the first block of its stage's chain (its body.0 + body.2 on f8_opener.hip, P12)
     int chain_timeout_ms = 10000; // bound of its halo-exchange spins (another process holding the CUs for longer: sticky error word, logits poisoned, f8_net_check)
@@ -223,6 +224,7 @@ struct ChainArgs {
     uint32_t timeout_ticks;                // bound of every spin (100 MHz wall clock)
     void* trace;
     int32_t R;                             // rows per tile of the instance to launch (chain_shape)
+    int32_t pool;                          // f8_cchain.hip only: out32 / q[] are forms of the AVERAGE POOL behind the last block ([N][C]: FXQAvgPool2d's wrapping int32 sum over the map)
 };
 constexpr int kChainSyncWords = 16 + 512;   // [0] ticket, [1] workgroups out, [16 + workgroup] halo flags (up to two workgroups per CU)
 constexpr int kChainErrWord = 1000;          // the sticky error word, inside the first 4096 bytes of the scratch
@@ -335,6 +337,13 @@ int chain_max_blocks(int C, int MID, int H, int W, int cin0, bool tail);
 void chain_shape(int C, int MID, int H, int W, int cin0, bool tail, int* R, int* wg_per_cu);
 hipError_t launch_chain(const ChainArgs& a, int C, int MID, int H, int W, int cin0, hipStream_t s, char* launched = nullptr, size_t cap = 0);   // launched: the symbol it started
 int chain_kernel_name(char* buf, size_t cap, int C, int MID, int H, int W, int cin0, bool tail, int fast);   // the symbol launch_chain starts (f8_chain.hip)
+// the identity blocks of a 7x7 bottleneck stage over clusters of eight workgroups (f8_cchain.hip): reached through chain_supported / launch_chain
+bool cchain_supported(int C, int MID, int H, int W, int cin0);
+size_t cchain_xchg_bytes();                                      // exchange scratch of a launch (per arena copy)
+int cchain_clusters(int N, int slots);                           // clusters (ChainArgs::NG) a launch over N images starts on `slots` compute units
+int cchain_kernel_name(char* buf, size_t cap, int fast);
+int chain_fast(const ChainArgs& a);                              // f8_chain.hip: 0 = generic instance, 1 = float-converter requantisation, 2 = integer
+hipError_t launch_cchain(const ChainArgs& a, int fast, hipStream_t s);
 // consecutive BasicBlock identity blocks of a stage in one launch (f8_bchain.hip)
 bool bchain_supported(int C, int H, int W);
 bool bchain_ds_supported(int C, int H, int W);

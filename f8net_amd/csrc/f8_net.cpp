@@ -294,6 +294,7 @@ static const OptKey kOptKeys[] = {
     {"fuse_p12", "F8_FUSE_P12", &Options::fuse_p12, 0, 1, true},
     {"fuse_chain", "F8_FUSE_CHAIN", &Options::fuse_chain, 0, 1, true},
     {"fuse_tail", "F8_FUSE_TAIL", &Options::fuse_tail, 0, 1, true},
+    {"fuse_chain7", "F8_FUSE_CHAIN7", &Options::fuse_chain7, 0, 1, true},
     {"fuse_pool", "F8_FUSE_POOL", &Options::fuse_pool, 0, 1, true},
     {"fuse_bchain", "F8_FUSE_BCHAIN", &Options::fuse_bchain, 0, 2, true},
     {"chain_timeout_ms", "F8_CHAIN_TIMEOUT_MS", &Options::chain_timeout_ms, 0, 1 << 20, false},
@@ -906,7 +907,8 @@ static void plan_bottleneck_blocks(f8_net* net, int max_batch) {
         const int C = a0.cd.cin, MID = a0.cd.cout;
         if (c.cd.cout != C || b.cd.cin != MID || b.cd.cout != MID || c.cd.cin != MID) continue;
         int R = 0;
-        const bool chainable = opt.fuse_chain && a0.cd.quant_input && chain_supported(C, MID, x.H, x.W, C);   // pass 1f decides; R = 0: no stand-alone launch
+        const bool chainable = opt.fuse_chain && a0.cd.quant_input && chain_supported(C, MID, x.H, x.W, C) &&    // pass 1f decides; R = 0: no stand-alone launch
+                               (opt.fuse_chain7 || !cchain_supported(C, MID, x.H, x.W, C));
         if (!fused_bottleneck_supported(C, MID, x.H, x.W, opt.whole_batch_launches ? max_batch : std::max(1, max_batch / opt.split), opt.fuse_stages, &R) && !chainable) {
             // no whole-block instance (the 7x7 maps of stage 3): body.0 + body.2 as one launch, the residual-carrying 1x1 stays
             if (opt.fuse_p12 && fused_p12_supported(C, MID, x.H, x.W) && a0.cd.relu && b.cd.relu && tb.consumers.size() == 1) {
@@ -1286,6 +1288,11 @@ static void plan_last_conv_and_pool(f8_net* net, int max_batch) {
         int ci = t.prod;
         if (ND[ci].kind == N_ADD) { if (ND[ci].fused_into < 0) continue; ci = ND[ci].fused_into; }
         Node& c = ND[ci];
+        if (c.kind == N_CONV && c.chain_into == ci && c.fused_add >= 0 && ND[c.fused_add].out == p.a && p.out != net->out_t && !ND[c.chain[0]].tail && ND[c.chain[0]].fb_a >= 0 &&
+            cchain_supported(c.cd.cout, c.cd.cin, t.H, t.W, ND[ND[c.chain[0]].fb_a].cd.cin)) {
+            c.pool = i; p.pool_host = ci;                         // the last block of a 7x7 cluster chain: the pool is summed from its stream registers (f8_cchain.hip)
+            continue;
+        }
         if (c.kind != N_CONV || c.absorbed_by >= 0 || c.dual >= 0 || c.dual_host >= 0 || c.fb_a >= 0 || c.fbd_a >= 0 || c.chain_into >= 0 || c.bchain_into >= 0 ||
             c.ir_a >= 0 || c.p12_a >= 0 || c.bb_a >= 0 || c.h2_head >= 0 || c.cd.groups != 1 || c.cd.kernel != 1 || c.cd.stride != 1 || c.cd.pad != 0 || !c.cd.quant_input) continue;
         if ((c.fused_add >= 0 ? ND[c.fused_add].out : c.out) != p.a) continue;
@@ -1576,19 +1583,24 @@ static int emit_steps(f8_net* net, int max_batch) {
                         }
                     }
                     out_t = ND[nd.fused_add].out;
+                    Tensor& o = T[out_t];                        // the stage's output map (geometry of the chain)
+                    if (nd.pool >= 0) {                          // ... summed over its pixels in the launch (1i): the step's outputs are the POOLED tensor's forms
+                        out_t = ND[nd.pool].out;
+                        if (T[out_t].forms.empty()) add_form(T[out_t], FORM_I32, 0, 0);
+                    }
                     select_outputs(net, out_t, &st.out, &extra);
-                    Tensor& o = T[out_t];
-                    const double px = (double)o.H * o.W;
+                    const double px = (double)o.H * o.W, opx = nd.pool >= 0 ? 1.0 : px;
                     double b = tail ? px * (x.Cs + T[st.src2_t].Cs) : px * x.Cs * (ds ? 1 : 4);   // the stage input, once (tail: the shortcut's pixels + mid2)
-                    if (st.out.f32 >= 0) b += px * o.Cs * 4;
-                    for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += px * o.Cs;
+                    if (st.out.f32 >= 0) b += opx * o.Cs * 4;
+                    for (int k = 0; k < 2; ++k) if (st.out.f8[k] >= 0) b += opx * o.Cs;
                     st.ops_per_img = ops; st.bytes_per_img = b; st.bytes_const = wbytes;
                     {   // per block: body.0's and body.2's int8 outputs (the TAIL join has none), the join, the next block's int8 input (last block: the output forms)
                         const double mid = (double)(tail ? ND[hf.dual].cd.cin : ND[ds ? hf.fbd_a : hf.fb_a].cd.cout);
-                        st.valu_per_img = px * ((double)(ch.size() - (tail ? 1 : 0)) * 2.0 * mid * 3.0 + (double)ch.size() * o.C * 2.0 + (double)(ch.size() - 1) * o.C * 3.0 + 3.0 * o.Cs * out_forms8(st));
+                        st.valu_per_img = px * ((double)(ch.size() - (tail ? 1 : 0)) * 2.0 * mid * 3.0 + (double)ch.size() * o.C * 2.0 + (double)(ch.size() - 1) * o.C * 3.0) +
+                                          opx * 3.0 * o.Cs * out_forms8(st) + (nd.pool >= 0 ? px * o.C : 0.0);
                     }
                     const Node& a0 = tail ? ND[hf.dual] : ND[ds ? hf.fbd_a : hf.fb_a];
-                    st.name = "stage_chain_x" + std::to_string(ch.size()) + (tail ? "_tail:" : (ds ? "_ds:" : ":")) + tname(net, a0.out) + ".." + tname(net, nd.out);
+                    st.name = "stage_chain_x" + std::to_string(ch.size()) + (tail ? "_tail" : (ds ? "_ds" : "")) + (nd.pool >= 0 ? "+avgpool:" : ":") + tname(net, a0.out) + ".." + tname(net, nd.out);
                     char kb[160];
                     const int C = o.C, MID = tail ? a0.cd.cin : a0.cd.cout;
                     int cR = 4, cW = 1;
@@ -2178,7 +2190,13 @@ int f8_net_upload(f8_net* net) {
     if ((e = hipMemset(net->d_err, 0, 256)) != hipSuccess) return hip_fail(e, "hipMemset(error words)");
     for (const Step& st : net->steps)
         if ((st.kind == S_CHAIN || st.kind == S_BCHAIN) && !net->d_chain) {
-            net->chain_stride = round_up_z(4096 + kChainXchgBytes, 4096);
+            size_t xchg = kChainXchgBytes;
+            for (const Step& c7 : net->steps)
+                if (c7.kind == S_CHAIN && !net->nodes[net->nodes[c7.node].chain[0]].tail) {
+                    const Tensor& o7 = net->tensors[net->nodes[net->nodes[c7.node].fused_add].out];   // the stage's map (c7.out.t: the pooled tensor when the pool runs in the launch)
+                    if (cchain_supported(o7.C, net->nodes[net->nodes[c7.node].chain[0]].cd.cin, o7.H, o7.W, o7.C)) xchg = std::max(xchg, cchain_xchg_bytes());
+                }
+            net->chain_stride = round_up_z(4096 + xchg, 4096);
             if ((e = hipMalloc((void**)&net->d_chain, net->chain_stride * parts_cap)) != hipSuccess) return hip_fail(e, "hipMalloc(chain scratch)");
             if ((e = hipMemset(net->d_chain, 0, net->chain_stride * parts_cap)) != hipSuccess) return hip_fail(e, "hipMemset(chain scratch)");
             // a host-visible mirror of the error word: a chain launch that gives up a halo wait stores its code there as well, and f8_net_run looks at it
@@ -2437,8 +2455,9 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             if (ds) a.x8in = (const int8_t*)fp(xF); else a.xr = (const int32_t*)fp(xF);
             if (tail) { a.tail = 1; a.m2in = (const int8_t*)fp(T[st.src2_t].forms[st.src2_f]); }
             const Node& a0 = tail ? net->nodes[hf.dual] : net->nodes[ds ? hf.fbd_a : hf.fb_a];
-            const Tensor& oT = T[st.out.t];
+            const Tensor& oT = T[net->nodes[nd.fused_add].out];      // the stage's output map (st.out.t: the pooled tensor when the pool runs in the launch)
             const int C = oT.C, MID = tail ? a0.cd.cin : a0.cd.cout;
+            a.pool = nd.pool >= 0 ? 1 : 0;
             int wg_per_cu = 1;
             chain_shape(C, MID, oT.H, oT.W, tail ? hf.cd.cin : a0.cd.cin, tail, &a.R, &wg_per_cu);
             const int tiles = (oT.H + a.R - 1) / a.R;
@@ -2447,6 +2466,10 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             if (slots < tiles)
                 return fail(F8_ERR_STATE, "f8_net_run: a stage-chain launch needs %d co-resident workgroups per image, the device has %d compute units (plan with fuse_chain = 0 / fuse_bchain = 0)", tiles, net->num_cu);
             a.N = N; a.NG = chain_groups(N, slots / tiles);
+            if (!ds && cchain_supported(C, MID, oT.H, oT.W, a0.cd.cin)) {      // the 7x7 stage: clusters of eight workgroups, four images per cluster and round
+                a.NG = cchain_clusters(N, slots);
+                if (a.NG < 1) return fail(F8_ERR_STATE, "f8_net_run: the 7x7 stage-chain launch needs 8 co-resident workgroups, the device has %d compute units (plan with fuse_chain7 = 0)", net->num_cu);
+            }
             fill_out(&a.out32, a.q);
             if (!net->d_chain) return fail(F8_ERR_STATE, "f8_net_run: chain scratch missing");
             a.sync = (uint32_t*)(net->d_chain + (size_t)part * net->chain_stride);

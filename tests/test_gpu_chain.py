@@ -65,6 +65,9 @@ CHAINS = [
     (256, 64, 56, 2, 256, 2),
     (256, 64, 56, 3, 64, 2),
     (256, 64, 56, 3, 64, 21),
+    # 7x7 (ResNet-50 stage 3): f8_cchain.hip — clusters of eight workgroups over four images; N = 5: one whole group + one image, 130: 33 groups on 32 clusters
+    (2048, 512, 7, 2, 2048, 5),
+    (2048, 512, 7, 3, 2048, 130),
 ]
 
 
