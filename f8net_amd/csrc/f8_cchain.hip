@@ -80,6 +80,30 @@ __device__ __forceinline__ v4i cq_tile16(const v16i& y, int n, int lo, int hi, u
 
 #define F8_LDS3(p) ((__attribute__((address_space(3))) void*)(p))
 
+// Found with this kernel (round 6).  In the TAIL phase seven independent MFMAs (one per pixel tile) end a K step and the epilogue's vector code follows.
+// Left to itself the scheduler moved that code up INTO the last step: the float-converter instance (FAST = 1) read the first tile's accumulators one MFMA
+// + `s_nop 6` behind the MFMA that writes them, and wrote `v_cvt_f32_i32 v114, ...` in the slot after `v_mfma ..., v[114:117], ...` (a dying B operand, reused
+// at once).  That build returned a few pixels of a tile DIFFERENT FROM RUN TO RUN (tests/test_gpu_chain.py, requant_float=1 on the 7x7 TAIL chain; the
+// integer instance, scheduled differently, was exact); with the vector code kept behind the MFMAs it is bit-exact.  Which of the two adjacencies the
+// hardware does not interlock was not isolated (tools/asm_war_scan.py lists the second kind: it also occurs where results are right); the guard covers
+// both: nothing is scheduled across the end of an MFMA group (an `asm volatile` alone does not stop the machine scheduler — the first version of this
+// guard left the instructions where they were), plus wait states.
+#ifndef F8_CC_WAR_NOPS
+#define F8_CC_WAR_NOPS 16
+#endif
+__device__ __forceinline__ void mfma_operands_read() {
+#ifdef F8_CC_NO_GUARD       // (tuning / demonstration builds: the schedule the compiler picks by itself)
+    return;
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (F8_CC_WAR_NOPS >= 16) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+    else if constexpr (F8_CC_WAR_NOPS >= 8) asm volatile("s_nop 7" ::: "memory");
+    else if constexpr (F8_CC_WAR_NOPS >= 4) asm volatile("s_nop 3" ::: "memory");
+    else if constexpr (F8_CC_WAR_NOPS >= 2) asm volatile("s_nop 1" ::: "memory");
+    else if constexpr (F8_CC_WAR_NOPS >= 1) asm volatile("s_nop 0" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // barrier that leaves vector-memory operations (the LDS-DMA ring) in flight: __syncthreads() drains them (s_waitcnt vmcnt(0) in front of every s_barrier —
 // each ring stage then exposes its whole latency); LDS accesses are complete, and no memory access moves across it
 __device__ __forceinline__ void lds_barrier() {
@@ -166,7 +190,97 @@ cchain_kernel(const ChainArgs a) {
     for (int grp = cl; grp < ngroups; grp += ncl) {
         const int m0 = grp * Cfg::NPX;                         // first global pixel of the group
         // =============================== stage input: the stream (I32T) -> registers; its int8 form -> exchange
-        {
+        if (a.tail) {
+            // TAIL: the stream is BORN here — the join of the stage-opening block whose 3x3 and shortcut have stride 2 (fix_resnet.py:55-77):
+            //   stream = clamp(((Wsc . x(2p, 2q) + bsc) << sa) + ((W4 . mid2 + b4) << sr)) [ReLU],   K = 1024 + 512 for this wave's channel tile x 7 pixel tiles.
+            // At most one of sa, sr is non-zero and everything wraps mod 2^32, so BOTH products accumulate in the stream registers: first the operand
+            // that shifts, the shift, then the other one on top (one accumulator set instead of two: the registers hold nothing else yet).  K walks in six
+            // chunks of 8 K32 steps; a chunk's B fragments (7 pixel tiles x 8 steps, gathered from the NHWC tensors by LDS-DMA: one pixel tile per wave,
+            // the lane's pixel row is its offset) sit in one of two 64 KB LDS buffers, the wave's 8 weight fragments in registers, one chunk ahead.
+            const ChainBlk& B = a.blk[0];
+            const bool sc_first = B.res_shl == 0;                 // the shortcut's product shifts (or nothing does): it goes first
+            const __amdgpu_buffer_rsrc_t rxs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x8in, 0, (unsigned)(a.N * 196 * 1024), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rm2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.m2in, 0, (unsigned)(npix * 512), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rwsc = wrsrc(B.wsc), rw4 = wrsrc(B.w4);
+            unsigned vx, vm;                                       // this lane's pixel of pixel tile `wave` in the block input (stride 2) / in mid2
+            {
+                const int p = wave * 32 + l31, m = m0 + p;
+                const int pi = p / Cfg::PXI, rem = p - pi * Cfg::PXI, r = rem / 7, cc = rem - r * 7;
+                const bool ok = wave < NPT && p < Cfg::NPX && m < npix;
+                vx = ok ? (unsigned)((((grp * Cfg::IMG + pi) * 14 + 2 * r) * 14 + 2 * cc) * 1024 + lh * 16) : kOOB;
+                vm = ok ? (unsigned)(m * 512 + lh * 16) : kOOB;
+            }
+            auto chunk_is_sc = [&](int cq) { return sc_first ? cq < 4 : cq >= 2; };
+            auto chunk_k = [&](int cq) { return sc_first ? (cq < 4 ? cq : cq - 4) : (cq < 2 ? cq : cq - 2); };   // the chunk's index inside its operand's K
+            auto issue = [&](int cq) {                             // 8 fragments per wave: pixel tile `wave` (wave 7: nothing to fetch, zeros), K32 steps 8 k .. 8 k + 7
+                char* const buf = lds + (cq & 1) * 65536 + wave * 8192;
+                const bool sc = chunk_is_sc(cq);
+                const int k0 = chunk_k(cq) * 256;
+#pragma unroll
+                for (int st = 0; st < 8; ++st) {
+                    if (sc) __builtin_amdgcn_raw_ptr_buffer_load_lds(rxs, F8_LDS3(buf + st * 1024), 16, vx, k0 + st * 32, 0, 0);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rm2, F8_LDS3(buf + st * 1024), 16, vm, k0 + st * 32, 0, 0);
+                }
+            };
+            v4i wa[2][8];
+            auto load_w = [&](v4i (&dst)[8], int cq) {
+                const bool sc = chunk_is_sc(cq);
+                const int f0 = (ct * (sc ? 32 : 16) + chunk_k(cq) * 8) * 1024;
+#pragma unroll
+                for (int st = 0; st < 8; ++st) dst[st] = sc ? __builtin_amdgcn_raw_buffer_load_b128(rwsc, l16, f0 + st * 1024, 0) : __builtin_amdgcn_raw_buffer_load_b128(rw4, l16, f0 + st * 1024, 0);
+            };
+            issue(0);
+            load_w(wa[0], 0);
+            {   // the first operand's bias: the accumulators' start value
+                const int32_t* const bf = sc_first ? B.bsc : B.b4;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const v4i bv = *(const v4i*)(bf + ct * 32 + 8 * g + 4 * lh);
+#pragma unroll
+                    for (int j = 0; j < NPT; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) res[j][4 * g + e] = bv[e];
+                }
+            }
+            static_for<6>([&](auto qc) {
+                constexpr int Q = decltype(qc)::value;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                lds_barrier();                                    // chunk Q is in LDS; everybody is past chunk Q - 1: its buffer takes chunk Q + 1
+                if constexpr (Q + 1 < 6) { issue(Q + 1); load_w(wa[(Q + 1) & 1], Q + 1); }
+                const char* const buf = lds + (Q & 1) * 65536;
+#pragma unroll
+                for (int st = 0; st < 8; ++st)
+#pragma unroll
+                    for (int j = 0; j < NPT; ++j) {
+                        const v4i xf = *(const v4i*)(buf + (j * 8 + st) * 1024 + l16);
+                        res[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wa[Q & 1][st], xf, res[j], 0, 0, 0);
+                    }
+                mfma_operands_read();
+                if ((sc_first && Q == 3) || (!sc_first && Q == 1)) {       // the first operand is complete: its shift, then the second one's bias
+                    const int sh = sc_first ? B.acc_shl : B.res_shl;
+                    const int32_t* const bs = sc_first ? B.b4 : B.bsc;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const v4i bv = *(const v4i*)(bs + ct * 32 + 8 * g + 4 * lh);
+#pragma unroll
+                        for (int j = 0; j < NPT; ++j)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) res[j][4 * g + e] = (int)(((unsigned)res[j][4 * g + e] << sh) + (unsigned)bv[e]);
+                    }
+                }
+            });
+            const int floor1 = B.relu1 ? 0 : -2147483647;         // the join's clamp_(min=-(2^31-1)) and the ReLU floor are one max
+            const ChainBlk& B1 = a.blk[1];
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) res[j][r] = max(res[j][r], floor1);
+                const v4i o = cq_tile16<FAST>(res[j], B1.nq, FAST ? 0 : B1.loq, FAST ? 255 : B1.hiq, FAST ? 0x80808080u : B1.xorq);
+                __builtin_amdgcn_raw_buffer_store_b128(o, rxc, l16, (j * NK1 + ct) * 1024, 17);
+            }
+            publish();
+            F8_CT(0);
+        } else {
             const ChainBlk& B0 = a.blk[0];
             const __amdgpu_buffer_rsrc_t rxr = __builtin_amdgcn_make_buffer_rsrc((void*)a.xr, 0, (unsigned)(((npix + 31) & ~31) * C * 4), 0x00020000);
 #pragma unroll
@@ -189,7 +303,7 @@ cchain_kernel(const ChainArgs a) {
             F8_CT(0);
         }
 
-        for (int b = 0; b < a.nblk; ++b) {
+        for (int b = a.tail ? 1 : 0; b < a.nblk; ++b) {
             const ChainBlk& B = a.blk[b];
             const bool last = b + 1 == a.nblk;
             const ChainBlk& BN = a.blk[last ? b : b + 1];
@@ -257,6 +371,7 @@ cchain_kernel(const ChainArgs a) {
                         acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[1][0], 0, 0, 0);
                         acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
                     }
+                    mfma_operands_read();
                 });
                 F8_CT(2);
                 __syncthreads();                                // the ring is dead: its bytes carry the K halves' exchange
@@ -357,6 +472,7 @@ cchain_kernel(const ChainArgs a) {
                         acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[1][0], 0, 0, 0);
                         acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
                     }
+                    mfma_operands_read();
                 });
                 F8_CT(5);
                 __syncthreads();                                // nobody reads the patch any more: its bytes carry the K halves' exchange
@@ -423,6 +539,7 @@ cchain_kernel(const ChainArgs a) {
                         if (k == 0) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wst[k], xf, breg, 0, 0, 0);
                         else acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wst[k], xf, acc, 0, 0, 0);
                     }
+                    mfma_operands_read();
                     v16i& rr = res[J];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -522,7 +639,8 @@ cchain_kernel(const ChainArgs a) {
 #endif
 }
 
-bool cchain_supported(int C, int MID, int H, int W, int cin0) { return C == 2048 && MID == 512 && H == 7 && W == 7 && cin0 == 2048; }
+// identity blocks only (cin0 = C: the stage's int32 stream comes in), or — tail — the JOIN of the stride-2 opening block first (cin0 = the block input's channels)
+bool cchain_supported(int C, int MID, int H, int W, int cin0, bool tail) { return C == 2048 && MID == 512 && H == 7 && W == 7 && cin0 == (tail ? 1024 : 2048); }
 size_t cchain_xchg_bytes() { return kCChainXchgBytes; }
 // clusters (of 8 workgroups, 4 images per round) a launch over N images starts on a device with `slots` free compute units
 int cchain_clusters(int N, int slots) {
@@ -542,7 +660,7 @@ static hipError_t launch_cchain_t(const ChainArgs& a, hipStream_t s) {
         if (attr_dev >= 0) attr_done |= 1ull << attr_dev;
     }
     const int grid = a.NG * CCfg::G;
-    if (a.NG < 1 || grid > 256 || !a.xr || a.tail) return hipErrorInvalidValue;
+    if (a.NG < 1 || grid > 256 || (a.tail ? (!a.x8in || !a.m2in || a.nblk < 2) : !a.xr)) return hipErrorInvalidValue;
 #ifdef F8_TRACE
     static unsigned* tbuf = nullptr; static int count = 0;
     static const int want = [] { const char* e = getenv("F8_TRACE_CHAIN7"); return e ? atoi(e) : -1; }();

@@ -926,7 +926,7 @@ chain_kernel(const ChainArgs a) {
 
 // instances: ResNet-50 stage 0 (opening block + identity blocks, 56x56), stage 1 (28x28), stage 2 (14x14) identity chains
 bool chain_supported(int C, int MID, int H, int W, int cin0) {
-    if (cchain_supported(C, MID, H, W, cin0)) return true;     // 7x7: the cluster kernel (f8_cchain.hip)
+    if (cchain_supported(C, MID, H, W, cin0, false)) return true;     // 7x7: the cluster kernel (f8_cchain.hip)
     if (C == 256 && MID == 64 && H == 56 && W == 56 && (cin0 == 64 || cin0 == 256)) return true;
     if (C == 512 && MID == 128 && H == 28 && W == 28 && cin0 == 512) return true;
     if (C == 1024 && MID == 256 && H == 14 && W == 14 && cin0 == 1024) return true;
@@ -934,6 +934,7 @@ bool chain_supported(int C, int MID, int H, int W, int cin0) {
 }
 // ... starting with the JOIN of a stride-2 opening block (TAIL): H, W = the stage's resolution, cin0 = the block input's channels
 bool chain_tail_supported(int C, int MID, int H, int W, int cin0) {
+    if (cchain_supported(C, MID, H, W, cin0, true)) return true;
     return (C == 512 && MID == 128 && H == 28 && W == 28 && cin0 == 256) || (C == 1024 && MID == 256 && H == 14 && W == 14 && cin0 == 512);
 }
 int chain_max_blocks(int C, int MID, int H, int W, int cin0, bool tail) { (void)C; (void)MID; (void)H; (void)W; (void)cin0; (void)tail; return kChainMaxBlocks; }
@@ -1046,7 +1047,7 @@ static bool chain_rot(int H, bool tail) {
 #endif
 }
 int chain_kernel_name(char* buf, size_t cap, int C, int MID, int H, int W, int cin0, bool tail, int fast) {
-    if (!tail && cchain_supported(C, MID, H, W, cin0)) return cchain_kernel_name(buf, cap, fast);
+    if (cchain_supported(C, MID, H, W, cin0, tail)) return cchain_kernel_name(buf, cap, fast);
     int R = 4, wg = 1;
     chain_shape(C, MID, H, W, cin0, tail, &R, &wg);
     const char* nb = MID == 64 ? F8_STR(F8_CH_S0) : (MID == 128 ? F8_STR(F8_CH_S1) : F8_STR(F8_CH_S2));
@@ -1060,7 +1061,7 @@ hipError_t launch_chain(const ChainArgs& a, int C, int MID, int H, int W, int ci
     if (a.nblk < 1 || a.nblk > kChainMaxBlocks) return hipErrorInvalidValue;
     const int fast = chain_fast(a);
     if (launched) chain_kernel_name(launched, cap, C, MID, H, W, cin0, a.tail != 0, fast);
-    if (!a.tail && cchain_supported(C, MID, H, W, cin0)) return launch_cchain(a, fast, s);
+    if (cchain_supported(C, MID, H, W, cin0, a.tail != 0)) return launch_cchain(a, fast, s);
 #define F8_CHAIN_INST(...) (fast == 1 ? launch_chain_t<__VA_ARGS__, 1, F8_CHAIN_ROT>(a, s) : fast == 2 ? launch_chain_t<__VA_ARGS__, 2, F8_CHAIN_ROT>(a, s) : launch_chain_t<__VA_ARGS__, 0, F8_CHAIN_ROT>(a, s))
 #define F8_CHAIN_ROT false
 #if F8_CH_R2_S0

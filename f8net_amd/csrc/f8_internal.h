@@ -338,7 +338,7 @@ void chain_shape(int C, int MID, int H, int W, int cin0, bool tail, int* R, int*
 hipError_t launch_chain(const ChainArgs& a, int C, int MID, int H, int W, int cin0, hipStream_t s, char* launched = nullptr, size_t cap = 0);   // launched: the symbol it started
 int chain_kernel_name(char* buf, size_t cap, int C, int MID, int H, int W, int cin0, bool tail, int fast);   // the symbol launch_chain starts (f8_chain.hip)
 // the identity blocks of a 7x7 bottleneck stage over clusters of eight workgroups (f8_cchain.hip): reached through chain_supported / launch_chain
-bool cchain_supported(int C, int MID, int H, int W, int cin0);
+bool cchain_supported(int C, int MID, int H, int W, int cin0, bool tail);   // tail: the join of the stride-2 opening block as the first block (cin0 = its input channels)
 size_t cchain_xchg_bytes();                                      // exchange scratch of a launch (per arena copy)
 int cchain_clusters(int N, int slots);                           // clusters (ChainArgs::NG) a launch over N images starts on `slots` compute units
 int cchain_kernel_name(char* buf, size_t cap, int fast);

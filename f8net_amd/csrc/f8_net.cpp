@@ -908,7 +908,7 @@ static void plan_bottleneck_blocks(f8_net* net, int max_batch) {
         if (c.cd.cout != C || b.cd.cin != MID || b.cd.cout != MID || c.cd.cin != MID) continue;
         int R = 0;
         const bool chainable = opt.fuse_chain && a0.cd.quant_input && chain_supported(C, MID, x.H, x.W, C) &&    // pass 1f decides; R = 0: no stand-alone launch
-                               (opt.fuse_chain7 || !cchain_supported(C, MID, x.H, x.W, C));
+                               (opt.fuse_chain7 || !cchain_supported(C, MID, x.H, x.W, C, false));
         if (!fused_bottleneck_supported(C, MID, x.H, x.W, opt.whole_batch_launches ? max_batch : std::max(1, max_batch / opt.split), opt.fuse_stages, &R) && !chainable) {
             // no whole-block instance (the 7x7 maps of stage 3): body.0 + body.2 as one launch, the residual-carrying 1x1 stays
             if (opt.fuse_p12 && fused_p12_supported(C, MID, x.H, x.W) && a0.cd.relu && b.cd.relu && tb.consumers.size() == 1) {
@@ -1041,6 +1041,7 @@ static void plan_stage_chains(f8_net* net, int max_batch) {
             Blk first;
             if (!block_of(i, &first)) continue;
             if (first.tail ? !chain_tail_supported(first.C, first.MID, first.H, first.W, first.cin0) : !chain_supported(first.C, first.MID, first.H, first.W, first.cin0)) continue;
+            if (!opt.fuse_chain7 && cchain_supported(first.C, first.MID, first.H, first.W, first.cin0, first.tail)) continue;
             std::vector<int> hosts{first.host};
             Blk cur = first;
             const int max_blocks = chain_max_blocks(first.C, first.MID, first.H, first.W, first.cin0, first.tail);
@@ -1288,8 +1289,8 @@ static void plan_last_conv_and_pool(f8_net* net, int max_batch) {
         int ci = t.prod;
         if (ND[ci].kind == N_ADD) { if (ND[ci].fused_into < 0) continue; ci = ND[ci].fused_into; }
         Node& c = ND[ci];
-        if (c.kind == N_CONV && c.chain_into == ci && c.fused_add >= 0 && ND[c.fused_add].out == p.a && p.out != net->out_t && !ND[c.chain[0]].tail && ND[c.chain[0]].fb_a >= 0 &&
-            cchain_supported(c.cd.cout, c.cd.cin, t.H, t.W, ND[ND[c.chain[0]].fb_a].cd.cin)) {
+        if (c.kind == N_CONV && c.chain_into == ci && c.fused_add >= 0 && ND[c.fused_add].out == p.a && p.out != net->out_t &&
+            cchain_supported(c.cd.cout, c.cd.cin, t.H, t.W, c.cd.cout, false)) {      // (geometry: a chain's last block is an identity block)
             c.pool = i; p.pool_host = ci;                         // the last block of a 7x7 cluster chain: the pool is summed from its stream registers (f8_cchain.hip)
             continue;
         }
@@ -2192,9 +2193,9 @@ int f8_net_upload(f8_net* net) {
         if ((st.kind == S_CHAIN || st.kind == S_BCHAIN) && !net->d_chain) {
             size_t xchg = kChainXchgBytes;
             for (const Step& c7 : net->steps)
-                if (c7.kind == S_CHAIN && !net->nodes[net->nodes[c7.node].chain[0]].tail) {
+                if (c7.kind == S_CHAIN) {
                     const Tensor& o7 = net->tensors[net->nodes[net->nodes[c7.node].fused_add].out];   // the stage's map (c7.out.t: the pooled tensor when the pool runs in the launch)
-                    if (cchain_supported(o7.C, net->nodes[net->nodes[c7.node].chain[0]].cd.cin, o7.H, o7.W, o7.C)) xchg = std::max(xchg, cchain_xchg_bytes());
+                    if (cchain_supported(o7.C, net->nodes[c7.node].cd.cin, o7.H, o7.W, o7.C, false)) xchg = std::max(xchg, cchain_xchg_bytes());   // (geometry; the last host is an identity block's body.4)
                 }
             net->chain_stride = round_up_z(4096 + xchg, 4096);
             if ((e = hipMalloc((void**)&net->d_chain, net->chain_stride * parts_cap)) != hipSuccess) return hip_fail(e, "hipMalloc(chain scratch)");
@@ -2466,7 +2467,7 @@ static int run_step(f8_net* net, const Step& st, const int32_t* input, void* out
             if (slots < tiles)
                 return fail(F8_ERR_STATE, "f8_net_run: a stage-chain launch needs %d co-resident workgroups per image, the device has %d compute units (plan with fuse_chain = 0 / fuse_bchain = 0)", tiles, net->num_cu);
             a.N = N; a.NG = chain_groups(N, slots / tiles);
-            if (!ds && cchain_supported(C, MID, oT.H, oT.W, a0.cd.cin)) {      // the 7x7 stage: clusters of eight workgroups, four images per cluster and round
+            if ((!ds || tail) && cchain_supported(C, MID, oT.H, oT.W, tail ? hf.cd.cin : a0.cd.cin, tail)) {      // the 7x7 stage: clusters of eight workgroups, four images per cluster and round
                 a.NG = cchain_clusters(N, slots);
                 if (a.NG < 1) return fail(F8_ERR_STATE, "f8_net_run: the 7x7 stage-chain launch needs 8 co-resident workgroups, the device has %d compute units (plan with fuse_chain7 = 0)", net->num_cu);
             }

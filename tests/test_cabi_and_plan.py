@@ -126,15 +126,22 @@ def test_plan_runs_each_stage_as_one_chain_launch():
         lines = net.describe().splitlines()
         chains = [l for l in lines if 'stage_chain_x' in l]
         # stage 0: opened by its (same-resolution) opening block; stages 1 and 2: by the JOIN of their stride-2 opening block (round 4: TAIL)
-        assert [l.split()[1].split(':')[0] for l in chains] == ['stage_chain_x3_ds', 'stage_chain_x4_tail', 'stage_chain_x6_tail'], net.describe()
-        assert all('i32=0' in l and 'i8=1' in l for l in chains)          # the next stage's opening block reads int8 only
+        # ... and stage 3 (round 6, f8_cchain.hip: clusters of eight workgroups) with the average pool behind its last block
+        assert [l.split()[1].split(':')[0] for l in chains] == ['stage_chain_x3_ds', 'stage_chain_x4_tail', 'stage_chain_x6_tail', 'stage_chain_x3_tail+avgpool'], net.describe()
+        assert all('i32=0' in l and 'i8=1' in l for l in chains)          # the next stage's opening block (the classifier) reads int8 only
         assert not any('fused_bottleneck' in l for l in lines)
         assert 'stage_0_layer_0.body.0..stage_0_layer_2.body.4' in chains[0] and 'stage_2_layer_0.body.4..stage_2_layer_5.body.4' in chains[2]
+        assert 'stage_3_layer_0.body.4..stage_3_layer_2.body.4' in chains[3] and not any('avgpool_sum' in l or '_dual:' in l or 'fused_p12:' in l for l in lines)
         # body.0 + body.2 of the stage-1 opener are one launch that writes mid2 as int8; no int32 tensor exists between a stage's blocks or in front of its chain
         opener = [l for l in lines if 'fused_opener_s2' in l]
         assert len(opener) == 1 and 'fused_opener_s2_p12' in opener[0] and 'i32=0 i8=1' in opener[0]
-        assert sum('i32=1' in l for l in lines) == 2                      # stage 3: its opener's join and the first 7x7 identity join (the last one is pooled in its launch)
-    assert net.num_launches <= 16
+        assert sum('i32=1' in l for l in lines) == 0                      # no int32 tensor is left in HBM anywhere in the network
+        # option fuse_chain7 = 0: the 7x7 stage as rounds 3 - 5 ran it — dual-GEMM join, fused_p12 + residual-carrying 1x1 per identity block, last join + pool
+        old = build_net(spec, synth.make_params(spec, 1234, topology.R50_NVIDIA_FRACLENS), max_batch=mb, hw=224, options={'fuse_chain7': 0}).describe().splitlines()
+        assert [l.split()[1].split(':')[0] for l in old if 'stage_chain_x' in l] == ['stage_chain_x3_ds', 'stage_chain_x4_tail', 'stage_chain_x6_tail']
+        assert sum('fused_p12:' in l for l in old) == 2 and sum('_dual:' in l for l in old) == 1 and sum('_res+avgpool:' in l for l in old) == 1
+        assert sum('i32=1' in l for l in old) == 2                        # stage 3: its opener's join and the first 7x7 identity join (the last one is pooled in its launch)
+    assert net.num_launches <= 12
     off = build_net(spec, synth.make_params(spec, 1234, topology.R50_NVIDIA_FRACLENS), max_batch=128, hw=224, options={'fuse_tail': 0}).describe()
     assert 'stage_chain_x3:' in off and 'stage_chain_x5:' in off and '_tail' not in off and '_p12_R' not in off      # the round-3 plan
     # ResNet-18 / MobileNets have no bottleneck blocks: nothing changes for them
@@ -229,7 +236,7 @@ def test_smoke_plans_hold_the_kernels_smoke_asserts():
     change that silently drops one of them would otherwise only fail on the GPU box)."""
     r50 = topology.get('resnet50', normalize=True)
     plan = build_net(r50, synth.make_params(r50, seed=3, fraclens=topology.R50_NVIDIA_FRACLENS), max_batch=2, hw=224).describe()
-    assert all(k in plan for k in ('stem7x7s2+maxpool3x3s2', 'stage_chain_x3_ds', 'stage_chain_x6_tail', 'fused_opener_s2_p12', '_dual', 'fused_p12:')), plan
+    assert all(k in plan for k in ('stem7x7s2+maxpool3x3s2', 'stage_chain_x3_ds', 'stage_chain_x6_tail', 'fused_opener_s2_p12', 'stage_chain_x3_tail+avgpool')), plan
     r18 = topology.get('resnet18')
     plan = build_net(r18, synth.make_params(r18, seed=3), max_batch=2, hw=224).describe()
     assert 'basic_chain_x2_ds' in plan and 'patch' in plan, plan
@@ -300,8 +307,10 @@ def test_planner_bounds_the_residual_stream_before_it_plans_the_float_requantisa
     """f8_net.cpp tensor_amax: the int32 stream of a chain launch is the shifted sum of bounded conv accumulators; the float-converter instance
     (template argument 1; option requant_float = 1) is planned only while that bound (and every accumulator's) stays below 2^31 - 2^16 — a bias that
     lifts ONE stream channel next to 2^31 plans the integer instance (2) for that launch alone; the default (requant_float = 0) plans it for every launch."""
-    def chains(net):
-        return [net.launch_kernel(i) for i in range(net.num_launches) if 'chain_kernel<' in net.launch_kernel(i)]
+    def chains(net):     # (the 56x56 / 28x28 / 14x14 launches; the 7x7 cluster chain, f8::cchain_kernel<instance>, below)
+        return [net.launch_kernel(i) for i in range(net.num_launches) if '::chain_kernel<' in net.launch_kernel(i) or 'bchain_kernel<' in net.launch_kernel(i)]
+    def cchain(net):
+        return [net.launch_kernel(i) for i in range(net.num_launches) if 'cchain_kernel<' in net.launch_kernel(i)]
     r50 = topology.get('resnet50', normalize=True)
     p = synth.reference_params(r50)
     fl = {'requant_float': 1}
@@ -309,6 +318,7 @@ def test_planner_bounds_the_residual_stream_before_it_plans_the_float_requantisa
     assert len(ks) == 3 and all(re.search(r', 1, false, (false|true), [48]>$', k) for k in ks), ks
     ks = chains(build_net(r50, p, max_batch=8, hw=224))
     assert len(ks) == 3 and all(re.search(r', 2, false, (false|true), [48]>$', k) for k in ks), ks
+    assert cchain(build_net(r50, p, max_batch=8, hw=224, options=fl)) == ['f8::cchain_kernel<1>'] and cchain(build_net(r50, p, max_batch=8, hw=224)) == ['f8::cchain_kernel<2>']
     q = {k: (v.copy() if hasattr(v, 'copy') else v) for k, v in p.items()}
     q['stage_1_layer_2.body.4.bias'][5] = 2 ** 31 - 2 ** 18          # body.4 feeds only the stream: no accumulator that is requantised grows
     ks = chains(build_net(r50, q, max_batch=8, hw=224, options=fl))

@@ -195,7 +195,8 @@ def _run_stage_chain(dev, cfg, variant, tail, options=None, big_bias=False):
 # ... starting with the JOIN of the stage-opening block whose 3x3 and shortcut have stride 2 (fix_resnet.py:55-77; ResNet-50 stage 1): its body.0 +
 # body.2 run on f8_opener.hip (P12: mid2 -> HBM, int8), its join (body.4 + 1x1 / 2 shortcut) is the first block of the chain launch (TAIL)
 TAIL_CHAINS = [(512, 128, 28, 3, 256, 3), (512, 128, 28, 1, 256, 5), (512, 128, 28, 3, 256, 37),   # C, MID, H = W of the stage, identity blocks, CIN0, N
-               (1024, 256, 14, 2, 512, 3), (1024, 256, 14, 5, 512, 70)]          # ResNet-50 stage 2: the opener's convs are launches of their own, its dual-GEMM join opens the chain
+               (1024, 256, 14, 2, 512, 3), (1024, 256, 14, 5, 512, 70),          # ResNet-50 stage 2: the opener's convs are launches of their own, its dual-GEMM join opens the chain
+               (2048, 512, 7, 2, 1024, 5), (2048, 512, 7, 1, 1024, 130)]        # stage 3: the same on the cluster kernel (f8_cchain.hip)
 
 
 @pytest.mark.parametrize('cfg', TAIL_CHAINS, ids=lambda g: 'x'.join(map(str, g)))

@@ -257,8 +257,14 @@ def test_late_stage_kernels_equal_the_tile_per_workgroup_plan_at_every_batch_siz
     big = build_net(spec, params, max_batch=128, hw=224, options={'whole_batch_launches': 1})
     big.set_pipelined(2)
     plan = big.describe()
-    for name in ('conv1x1_wstat:', 'conv1x1_wstat_dual:', 'conv1x1_wstat_res:', 'conv3x3s2_wreg:', 'fused_p12:', 'linear_dense:', 'read by the stem launch'):
+    for name in ('conv1x1_wstat:', 'conv3x3s2_wreg:', 'stage_chain_x3_tail+avgpool:', 'linear_dense:', 'read by the stem launch'):    # stage 3: the cluster chain (f8_cchain.hip)
         assert name in plan, plan
+    # ... and the plan of rounds 3 - 5 for the 7x7 stage (option fuse_chain7 = 0): dual GEMM, fused_p12 + residual-carrying 1x1, join + pool
+    big7 = build_net(spec, params, max_batch=128, hw=224, options={'whole_batch_launches': 1, 'fuse_chain7': 0})
+    big7.set_pipelined(2)
+    plan7 = big7.describe()
+    for name in ('conv1x1_wstat:', 'conv1x1_wstat_dual:', 'conv1x1_wstat_res:', 'conv3x3s2_wreg:', 'fused_p12:', 'conv1x1_res+avgpool:', 'linear_dense:'):
+        assert name in plan7, plan7
     off = {'wstat': 0, 's2wreg': 0, 'fuse_p12': 0, 'wreg': 0, 'fuse_fc': 0, 'fuse_input': 0}
     ref = build_net(spec, params, max_batch=128, hw=224, options=off)
     assert not any(k in ref.describe() for k in ('wstat', 'wreg', 'fused_p12:', 'linear_dense'))
@@ -266,6 +272,8 @@ def test_late_stage_kernels_equal_the_tile_per_workgroup_plan_at_every_batch_siz
     for k in (1, 2, 3, 31, 33, 100, 127, 128):
         got = big.run(xd[:k].contiguous()).cpu().numpy()
         np.testing.assert_array_equal(got, full[:k])
+        if k in (1, 33, 128):
+            np.testing.assert_array_equal(big7.run(xd[:k].contiguous()).cpu().numpy(), full[:k])
     big.set_pipelined(False)
 
 
