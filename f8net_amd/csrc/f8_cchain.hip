@@ -371,8 +371,8 @@ cchain_kernel(const ChainArgs a) {
                         acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[1][0], 0, 0, 0);
                         acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
                     }
-                    mfma_operands_read();
                 });
+                mfma_operands_read();                           // (no vector instruction reads an accumulator inside the loop: one guard behind it)
                 F8_CT(2);
                 __syncthreads();                                // the ring is dead: its bytes carry the K halves' exchange
                 // wave (pp, kh) finishes channel tile kh of its two pixel tiles: it gives away its sums for tile 1 - kh and takes the partner's for tile kh
@@ -472,8 +472,8 @@ cchain_kernel(const ChainArgs a) {
                         acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[1][0], 0, 0, 0);
                         acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
                     }
-                    mfma_operands_read();
                 });
+                mfma_operands_read();                           // (no vector instruction reads an accumulator inside the loop: one guard behind it)
                 F8_CT(5);
                 __syncthreads();                                // nobody reads the patch any more: its bytes carry the K halves' exchange
 #pragma unroll
