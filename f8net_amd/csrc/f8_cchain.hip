@@ -84,10 +84,12 @@ __device__ __forceinline__ v4i cq_tile16(const v16i& y, int n, int lo, int hi, u
 // Left to itself the scheduler moved that code up INTO the last step: the float-converter instance (FAST = 1) read the first tile's accumulators one MFMA
 // + `s_nop 6` behind the MFMA that writes them, and wrote `v_cvt_f32_i32 v114, ...` in the slot after `v_mfma ..., v[114:117], ...` (a dying B operand, reused
 // at once).  That build returned a few pixels of a tile DIFFERENT FROM RUN TO RUN (tests/test_gpu_chain.py, requant_float=1 on the 7x7 TAIL chain; the
-// integer instance, scheduled differently, was exact); with the vector code kept behind the MFMAs it is bit-exact.  Which of the two adjacencies the
-// hardware does not interlock was not isolated (tools/asm_war_scan.py lists the second kind: it also occurs where results are right); the guard covers
-// both: nothing is scheduled across the end of an MFMA group (an `asm volatile` alone does not stop the machine scheduler — the first version of this
-// guard left the instructions where they were), plus wait states.
+// integer instance, scheduled differently, was exact); with the vector code kept behind the MFMAs it is bit-exact (every variant of this guard, 0 to 16
+// wait states).  The mechanism is NOT isolated: tools/ubench/ubench_mfma_hazard.hip (profiles/ubench_mfma_hazard_r06.txt) shows the hardware interlocks a
+// vector write to SrcA / SrcB right behind the MFMA (never a wrong result, with or without a backlog of MFMAs), and that a vector read of a result needs
+// 9 .. 16 wait states directly behind its MFMA, 3 .. 4 with one independent MFMA in between, none with two — the compiler's `s_nop 6` satisfies that.  What
+// is known is the cure: nothing is scheduled across the end of an MFMA group (an `asm volatile` alone does not stop the machine scheduler — the first
+// version of this guard left the instructions where they were), plus wait states.
 #ifndef F8_CC_WAR_NOPS
 #define F8_CC_WAR_NOPS 16
 #endif

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Static scan of device assembly for the write-after-read hazard found with f8_cchain.hip (round 6): a VECTOR instruction that writes a register which a
-v_mfma issued at most WINDOW instructions earlier reads as SrcA / SrcB.  Neither the hardware nor the compiler's hazard recogniser covers it on gfx950's
-16-byte-operand MFMAs; an occurrence is a latent bit error.   python tools/asm_war_scan.py file.s [window=2]"""
+"""Static scan of device assembly: vector instructions that write a register which a v_mfma issued at most WINDOW instructions earlier reads as SrcA /
+SrcB.  Written while hunting the run-to-run differences of f8_cchain.hip's float-converter instance (round 6); tools/ubench/ubench_mfma_hazard.hip then showed
+that gfx950 INTERLOCKS this write-after-read (no wrong result in 4 M trials at 0 .. 16 wait states), so an occurrence is NOT an error — the tool stays as a
+way to look at how close the compiler packs vector code behind MFMAs.   python tools/asm_war_scan.py file.s [window=2]"""
 import re
 import sys
 
