@@ -22,9 +22,11 @@ timeout 900 python bench.py --arch mobilenet_v2 --bs 128 --steps 200 --warmup 20
 timeout 900 python bench.py --arch resnet50 --bs 256 --steps 200 --warmup 20 --per-layer > $OUT/bench_${TAG}_resnet50_bs256.json 2> $OUT/perlayer_${TAG}_resnet50_bs256.txt
 # round 5: what bounds the chain launches — the P3 microbenchmark (vector throughput; 8 / 12 / 16 waves; ablations) and the per-wave phase cycle counters
 # of a -DF8_TRACE build (tools/build_trace.sh) for the three ResNet-50 instances; rocprofv3 --att has no decoder library on this image (att_probe)
+if [ -x tools/ubench/ubench_mfma_hazard.bin ]; then tools/ubench/ubench_mfma_hazard.bin > $OUT/ubench_mfma_hazard_$TAG.txt 2>&1; fi
 if [ -x tools/ubench/ubench_p3.bin ]; then tools/ubench/ubench_p3.bin > $OUT/ubench_p3_$TAG.txt 2>&1; fi
 if [ -f f8net_amd/libf8net_trace.so ]; then
   for k in 3 4 5; do F8NET_LIB=f8net_amd/libf8net_trace.so F8_TRACE_CHAIN=$k timeout 200 python tools/trace_run.py 2>&1 | grep -A12 "trace chain"; done > $OUT/chain_trace_$TAG.txt
+  F8NET_LIB=f8net_amd/libf8net_trace.so F8_TRACE_CHAIN7=3 timeout 200 python tools/trace_chain7.py 2>&1 | grep "trace cchain" > $OUT/cchain_trace_$TAG.txt      # round 6: the 7x7 cluster chain's phases
 fi
 (cd /tmp && TMPDIR=/tmp timeout 120 rocprofv3 --att --kernel-trace -d /tmp/att_probe -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -3) > $OUT/att_probe_$TAG.log 2>&1
 rm -rf gpurun_out/prof_*
