@@ -236,7 +236,7 @@ int f8_net_check(f8_net* net);
  * before f8_net_finalize (F8_ERR_STATE afterwards); scheduling keys may change between runs.
  *   planning  : split (1..4 concurrent sub-batches of a run), arena_copies (0 = split; more: that many whole runs in flight under
  *               f8_net_set_pipelined(2) with pipeline_depth), fuse_blocks, fuse_stages (bit mask, -1 = auto), fuse_dual,
- *               fuse_ds, fuse_opener, fuse_fc (the classifier writes the caller's logits buffer itself), fuse_stem, fuse_input (the fused stem launch reads the caller's NCHW buffer itself), fuse_ir (1 = where it wins, 2 = every block), fuse_chain (all consecutive bottleneck blocks of a stage in one launch, the int32 residual stream in registers; it takes precedence over fuse_stages and over the chunk56 / chunk28 / chunk14 keys for the stages it plans: set fuse_chain = 0 to get the per-block launches those keys govern), fuse_tail (the join of a stride-2 stage-opening block opens that launch: its int32 output never exists), fuse_pool (the network's last 1x1 conv, with its residual join, and the average pool behind it in one launch),
+ *               fuse_ds, fuse_opener, fuse_fc (the classifier writes the caller's logits buffer itself), fuse_stem, fuse_input (the fused stem launch reads the caller's NCHW buffer itself), fuse_ir (1 = where it wins, 2 = every block), fuse_chain (all consecutive bottleneck blocks of a stage in one launch, the int32 residual stream in registers; it takes precedence over fuse_stages and over the chunk56 / chunk28 / chunk14 keys for the stages it plans: set fuse_chain = 0 to get the per-block launches those keys govern), fuse_tail (the join of a stride-2 stage-opening block opens that launch: its int32 output never exists), fuse_chain7 (the 7x7 bottleneck stage — that join, its identity blocks and the average pool behind them — as one launch over clusters of eight workgroups, f8_cchain.hip; 0: the dual-GEMM / fused_p12 / residual-join launches of rounds 3 - 5), fuse_pool (the network's last 1x1 conv, with its residual join, and the average pool behind it in one launch),
  *               fuse_bchain (the same for BasicBlock stages: 1 = consecutive identity blocks, 2 = with the stage-opening block in front), stem_rows (ResNet head:
  *               row-walking kernel, pool in registers), fuse_head2 (MobileNet-V2: head conv + depthwise + 1x1 as one row-walking launch), dw_mma (depthwise
  *               3x3 on the matrix cores), shared_streams (internal streams are one set per device for all handles), fuse_p12 (7x7 block: first two
