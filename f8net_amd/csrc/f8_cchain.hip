@@ -651,7 +651,7 @@ int cchain_clusters(int N, int slots) {
     const int rounds = (groups + cap - 1) / cap;
     return (groups + rounds - 1) / rounds;                      // the fewest clusters that need no more rounds
 }
-int cchain_kernel_name(char* buf, size_t cap, int fast) { return snprintf(buf, cap, "f8::cchain_kernel<%d>", fast); }
+int cchain_kernel_name(char* buf, size_t cap, int fast) { return snprintf(buf, cap, "f8::cchain_kernel<%d>", fast != 0 ? 2 : 0); }
 
 template <int FAST>
 static hipError_t launch_cchain_t(const ChainArgs& a, hipStream_t s) {
@@ -690,9 +690,11 @@ static hipError_t launch_cchain_t(const ChainArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// fast: chain_fast(a) (f8_chain.hip)
+// fast: chain_fast(a) (f8_chain.hip).  There is NO float-converter instance (1) of this kernel: it was built, and its TAIL form returned a few wrong pixels in about every
+// second run of one test (tests/test_gpu_chain.py, requant_float=1, 130 images) — with the scheduling guard above in place, the integer instance beside it exact in every
+// run, soak and suite.  The integer form is exact for every value the float form takes, so plans with requant_float = 1 run instance 2 here.
 hipError_t launch_cchain(const ChainArgs& a, int fast, hipStream_t s) {
-    return fast == 1 ? launch_cchain_t<1>(a, s) : fast == 2 ? launch_cchain_t<2>(a, s) : launch_cchain_t<0>(a, s);
+    return fast != 0 ? launch_cchain_t<2>(a, s) : launch_cchain_t<0>(a, s);
 }
 
 }  // namespace f8

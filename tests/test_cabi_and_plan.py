@@ -318,7 +318,8 @@ def test_planner_bounds_the_residual_stream_before_it_plans_the_float_requantisa
     assert len(ks) == 3 and all(re.search(r', 1, false, (false|true), [48]>$', k) for k in ks), ks
     ks = chains(build_net(r50, p, max_batch=8, hw=224))
     assert len(ks) == 3 and all(re.search(r', 2, false, (false|true), [48]>$', k) for k in ks), ks
-    assert cchain(build_net(r50, p, max_batch=8, hw=224, options=fl)) == ['f8::cchain_kernel<1>'] and cchain(build_net(r50, p, max_batch=8, hw=224)) == ['f8::cchain_kernel<2>']
+    # (the 7x7 cluster chain has no float-converter instance: the integer one is exact wherever the float form is)
+    assert cchain(build_net(r50, p, max_batch=8, hw=224, options=fl)) == ['f8::cchain_kernel<2>'] and cchain(build_net(r50, p, max_batch=8, hw=224)) == ['f8::cchain_kernel<2>']
     q = {k: (v.copy() if hasattr(v, 'copy') else v) for k, v in p.items()}
     q['stage_1_layer_2.body.4.bias'][5] = 2 ** 31 - 2 ** 18          # body.4 feeds only the stream: no accumulator that is requantised grows
     ks = chains(build_net(r50, q, max_batch=8, hw=224, options=fl))

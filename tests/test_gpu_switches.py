@@ -99,6 +99,8 @@ def test_chunked_execution_is_bit_exact_with_ragged_chunks():
 # one process.  Each entry: options of one handle; results must equal the oracle bit for bit and the plan must change as stated.
 OPTION_SETS = [
     ({}, 'stage_chain_x6_tail'), ({'fuse_tail': 0}, 'stage_chain_x5'),      # the joins of the stride-2 opening blocks open their stages' chain launches / the round-3 plan
+    ({}, 'stage_chain_x3_tail+avgpool'), ({'fuse_chain7': 0}, 'fused_p12:'), ({'fuse_chain7': 0, 'requant_float': 1}, 'conv1x1_res+avgpool'),      # round 6: the 7x7 stage on the cluster kernel (f8_cchain.hip) / as rounds 3 - 5 ran it
+    ({'fuse_tail': 0, 'fuse_pool': 0}, 'stage_chain_x2:'),      # ... its identity-first form (the stream comes in as an int32 tensor) with the pool as a launch of its own
     ({'fuse_chain': 0}, 'fused_bottleneck_R'),
     ({'fuse_chain': 0, 'fuse_stages': 7}, 'fused_bottleneck_R7'),
     ({'fuse_chain': 0, 'fuse_ds': 0}, '_dual:'),

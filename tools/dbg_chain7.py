@@ -2,7 +2,9 @@
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import test_gpu_chain as tc
 
 def report(got, want, err_msg=''):
