@@ -80,7 +80,7 @@ def test_stage_chain_matches_oracle(dev, cfg, variant, tail):
     _run_stage_chain(dev, cfg, variant, tail)
 
 
-@pytest.mark.parametrize('cfg', [CHAINS[0], CHAINS[2], CHAINS[4], CHAINS[5]], ids=lambda g: 'x'.join(map(str, g)))
+@pytest.mark.parametrize('cfg', [CHAINS[0], CHAINS[2], CHAINS[4], CHAINS[5], CHAINS[7]], ids=lambda g: 'x'.join(map(str, g)))    # (CHAINS[7]: the 7x7 cluster chain has an integer instance only)
 @pytest.mark.parametrize('mode', ['requant_float=1', 'bias_near_2^31'])
 def test_stage_chain_float_requant_instances(dev, cfg, mode):
     """The float-converter requantisation (option `requant_float = 1`; the default plans the INTEGER form — shift / round-half-even / clamp,
